@@ -1,0 +1,101 @@
+/*
+ * vfa_hip.h -- C ABI of the MI355X (gfx950) multiview feature -> voxel projection + aggregation path.
+ *
+ * The reference (Jiahao-Ma/VFA) has no FFI on this path: its boundary is the Python call
+ * VFA.forward (vfa/model/vfa_op.py:61-125) and the camera loop of VFANet.forward
+ * (vfa/model/vfanet.py:64-82).  This header is the boundary the MI355X build introduces underneath
+ * that call; vfa_amd/vfa_op.py binds it with ctypes (see INTEGRATION.md for the stub a maintainer of
+ * the reference would add).  Each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm allocations in practice);
+ *     the library allocates nothing, keeps no global state and is re-entrant;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is stream-ordered
+ *     and asynchronous, nothing synchronises the device;
+ *   - return value: 0 on success, otherwise a hipError_t (launch failure) or VFA_ERR_* (bad argument);
+ *     nothing throws, nothing exits;
+ *   - fp32 everywhere, with the rounding sequence of the reference's PyTorch CPU path (SURVEY.md
+ *     Appendix A): the stage outputs are bit-identical to the reference up to the sign of zero of
+ *     masked voxels;
+ *   - `n_views` batches cameras that share feature-map and grid shapes (one scale of one frame).
+ *
+ * Layouts
+ *   feature   (n_views, C, Hf, Wf)          NCHW, as the reference's lateral maps
+ *   integral  (n_views, Hf, Wf, C)          channels-last, so one tap of one box is C contiguous floats
+ *   box       (n_views, nl, n_cells, 4)     left, top, right, bottom in normalised [-1,1] image coords
+ *   area      (n_views, nl, n_cells)
+ *   visible   (n_views, nl, n_cells)        0/1 bytes
+ *   vox       (n_views, cell_count, nl*C)   column = layer*C + c (VFA_VOX_LAYER_MAJOR) or
+ *                                           column = c*nl + layer (VFA_VOX_REFERENCE, vfa_op.py:120)
+ */
+#ifndef VFA_HIP_H
+#define VFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFA_ABI_VERSION 1
+
+/* world-unit conversion of the grid, reference vfa_op.py:23-44 (chosen by args.data) */
+#define VFA_CONV_MULTIVIEWC 0 /* x / 1.0                                   */
+#define VFA_CONV_MULTIVIEWX 1 /* x / 40.0 (true division)                  */
+#define VFA_CONV_WILDTRACK 2  /* x*2.5-300, y*2.5-900, z*2.5               */
+
+#define VFA_VOX_REFERENCE 0   /* vox[cell, c*nl + layer]   (vfa_op.py:120) */
+#define VFA_VOX_LAYER_MAJOR 1 /* vox[cell, layer*C + c]    (coalesced; collapse.weight columns permuted by the host) */
+
+#define VFA_ERR_BAD_ARGUMENT 10001
+
+/* ABI version of the loaded library (VFA_ABI_VERSION at build time). */
+int vfa_abi_version(void);
+
+/* Integral image of every feature map: cumsum over W then over H, double accumulator rounded to
+ * fp32 at every element (what ATen's CPU cumsum does).        replaces vfa_op.py:110, 172-173 */
+int vfa_integral_image_f32(const float *feature, float *integral, int n_views, int C, int Hf, int Wf,
+                           void *stream);
+
+/* Cube corners -> world units -> 3x4 projection -> normalise/clamp -> 2-D bounding box, area and
+ * visibility of every (view, layer, cell).                      replaces vfa_op.py:64-88, 104-106
+ * and vfa/utils.py:50-59 (project).
+ *   calibs (n_views, 3, 4); grid (n_cells, 3) cell origins in grid units; z_layers (nl);
+ *   corner_off (8, 3) in generate_cube order (vfa_op.py:127-133); img_w/img_h = args.image_size[::-1]. */
+int vfa_box_params_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off,
+                       int n_views, int n_cells, int nl, int conv_kind, float img_w, float img_h, int Hf, int Wf,
+                       float cmin, float cmax, float *box, float *area, uint8_t *visible, void *stream);
+
+/* Box pooling: four bilinear samples of the integral image at the box corners,
+ * vox = (((lt + rb) - rt) - lb) / area * visible.               replaces vfa_op.py:112-120
+ * Processes cells [cell_begin, cell_begin + cell_count) of every view so that the caller can bound
+ * the size of `vox` on large grids. */
+int vfa_gather_f32(const float *integral, const float *box, const float *area, const uint8_t *visible, float *vox,
+                   int n_views, int C, int Hf, int Wf, int nl, int n_cells, int cell_begin, int cell_count,
+                   int vox_layout, void *stream);
+
+/* Fused form of the two entry points above: every wave projects the eight cube corners of its box on
+ * eight lanes, reduces min/max with wave shuffles and pools; box/area/visible never touch memory. */
+int vfa_project_gather_f32(const float *integral, const float *calibs, const float *grid, const float *z_layers,
+                           const float *corner_off, float *vox, int n_views, int C, int Hf, int Wf, int nl,
+                           int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w, float img_h,
+                           float cmin, float cmax, int vox_layout, void *stream);
+
+/* Epilogue of `collapse` for one VFA call batch:  out = (accumulate ? out : 0) + sum_v relu(lin[v] + bias)
+ * with views added in index order.            replaces vfa_op.py:124 (ReLU) and vfanet.py:82 (view sum)
+ *   lin (n_views, M, N) = vox . W^T without bias; bias (N) or NULL; out (M, N). */
+int vfa_bias_relu_accumulate_f32(const float *lin, const float *bias, float *out, int n_views, size_t M, int N,
+                                 int accumulate, void *stream);
+
+/* Scale sum + view sum in the reference's order:
+ *   ortho = sum_v ((relu(lin8[v]+b8) + relu(lin16[v]+b16)) + relu(lin32[v]+b32))
+ *                                                               replaces vfanet.py:79 and :82 */
+int vfa_scale_view_sum_f32(const float *lin8, const float *lin16, const float *lin32, const float *bias8,
+                           const float *bias16, const float *bias32, float *ortho, int n_views, size_t M, int N,
+                           int accumulate, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFA_HIP_H */

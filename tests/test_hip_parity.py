@@ -1,0 +1,336 @@
+"""Parity of the HIP path (through the C ABI) with the reference: golden fixtures, the CPU oracle on seeded
+inputs, and size-independent properties at full workload sizes.   Run with ``-m gpu`` on an MI355X.
+
+Bar: every pre-GEMM stage tensor (integral, box, area, visible, vox) BITWISE equal to the reference
+(up to the sign of zero for masked voxels, which the kernel writes as +0 without computing them);
+post-GEMM maps within rtol 1e-4, atol 1e-5*max|ref| (the reference's own MKL summation order is not
+reproducible).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import VFA_CASES, VFANET_CASES, golden_path
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL_REL = 1e-4, 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bitwise(name, got, ref, zero_sign_free=False):
+    got, ref = np.asarray(got, dtype=np.float32), np.asarray(ref, dtype=np.float32)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    eq = _bits(got) == _bits(ref)
+    if zero_sign_free:
+        eq |= (got == 0) & (ref == 0)
+    assert eq.all(), f"{name}: {np.count_nonzero(~eq)} of {eq.size} elements differ bitwise " \
+                     f"(max abs diff {np.nanmax(np.abs(got - ref))})"
+
+
+def assert_close(name, got, ref):
+    ref = np.asarray(ref)
+    np.testing.assert_allclose(np.asarray(got), ref, rtol=RTOL, atol=ATOL_REL * np.abs(ref).max(), err_msg=name)
+
+
+def _meta(d):
+    return dict(data=str(d["data"]), image_size=tuple(int(v) for v in d["image_size"]),
+                cube_size=tuple(float(v) for v in d["cube_size"]), grid_height=float(d["grid_height"]))
+
+
+def _module(d, channel, dev, cube_size=None, grid_height=None):
+    import vfa_amd
+    m = _meta(d)
+    args = SimpleNamespace(data=m["data"], image_size=m["image_size"])
+    cs = tuple(d["cube_size"].tolist()) if cube_size is None else cube_size
+    gh = d["grid_height"].item() if grid_height is None else grid_height
+    # the fixtures were generated with integer cube sizes / heights where the values are integral
+    cs = tuple(int(v) if float(v).is_integer() else float(v) for v in cs)
+    gh = int(gh) if float(gh).is_integer() else float(gh)
+    return vfa_amd.VFA(channel, grid_height=gh, cube_size=cs, feat_scale=1, args=args).to(dev)
+
+
+def _to_layer_major(vox_ref, C, nl):
+    """reference column c*nl + layer -> layer*C + c."""
+    n_cells = vox_ref.shape[0]
+    return vox_ref.reshape(n_cells, C, nl).transpose(0, 2, 1).reshape(n_cells, nl * C)
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures generated from the reference itself
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", VFA_CASES)
+def test_stages_bitwise_vs_reference_fixture(case):
+    from vfa_amd import _lib, ops
+    dev = _dev()
+    d = np.load(golden_path(case))
+    C, Hf, Wf = d["feature"].shape
+    mod = _module(d, C, dev)
+    nl = mod.num_grid_layer
+    assert np.array_equal(mod.z_corners.cpu().numpy(), d["z_corners"])
+    assert np.array_equal(mod.corners_offset.cpu().numpy(), d["corners_offset"])
+
+    feat = torch.from_numpy(d["feature"]).to(dev)[None]
+    integral = ops.integral_image(feat)
+    ig = integral.cpu().numpy()[0]
+    assert_bitwise("integral", ig[1:-1, 1:-1, :].transpose(2, 0, 1), d["integral"])
+    assert (ig[0] == 0).all() and (ig[-1] == 0).all() and (ig[:, 0] == 0).all() and (ig[:, -1] == 0).all()
+
+    calib = torch.from_numpy(d["calib"]).to(dev)[None]
+    grid = torch.from_numpy(d["grid"]).to(dev)
+    zl, co = mod._kernel_geometry(dev)
+    m = _meta(d)
+    img_wh = (m["image_size"][1], m["image_size"][0])
+    kind = _lib.CONV_KIND[m["data"]]
+    box, area, vis = ops.box_params(calib, grid.reshape(-1, 3), zl, co, kind, img_wh, (Hf, Wf))
+    assert_bitwise("box", box.cpu().numpy()[0], d["box"])
+    assert_bitwise("area", area.cpu().numpy()[0], d["area"])
+    assert np.array_equal(vis.cpu().numpy()[0].astype(bool), d["visible"])
+
+    vox_ref_layout = ops.gather(integral, box, area, vis, layout=_lib.VOX_REFERENCE).cpu().numpy()[0]
+    assert_bitwise("vox (reference layout)", vox_ref_layout, d["vox"], zero_sign_free=True)
+    vox_lm = ops.gather(integral, box, area, vis, layout=_lib.VOX_LAYER_MAJOR).cpu().numpy()[0]
+    assert_bitwise("vox (layer-major)", vox_lm, _to_layer_major(d["vox"], C, nl), zero_sign_free=True)
+    fused = ops.project_gather(integral, calib.reshape(1, 12), grid.reshape(-1, 3).contiguous(), zl, co, kind, img_wh)
+    assert_bitwise("vox (fused projection)", fused.cpu().numpy()[0], _to_layer_major(d["vox"], C, nl),
+                   zero_sign_free=True)
+    fused_ref = ops.project_gather(integral, calib.reshape(1, 12), grid.reshape(-1, 3).contiguous(), zl, co, kind,
+                                   img_wh, layout=_lib.VOX_REFERENCE)
+    assert_bitwise("vox (fused, reference layout)", fused_ref.cpu().numpy()[0], d["vox"], zero_sign_free=True)
+
+
+@pytest.mark.parametrize("case", VFA_CASES)
+def test_module_forward_vs_reference_fixture(case):
+    dev = _dev()
+    d = np.load(golden_path(case))
+    C = d["feature"].shape[0]
+    mod = _module(d, C, dev)
+    with torch.no_grad():
+        mod.collapse.weight.copy_(torch.from_numpy(d["weight"]))
+        mod.collapse.bias.copy_(torch.from_numpy(d["bias"]))
+        out = mod(torch.from_numpy(d["feature"]).to(dev)[None], torch.from_numpy(d["calib"]).to(dev),
+                  torch.from_numpy(d["grid"]).to(dev)[None])
+    assert tuple(out.shape) == (1,) + d["ortho"].shape
+    assert not out.is_contiguous()  # permuted view of the channels-last buffer, like the reference returns
+    assert_close("ortho", out[0].cpu().numpy(), d["ortho"])
+
+
+@pytest.mark.parametrize("case", VFANET_CASES)
+def test_aggregate_vs_reference_vfanet_fixture(case):
+    import vfa_amd
+    dev = _dev()
+    d = np.load(golden_path(case))
+    mods = {}
+    for s in (8, 16, 32):
+        mods[s] = _module(d, 256, dev)
+        with torch.no_grad():
+            mods[s].collapse.weight.copy_(torch.from_numpy(d[f"weight{s}"]))
+            mods[s].collapse.bias.copy_(torch.from_numpy(d[f"bias{s}"]))
+    lats = {s: torch.from_numpy(d[f"lat{s}"]).to(dev) for s in (8, 16, 32)}
+    with torch.no_grad():
+        out = vfa_amd.aggregate_views(mods[8], mods[16], mods[32], lats[8], lats[16], lats[32],
+                                      torch.from_numpy(d["calibs"]).to(dev), torch.from_numpy(d["grid"]).to(dev)[None])
+    assert_close("summed ortho", out[0].cpu().numpy(), d["ortho"])
+    # the reference's own per-camera interface gives the same sum
+    with torch.no_grad():
+        acc = 0
+        for cam in range(d["calibs"].shape[0]):
+            calib = torch.from_numpy(d["calibs"][cam]).to(dev)
+            grid = torch.from_numpy(d["grid"]).to(dev)[None]
+            f = [mods[s](lats[s][[cam]], calib, grid) for s in (8, 16, 32)]
+            acc = acc + (f[0] + f[1] + f[2])
+    assert_close("per-camera loop", acc[0].cpu().numpy(), d["ortho"])
+
+
+# ------------------------------------------------------------------------------------------------
+# the CPU oracle on seeded inputs at production channel count
+# ------------------------------------------------------------------------------------------------
+ORACLE_CASES = [
+    # workload, camera, scale index, grid crop (rows, cols) -- sized so the oracle finishes in seconds
+    ("multiviewc_156x156x5", 0, 0, (60, 156)),
+    ("multiviewc_156x156x5", 3, 2, (156, 156)),
+    ("multiviewc_200x200x1", 5, 1, (200, 200)),
+    ("wildtrack_120x360x8", 1, 0, (40, 360)),
+    ("wildtrack_120x360x8", 4, 2, (120, 100)),
+    ("multiviewx_160x250x8", 2, 1, (64, 250)),
+]
+
+
+@pytest.mark.parametrize("name,cam,si,crop", ORACLE_CASES)
+def test_vox_bitwise_vs_oracle_c256(oracle, name, cam, si, crop):
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload(name, channels=256, seed=11 + cam, n_cam=cam + 1)
+    feat = wl["features"][cam][si]
+    grid = wl["grid"][0, :crop[0], :crop[1]].contiguous()
+    calib = wl["calibs"][cam]
+    import vfa_amd
+    mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+    nl = mod.num_grid_layer
+    zl = oracle.z_layers_of(wl["grid_height"], wl["cube_size"])
+    co = oracle.corner_offsets(wl["cube_size"])
+    Hf, Wf = feat.shape[-2:]
+    I = oracle.integral_image(feat[0].numpy())
+    box, area, vis = oracle.box_params(calib.numpy(), grid.numpy(), zl, co, wl["args"].data, wl["args"].image_size,
+                                       Hf, Wf)
+    vox = oracle.gather(I, box, area, vis)
+
+    integral = ops.integral_image(feat.to(dev))
+    assert_bitwise("integral", integral.cpu().numpy()[0][1:-1, 1:-1].transpose(2, 0, 1), I)
+    zl_d, co_d = mod._kernel_geometry(dev)
+    got = ops.project_gather(integral, calib.reshape(1, 12).to(dev), grid.reshape(-1, 3).to(dev), zl_d, co_d,
+                             _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1])
+    assert 0.02 < vis.mean() < 1.0, "the case should mix visible and invisible boxes"
+    assert_bitwise("vox", got.cpu().numpy()[0], _to_layer_major(vox, 256, nl), zero_sign_free=True)
+
+
+def test_odd_shapes_vs_oracle(oracle):
+    """C not a multiple of 4 (scalar path), W not a multiple of the staging chunk, one layer, tiny grid."""
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import ring_cameras
+    from vfa_amd.utils import make_grid
+    dev = _dev()
+    gen = torch.Generator().manual_seed(5)
+    for C, Hf, Wf, nl_h in ((3, 7, 9, 1), (5, 33, 65, 3), (66, 23, 40, 2), (130, 12, 31, 4)):
+        feat = torch.randn(2, C, Hf, Wf, generator=gen)  # signed features
+        calibs = ring_cameras(2, (500.0, 400.0, 0.0), 900.0, 300.0, 700.0, (640, 480), phase=0.3)
+        grid = make_grid(world_size=(800, 1000), cube_LW=(80, 100), dataset="MultiviewC")
+        cube = (80, 100, 50)
+        zl = oracle.z_layers_of(50 * nl_h, cube)
+        co = oracle.corner_offsets(cube)
+        integral = ops.integral_image(feat.to(dev))
+        got = ops.project_gather(integral, calibs.reshape(2, 12).to(dev), grid.reshape(-1, 3).to(dev),
+                                 torch.from_numpy(zl).to(dev), torch.from_numpy(co).to(dev), 0, (640, 480))
+        for v in range(2):
+            I = oracle.integral_image(feat[v].numpy())
+            assert_bitwise("integral", integral.cpu().numpy()[v][1:-1, 1:-1].transpose(2, 0, 1), I)
+            box, area, vis = oracle.box_params(calibs[v].numpy(), grid.numpy(), zl, co, "MultiviewC", (480, 640), Hf, Wf)
+            vox = oracle.gather(I, box, area, vis)
+            assert_bitwise(f"vox C={C}", got.cpu().numpy()[v], _to_layer_major(vox, C, len(zl)), zero_sign_free=True)
+
+
+def test_epilogues_vs_numpy():
+    from vfa_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(3)
+    for n, M, N in ((1, 7, 5), (3, 130, 256), (7, 1000, 8)):
+        lin = [torch.randn(n, M, N, generator=gen) for _ in range(3)]
+        bias = [torch.randn(N, generator=gen) for _ in range(3)]
+        got = ops.bias_relu_accumulate(lin[0].to(dev), bias[0].to(dev)).cpu().numpy()
+        ref = np.zeros((M, N), np.float32)
+        for v in range(n):
+            ref = ref + np.maximum(lin[0][v].numpy() + bias[0].numpy(), 0)
+        assert_bitwise("bias_relu_accumulate", got, ref, zero_sign_free=True)
+        got2 = ops.bias_relu_accumulate(lin[1].to(dev), None, out=torch.from_numpy(ref.copy()).to(dev),
+                                        accumulate=True).cpu().numpy()
+        ref2 = ref.copy()
+        for v in range(n):
+            ref2 = ref2 + np.maximum(lin[1][v].numpy(), 0)
+        assert_bitwise("accumulate=1", got2, ref2, zero_sign_free=True)
+        got3 = ops.scale_view_sum(*(t.to(dev) for t in lin), *(b.to(dev) for b in bias)).cpu().numpy()
+        ref3 = np.zeros((M, N), np.float32)
+        for v in range(n):
+            r = [np.maximum(lin[k][v].numpy() + bias[k].numpy(), 0) for k in range(3)]
+            ref3 = ref3 + ((r[0] + r[1]) + r[2])
+        assert_bitwise("scale_view_sum", got3, ref3, zero_sign_free=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# properties at BASELINE.json's full sizes (no oracle needed)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["multiviewc_200x200x1", "multiviewc_156x156x5", "wildtrack_120x360x8"])
+def test_full_size_properties(name):
+    import vfa_amd
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload(name, channels=256, seed=0, device=dev)
+    n = wl["n_cam"]
+    torch.manual_seed(0)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+            for _ in range(3)]
+    lats = [torch.cat([wl["features"][c][s] for c in range(n)]) for s in range(3)]
+    grid_flat = wl["grid"].reshape(-1, 3).contiguous()
+    kind = _lib.CONV_KIND[wl["args"].data]
+    img_wh = wl["args"].image_size[::-1]
+    zl, co = mods[0]._kernel_geometry(dev)
+    calibs = wl["calibs"].reshape(n, 12).contiguous()
+    n_cells = grid_flat.shape[0]
+
+    integral = ops.integral_image(lats[0])
+    # (1) the last integral value is the total sum of the (non-negative) map, to fp32 accumulation accuracy
+    tot = lats[0].double().sum(dim=(2, 3))
+    torch.testing.assert_close(integral[:, -2, -2, :].double(), tot, rtol=1e-5, atol=1e-3)
+    # (2) fused projection == separate box kernel + gather, bitwise; chunking over cells is invisible
+    full = ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh)
+    box, area, vis = ops.box_params(calibs, grid_flat, zl, co, kind, img_wh, lats[0].shape[-2:])
+    unfused = ops.gather(integral, box, area, vis)
+    assert torch.equal(full.view(torch.int32), unfused.view(torch.int32))
+    cut = n_cells // 3 + 1
+    parts = [ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, cell_begin=b,
+                                cell_count=min(cut, n_cells - b)) for b in range(0, n_cells, cut)]
+    assert torch.equal(torch.cat(parts, dim=1).view(torch.int32), full.view(torch.int32))
+    # (3) masked voxels are exactly zero, visible ones finite; a box mean of a non-negative map is >= -eps
+    nl = zl.numel()
+    v = full.view(n, n_cells, nl, 256)
+    vis_cl = vis.permute(0, 2, 1).bool()
+    assert (v[~vis_cl] == 0).all()
+    assert torch.isfinite(v).all()
+    # (4) a constant map pools to that constant wherever the box lies inside the image
+    const = torch.full_like(lats[0][:1], 1.0)
+    ic = ops.integral_image(const)
+    vc = ops.project_gather(ic, calibs[:1], grid_flat, zl, co, kind, img_wh).view(n_cells, nl, 256)
+    b0 = box[0].permute(1, 0, 2)
+    inside = (b0[..., 0] > -0.98) & (b0[..., 1] > -0.98) & (b0[..., 2] < 0.94) & (b0[..., 3] < 0.94) & vis_cl[0]
+    inside &= area[0].permute(1, 0) > 8  # cancellation error of the 4-corner sum ~ 4 ulp(Hf*Wf) / area
+    if inside.any():
+        # area carries the reference's 4x convention: mean of a constant-1 map = 1/4 * (1 - eps/area)
+        got = vc[inside]
+        assert torch.allclose(got, torch.full_like(got, 0.25), rtol=0, atol=5e-3), (got.min(), got.max())
+    # (5) the batched aggregate equals the reference-style per-camera loop, camera order does not matter
+    with torch.no_grad():
+        ortho = vfa_amd.aggregate_views(*mods, *lats, wl["calibs"], wl["grid"])
+        perm = torch.randperm(n).to(dev)
+        ortho_p = vfa_amd.aggregate_views(*mods, *(l[perm] for l in lats), wl["calibs"][perm], wl["grid"])
+        acc = 0
+        for cam in range(n):
+            f = [mods[s](lats[s][[cam]], wl["calibs"][cam], wl["grid"]) for s in range(3)]
+            acc = acc + (f[0] + f[1] + f[2])
+    L, W = wl["grid"].shape[1:3]
+    assert tuple(ortho.shape) == (1, 256, L, W)
+    scale = ortho.abs().max().item()
+    assert scale > 0
+    torch.testing.assert_close(ortho, acc, rtol=RTOL, atol=ATOL_REL * scale)
+    torch.testing.assert_close(ortho_p, ortho, rtol=RTOL, atol=ATOL_REL * scale)
+
+
+def test_empty_and_degenerate_inputs():
+    import vfa_amd
+    from vfa_amd import ops
+    dev = _dev()
+    args = SimpleNamespace(data="MultiviewC", image_size=(720, 1280))
+    mod = vfa_amd.VFA(8, args=args).to(dev)
+    feat = torch.rand(1, 8, 23, 40, device=dev)
+    # empty grid
+    out = mod(feat, torch.eye(3, 4, device=dev), torch.zeros(1, 0, 5, 3, device=dev))
+    assert tuple(out.shape) == (1, 8, 0, 5)
+    # a camera looking away: every box invisible -> relu(bias) everywhere
+    calib = torch.tensor([[900., 0, 640, 1e9], [0, 900., 360, 1e9], [0, 0, 0, 1.]], device=dev)
+    grid = vfa_amd.make_grid((200, 300), cube_LW=(25, 25), dataset="MultiviewC").to(dev)[None]
+    out = mod(feat, calib, grid)
+    ref = torch.relu(mod.collapse.bias).view(1, 8, 1, 1).expand_as(out)
+    assert torch.equal(out, ref)
+    # zero views
+    z = ops.integral_image(torch.zeros(0, 8, 4, 4, device=dev))
+    assert z.shape == (0, 6, 6, 8)

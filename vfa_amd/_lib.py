@@ -1,0 +1,82 @@
+"""ctypes binding of the HIP library (``vfa_amd/csrc/libvfa_hip.so``, C ABI in ``include/vfa_hip.h``).
+
+There is deliberately NO fallback: if the library is missing or a launch fails the caller gets an
+exception.  The product path never touches ``oracle/`` or any CPU implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvfa_hip.so")
+ABI_VERSION = 1
+
+CONV_KIND = {"MultiviewC": 0, "MultiviewX": 1, "Wildtrack": 2}
+VOX_REFERENCE, VOX_LAYER_MAJOR = 0, 1
+
+_c_int, _c_float, _c_size_t, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> argtypes; must list every symbol include/vfa_hip.h declares (tests/test_abi.py checks it)
+SIGNATURES = {
+    "vfa_abi_version": [],
+    "vfa_integral_image_f32": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
+    "vfa_box_params_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _c_int,
+                           _c_float, _c_float, _vp, _vp, _vp, _vp],
+    "vfa_gather_f32": [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                       _vp],
+    "vfa_project_gather_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                               _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],
+    "vfa_bias_relu_accumulate_f32": [_vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _vp],
+    "vfa_scale_view_sum_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _vp],
+}
+
+_lib = None
+
+
+class VFAHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library once.  Raises if it has not been built (``python -m vfa_amd.build``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VFAHipError(
+                f"{LIB_PATH} is missing: build it with `python -m vfa_amd.build` (hipcc --offload-arch=gfx950). "
+                "vfa_amd has no CPU or PyTorch fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        got = handle.vfa_abi_version()
+        if got != ABI_VERSION:
+            raise VFAHipError(f"libvfa_hip.so has ABI version {got}, the Python side expects {ABI_VERSION}; rebuild")
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Call an entry point; a non-zero status becomes an exception (reference error behaviour = Python exceptions)."""
+    status = getattr(lib(), name)(*args)
+    if status != 0:
+        raise VFAHipError(f"{name} failed with status {status}"
+                          + (" (bad argument)" if status == 10001 else " (hipError_t)"))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream_handle():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    """The path runs on the GPU only; refuse CPU tensors loudly instead of falling back."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise VFAHipError("vfa_amd runs on an AMD GPU (MI355X, gfx950) only; got a CPU tensor and there is no "
+                              "CPU fallback")

@@ -1,0 +1,88 @@
+"""Cross-scale / cross-view aggregation of the projected BEV maps (reference ``vfa/model/vfanet.py:64-82``).
+
+The reference loops over cameras in Python, calls ``VFA.forward`` three times per camera and adds the
+results (``vfa_feat8 + vfa_feat16 + vfa_feat32`` :79, ``ortho += vfa_feats`` :82).  Here all cameras of a
+scale go through one launch of each kernel and one fused epilogue forms
+
+    ortho = sum_cam ((relu(lin8+b8) + relu(lin16+b16)) + relu(lin32+b32))        (same association order)
+
+Multi-GPU: cameras are sharded over ranks (``camera_shard``); every rank forms the partial sum of its
+cameras and one RCCL all-reduce over xGMI fuses the grid (``all_reduce_ortho``).  The reference has no
+distributed code; this is the data-parallel axis the path offers.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class _ScaleViewSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lin8, lin16, lin32, b8, b16, b32):
+        ortho = ops.scale_view_sum(lin8, lin16, lin32, b8, b16, b32)
+        ctx.save_for_backward(lin8, lin16, lin32, b8, b16, b32)
+        return ortho
+
+    @staticmethod
+    def backward(ctx, grad):
+        lin8, lin16, lin32, b8, b16, b32 = ctx.saved_tensors
+        outs, bias_grads = [], []
+        for lin, b in ((lin8, b8), (lin16, b16), (lin32, b32)):
+            g = grad.unsqueeze(0) * ((lin + b) > 0)
+            outs.append(g)
+            bias_grads.append(g.sum(dim=(0, 1)))
+        return (*outs, *bias_grads)
+
+
+def camera_shard(n_cam, rank=None, world=None):
+    """Cameras owned by ``rank``: rank, rank+world, ... (one camera per GPU when world >= n_cam)."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return list(range(rank, n_cam, world))
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x.  Every rank then runs the same heads on the same y, so dL/dx = dL/dy locally."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        y = x.detach().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad, None
+
+
+def all_reduce_ortho(ortho_nhwc, group=None):
+    """Sum the partial BEV maps of all ranks in place (RCCL over xGMI; backend string "nccl" on ROCm)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if ortho_nhwc.requires_grad:
+            return _AllReduceSum.apply(ortho_nhwc, group)
+        dist.all_reduce(ortho_nhwc, op=dist.ReduceOp.SUM, group=group)
+    return ortho_nhwc
+
+
+def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange=(-1, 0.95), reduce_group=None,
+                    distributed=False):
+    """The camera loop of ``VFANet.forward`` for the cameras held by this process.
+
+    lat* (n,C,h,w) lateral maps of the local cameras, calibs (n,3,4), grid (1,L,W,3)
+    -> ortho (1,C,L,W): a permuted view of the channels-last buffer, like the reference returns.
+    With ``distributed=True`` the partial sums of all ranks are all-reduced.
+    """
+    length, width = grid.shape[-3], grid.shape[-2]
+    n = calibs.shape[0]
+    if n > 0:
+        lin8 = vfa8.project_views(lat8, calibs, grid, crange)
+        lin16 = vfa16.project_views(lat16, calibs, grid, crange)
+        lin32 = vfa32.project_views(lat32, calibs, grid, crange)
+        ortho = _ScaleViewSum.apply(lin8, lin16, lin32, vfa8.collapse.bias, vfa16.collapse.bias, vfa32.collapse.bias)
+    else:  # a rank without cameras (8 GPUs, 7 cameras) contributes zeros
+        ortho = torch.zeros((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
+    if distributed:
+        ortho = all_reduce_ortho(ortho, reduce_group)
+    return ortho.view(1, length, width, -1).permute(0, 3, 1, 2)

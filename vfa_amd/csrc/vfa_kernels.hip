@@ -1,0 +1,658 @@
+// vfa_kernels.hip -- hand-written HIP (gfx950 / CDNA4, wave64) kernels of the multiview feature -> voxel
+// projection + aggregation path, behind the C ABI of include/vfa_hip.h.
+//
+// Reference behaviour reproduced (file:line relative to Jiahao-Ma/VFA):
+//   vfa/model/vfa_op.py:61-125   VFA.forward  (cube corners, projection, clamped box, integral-image
+//                                box pooling at 4 bilinear-sampled corners, visibility mask, collapse)
+//   vfa/utils.py:50-59           project
+//   vfa/model/vfanet.py:79, 82   scale sum, view sum
+//
+// Numerics: fp32 with the rounding sequence of the reference's PyTorch CPU path.
+// The file is compiled with -ffp-contract=off; an FMA appears only where fmaf() is written.
+//
+// Data layout in HBM (see include/vfa_hip.h): the integral image is stored channels-last with a one-pixel
+// zero border, (n_views, Hf+2, Wf+2, C).  One bilinear tap of one box is then C contiguous floats (1 KiB at
+// C = 256 = one 16 B/lane wave64 load), and grid_sample's zeros padding is a plain load of the border.
+#include <hip/hip_runtime.h>
+
+#include "vfa_hip.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+// torch.clamp / min / max propagate NaN; ordered comparisons do that for free.
+__device__ __forceinline__ float clamp_t(float v, float lo, float hi)
+{
+    if (v < lo) return lo;
+    if (v > hi) return hi;
+    return v;
+}
+__device__ __forceinline__ float min_t(float a, float b) { return (a != a || a < b) ? a : b; }
+__device__ __forceinline__ float max_t(float a, float b) { return (a != a || a > b) ? a : b; }
+
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniform_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Give every XCD one
+// contiguous eighth of the logical work so that neighbouring boxes -- whose image footprints overlap --
+// are served by the same L2.  Speed only; any placement is correct.
+__device__ __forceinline__ long long xcd_contiguous(long long block, long long per_xcd)
+{
+    return (block & 7) * per_xcd + (block >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// integral image, pass 1: cumsum along W.                                reference vfa_op.py:173 (inner)
+// One wave owns 64 channels of one image row.  The row is staged through LDS in 32-column chunks so that
+// the NCHW reads are row-contiguous and the channels-last writes are channel-contiguous (256 B per
+// wave store).  Each lane scans one channel sequentially with a double accumulator rounded to fp32 at
+// every element -- ATen's CPU cumsum -- so the result is bit-identical to the reference.
+// grid = (Hf, ceil(C/64), n_views), block = 64.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRowChunk = 32;
+
+__global__ __launch_bounds__(kWave) void integral_rows_kernel(const float *__restrict__ feat,
+                                                              float *__restrict__ out, int C, int H, int W)
+{
+    __shared__ float tile[kWave][kRowChunk + 1];
+    const int lane = threadIdx.x;
+    const int y = blockIdx.x, c0 = blockIdx.y * kWave, v = blockIdx.z;
+    const int nch = min(kWave, C - c0);
+    const size_t plane = (size_t)H * W;
+    const float *src = feat + ((size_t)v * C + c0) * plane + (size_t)y * W;
+    const int Wp = W + 2;
+    float *dst = out + (((size_t)v * (H + 2) + (y + 1)) * Wp) * C + c0; // padded row y+1, padded col 0
+    const bool active = lane < nch;
+    if (active) {
+        dst[lane] = 0.0f;                        // left border
+        dst[(size_t)(W + 1) * C + lane] = 0.0f;  // right border
+    }
+    double acc = 0.0;
+    for (int x0 = 0; x0 < W; x0 += kRowChunk) {
+        const int nx = min(kRowChunk, W - x0);
+        const int j = lane & (kRowChunk - 1);
+        for (int r = lane >> 5; r < nch; r += 2)
+            if (j < nx) tile[r][j] = src[(size_t)r * plane + x0 + j];
+        __syncthreads();
+        if (active) {
+            for (int k = 0; k < nx; ++k) {
+                acc += (double)tile[lane][k];
+                dst[(size_t)(x0 + k + 1) * C + lane] = (float)acc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// integral image, pass 2: cumsum along H, in place on the channels-last buffer, plus the zero top and
+// bottom border rows.                                                   reference vfa_op.py:173 (outer)
+// One thread owns VEC channels of one padded column; loads of a column are independent of the running
+// sum, so they are issued eight rows ahead.
+// ------------------------------------------------------------------------------------------------
+template <int VEC> struct vec_of;
+template <> struct vec_of<1> { using type = float; };
+template <> struct vec_of<4> { using type = float4; };
+
+template <int VEC> __device__ __forceinline__ void scan_step(double (&acc)[VEC], typename vec_of<VEC>::type &v);
+template <> __device__ __forceinline__ void scan_step<1>(double (&acc)[1], float &v)
+{
+    acc[0] += (double)v;
+    v = (float)acc[0];
+}
+template <> __device__ __forceinline__ void scan_step<4>(double (&acc)[4], float4 &v)
+{
+    acc[0] += (double)v.x; v.x = (float)acc[0];
+    acc[1] += (double)v.y; v.y = (float)acc[1];
+    acc[2] += (double)v.z; v.z = (float)acc[2];
+    acc[3] += (double)v.w; v.w = (float)acc[3];
+}
+template <int VEC> __device__ __forceinline__ typename vec_of<VEC>::type vzero();
+template <> __device__ __forceinline__ float vzero<1>() { return 0.0f; }
+template <> __device__ __forceinline__ float4 vzero<4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int VEC>
+__global__ __launch_bounds__(256) void integral_cols_kernel(float *__restrict__ io, int H, size_t row_vecs,
+                                                            size_t total_vecs)
+{
+    using V = typename vec_of<VEC>::type;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_vecs) return;
+    const size_t v = i / row_vecs, r = i % row_vecs;
+    V *p = reinterpret_cast<V *>(io) + v * (size_t)(H + 2) * row_vecs + r;
+    p[0] = vzero<VEC>();
+    p[(size_t)(H + 1) * row_vecs] = vzero<VEC>();
+    p += row_vecs; // first interior row
+    double acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.0;
+    constexpr int U = 8;
+    int y = 0;
+    for (; y + U <= H; y += U) {
+        V t[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) t[k] = p[(size_t)(y + k) * row_vecs];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            scan_step<VEC>(acc, t[k]);
+            p[(size_t)(y + k) * row_vecs] = t[k];
+        }
+    }
+    for (; y < H; ++y) {
+        V t = p[(size_t)y * row_vecs];
+        scan_step<VEC>(acc, t);
+        p[(size_t)y * row_vecs] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// box parameters                                           reference vfa_op.py:64-88, 104-106; utils.py:56-59
+// ------------------------------------------------------------------------------------------------
+struct BoxGeom {
+    const float *calibs;     // (n_views, 12)
+    const float *grid;       // (n_cells, 3)
+    const float *z_layers;   // (nl)
+    const float *corner_off; // (8, 3)
+    int conv_kind;
+    float img_w, img_h;
+    float cmin, cmax;
+};
+
+// Normalised image coordinates of cube corner k of (cell, layer) seen by `P` (3x4, row-major).
+// Every operation is a separately rounded fp32 op in the reference's order.
+__device__ __forceinline__ void project_corner(const BoxGeom &g, const float *__restrict__ P, float gx, float gy,
+                                               float gz, int k, float &nu, float &nv)
+{
+    float x = gx + g.corner_off[k * 3 + 0];
+    float y = gy + g.corner_off[k * 3 + 1];
+    float z = gz + g.corner_off[k * 3 + 2];
+    if (g.conv_kind == VFA_CONV_MULTIVIEWX) {
+        x = x / 40.0f; y = y / 40.0f; z = z / 40.0f;
+    } else if (g.conv_kind == VFA_CONV_WILDTRACK) {
+        x = x * 2.5f; x = x - 300.0f;
+        y = y * 2.5f; y = y - 900.0f;
+        z = z * 2.5f;
+    }
+    float h[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float a0 = P[r * 4 + 0] * x, a1 = P[r * 4 + 1] * y, a2 = P[r * 4 + 2] * z;
+        float s = a0 + a1;
+        s = s + a2;
+        h[r] = s + P[r * 4 + 3];
+    }
+    const float u = h[0] / h[2], w = h[1] / h[2];
+    nu = (2.0f * u) / g.img_w; nu = nu - 1.0f; nu = clamp_t(nu, g.cmin, g.cmax);
+    nv = (2.0f * w) / g.img_h; nv = nv - 1.0f; nv = clamp_t(nv, g.cmin, g.cmax);
+}
+
+__device__ __forceinline__ float box_area(float l, float t, float r, float b, int Hf, int Wf)
+{
+    const float dx = r - l, dy = b - t;
+    float a = dx * dy;
+    a = a * (float)Hf;
+    a = a * (float)Wf;
+    a = a + (float)1e-6;
+    return a;
+}
+__device__ __forceinline__ bool box_visible(float a, int Hf, int Wf)
+{
+    return (a > (float)1e-6) && (a < (float)((double)(Hf * Wf) * 0.3));
+}
+
+// one thread per (view, layer, cell)
+__global__ __launch_bounds__(256) void box_params_kernel(BoxGeom g, int n_cells, int nl, size_t total, int Hf,
+                                                         int Wf, float4 *__restrict__ box, float *__restrict__ area,
+                                                         uint8_t *__restrict__ visible)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cell = (int)(idx % n_cells);
+    const size_t vl = idx / n_cells;
+    const int layer = (int)(vl % nl), view = (int)(vl / nl);
+    const float *P = g.calibs + (size_t)view * 12;
+    const float gx = g.grid[cell * 3 + 0] + 0.0f; // + the int64 zeros of z_corners (vfa_op.py:52, :64)
+    const float gy = g.grid[cell * 3 + 1] + 0.0f;
+    const float gz = g.grid[cell * 3 + 2] + g.z_layers[layer];
+    float l = 0, t = 0, r = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float nu, nv;
+        project_corner(g, P, gx, gy, gz, k, nu, nv);
+        if (k == 0) { l = r = nu; t = b = nv; }
+        else { l = min_t(l, nu); r = max_t(r, nu); t = min_t(t, nv); b = max_t(b, nv); }
+    }
+    const float a = box_area(l, t, r, b, Hf, Wf);
+    box[idx] = make_float4(l, t, r, b);
+    area[idx] = a;
+    visible[idx] = box_visible(a, Hf, Wf) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// box pooling                                                               reference vfa_op.py:112-120
+// ------------------------------------------------------------------------------------------------
+// One axis of F.grid_sample's bilinear set-up (align_corners=False): pixel coordinate by ONE fma,
+// i0 = floor, hi = weight of tap i0+1, lo = weight of tap i0.              SURVEY.md A.5
+struct Axis { int i0; float hi, lo; };
+__device__ __forceinline__ Axis make_axis(float g, int size)
+{
+    const float X = fmaf(g + 1.0f, (float)size / 2.0f, -0.5f);
+    const float f = floorf(X);
+    Axis a;
+    a.i0 = (int)f;
+    a.hi = X - f;
+    a.lo = 1.0f - a.hi;
+    return a;
+}
+
+template <int VEC> __device__ __forceinline__ typename vec_of<VEC>::type vmul(typename vec_of<VEC>::type a, float w);
+template <> __device__ __forceinline__ float vmul<1>(float a, float w) { return a * w; }
+template <> __device__ __forceinline__ float4 vmul<4>(float4 a, float w)
+{
+    return make_float4(a.x * w, a.y * w, a.z * w, a.w * w);
+}
+template <int VEC>
+__device__ __forceinline__ typename vec_of<VEC>::type vfma(typename vec_of<VEC>::type a, float w,
+                                                           typename vec_of<VEC>::type c);
+template <> __device__ __forceinline__ float vfma<1>(float a, float w, float c) { return fmaf(a, w, c); }
+template <> __device__ __forceinline__ float4 vfma<4>(float4 a, float w, float4 c)
+{
+    return make_float4(fmaf(a.x, w, c.x), fmaf(a.y, w, c.y), fmaf(a.z, w, c.z), fmaf(a.w, w, c.w));
+}
+
+// bilinear sample, taps in the order nw, ne, sw, se: one rounded product then three FMAs (A.5)
+template <int VEC>
+__device__ __forceinline__ typename vec_of<VEC>::type bilinear(typename vec_of<VEC>::type nw, typename vec_of<VEC>::type ne,
+                                                               typename vec_of<VEC>::type sw, typename vec_of<VEC>::type se,
+                                                               const Axis &ax, const Axis &ay)
+{
+    const float wnw = ay.lo * ax.lo, wne = ay.lo * ax.hi, wsw = ay.hi * ax.lo, wse = ay.hi * ax.hi;
+    auto v = vmul<VEC>(nw, wnw);
+    v = vfma<VEC>(ne, wne, v);
+    v = vfma<VEC>(sw, wsw, v);
+    v = vfma<VEC>(se, wse, v);
+    return v;
+}
+
+// (((lt + rb) - rt) - lb) / area                                                        (A.6)
+__device__ __forceinline__ float box_mean(float lt, float rb, float rt, float lb, float area)
+{
+    float v = lt + rb;
+    v = v - rt;
+    v = v - lb;
+    return v / area;
+}
+template <int VEC>
+__device__ __forceinline__ typename vec_of<VEC>::type vbox_mean(typename vec_of<VEC>::type lt, typename vec_of<VEC>::type rb,
+                                                                typename vec_of<VEC>::type rt, typename vec_of<VEC>::type lb,
+                                                                float area);
+template <> __device__ __forceinline__ float vbox_mean<1>(float lt, float rb, float rt, float lb, float area)
+{
+    return box_mean(lt, rb, rt, lb, area);
+}
+template <> __device__ __forceinline__ float4 vbox_mean<4>(float4 lt, float4 rb, float4 rt, float4 lb, float area)
+{
+    return make_float4(box_mean(lt.x, rb.x, rt.x, lb.x, area), box_mean(lt.y, rb.y, rt.y, lb.y, area),
+                       box_mean(lt.z, rb.z, rt.z, lb.z, area), box_mean(lt.w, rb.w, rt.w, lb.w, area));
+}
+
+// The 16 taps of a box are the product {top rows yt, yt+1, bottom rows yb, yb+1} x {left cols xl, xl+1,
+// right cols xr, xr+1}.  P[row][col] holds them; when the right pair coincides with / overlaps the left
+// pair (DXC = xr - xl = 0 or 1; boxes are often narrower than a feature pixel) the shared columns are
+// loaded once.  RB0/RB1 and CR0/CR1 name where the bottom rows / right columns live in P.
+template <int VEC, int DYC, int DXC>
+__device__ __forceinline__ typename vec_of<VEC>::type pool_box(const typename vec_of<VEC>::type (&P)[4][4], const Axis &xl,
+                                                               const Axis &xr, const Axis &yt, const Axis &yb,
+                                                               float area)
+{
+    constexpr int RB0 = DYC == 0 ? 0 : (DYC == 1 ? 1 : 2), RB1 = DYC == 0 ? 1 : 3;
+    constexpr int CR0 = DXC == 0 ? 0 : (DXC == 1 ? 1 : 2), CR1 = DXC == 0 ? 1 : 3;
+    const auto lt = bilinear<VEC>(P[0][0], P[0][1], P[1][0], P[1][1], xl, yt);
+    const auto rb = bilinear<VEC>(P[RB0][CR0], P[RB0][CR1], P[RB1][CR0], P[RB1][CR1], xr, yb);
+    const auto rt = bilinear<VEC>(P[0][CR0], P[0][CR1], P[1][CR0], P[1][CR1], xr, yt);
+    const auto lb = bilinear<VEC>(P[RB0][0], P[RB0][1], P[RB1][0], P[RB1][1], xl, yb);
+    return vbox_mean<VEC>(lt, rb, rt, lb, area);
+}
+
+struct GatherDims {
+    int C, Hf, Wf, nl, n_cells, cell_begin, cell_count, vox_layout;
+    long long n_boxes;    // n_views * cell_count * nl
+    long long per_xcd;    // blocks per XCD
+};
+
+// One wave per box; lanes are channels (VEC = 4: 64 lanes x float4 = 256 channels = one 1 KiB load per tap).
+// Box parameters are wave-uniform: they are computed once, moved to SGPRs and drive scalar branches
+// (invisible boxes exit before touching the integral image; duplicate taps are not loaded).
+// FUSED: the wave also projects the eight cube corners itself (lane k & 7 = corner k) and reduces
+// min / max with xor-shuffles, which is exact and order-insensitive.
+template <int VEC, bool FUSED>
+__global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ integral, const float4 *__restrict__ box,
+                                                     const float *__restrict__ area_in,
+                                                     const uint8_t *__restrict__ visible_in, BoxGeom g, GatherDims d,
+                                                     float *__restrict__ vox)
+{
+    using V = typename vec_of<VEC>::type;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = uniform_i(threadIdx.x >> 6);
+    const long long blk = xcd_contiguous(blockIdx.x, d.per_xcd);
+    const long long wid = blk * 4 + wave; // (view, cell_local, layer), layer fastest
+    if (wid >= d.n_boxes) return;
+    const int layer = (int)(wid % d.nl);
+    const long long vc = wid / d.nl;
+    const int cell_local = (int)(vc % d.cell_count), view = (int)(vc / d.cell_count);
+    const int cell = d.cell_begin + cell_local;
+
+    float l, t, r, b, area;
+    bool vis;
+    if constexpr (FUSED) {
+        const float *P = g.calibs + (size_t)view * 12;
+        const float gx = g.grid[cell * 3 + 0] + 0.0f;
+        const float gy = g.grid[cell * 3 + 1] + 0.0f;
+        const float gz = g.grid[cell * 3 + 2] + g.z_layers[layer];
+        float nu, nv;
+        project_corner(g, P, gx, gy, gz, lane & 7, nu, nv);
+        l = r = nu; t = b = nv;
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            l = min_t(l, __shfl_xor(l, m));
+            r = max_t(r, __shfl_xor(r, m));
+            t = min_t(t, __shfl_xor(t, m));
+            b = max_t(b, __shfl_xor(b, m));
+        }
+        l = uniform_f(l); t = uniform_f(t); r = uniform_f(r); b = uniform_f(b);
+        area = box_area(l, t, r, b, d.Hf, d.Wf);
+        vis = box_visible(area, d.Hf, d.Wf);
+    } else {
+        const size_t bidx = ((size_t)view * d.nl + layer) * d.n_cells + cell;
+        const float4 bx = box[bidx];
+        l = uniform_f(bx.x); t = uniform_f(bx.y); r = uniform_f(bx.z); b = uniform_f(bx.w);
+        area = uniform_f(area_in[bidx]);
+        vis = uniform_i(visible_in[bidx]) != 0;
+    }
+
+    // output address of channel c of this box
+    const size_t row = (size_t)view * d.cell_count + cell_local;
+    const size_t K = (size_t)d.C * d.nl;
+    float *out_lm = vox + row * K + (size_t)layer * d.C; // layer-major: + c
+    float *out_ref = vox + row * K + layer;               // reference:   + c*nl
+
+    if (!vis) {
+        // (x / area) * 0: zero, or NaN when the box itself is NaN (reference: vox * visible)
+        const float z = area * 0.0f;
+        for (int c = lane * VEC; c < d.C; c += kWave * VEC) {
+            if (d.vox_layout == VFA_VOX_LAYER_MAJOR) {
+                if constexpr (VEC == 4) *reinterpret_cast<float4 *>(out_lm + c) = make_float4(z, z, z, z);
+                else out_lm[c] = z;
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) out_ref[(size_t)(c + k) * d.nl] = z;
+            }
+        }
+        return;
+    }
+
+    const Axis xl = make_axis(l, d.Wf), xr = make_axis(r, d.Wf);
+    const Axis yt = make_axis(t, d.Hf), yb = make_axis(b, d.Hf);
+    // padded coordinates: any out-of-image tap lands on the zero border
+    const int Wp = d.Wf + 2;
+    auto px = [&](int x) { return uniform_i(min(max(x, -1), d.Wf) + 1); };
+    auto py = [&](int y) { return uniform_i(min(max(y, -1), d.Hf) + 1); };
+    const int dx = uniform_i(xr.i0 - xl.i0), dy = uniform_i(yb.i0 - yt.i0);
+    const int dxc = dx == 0 ? 0 : (dx == 1 ? 1 : 2), dyc = dy == 0 ? 0 : (dy == 1 ? 1 : 2);
+    const int colx[4] = {px(xl.i0), px(xl.i0 + 1), px(xr.i0), px(xr.i0 + 1)};
+    const int rowy[4] = {py(yt.i0), py(yt.i0 + 1), py(yb.i0), py(yb.i0 + 1)};
+    const float *img = integral + (size_t)view * (d.Hf + 2) * Wp * d.C;
+
+    for (int c = lane * VEC; c < d.C; c += kWave * VEC) {
+        V P[4][4];
+        auto tap = [&](int ry, int cx) {
+            return *reinterpret_cast<const V *>(img + ((size_t)rowy[ry] * Wp + colx[cx]) * d.C + c);
+        };
+        auto load_row = [&](int ry) {
+            P[ry][0] = tap(ry, 0);
+            P[ry][1] = tap(ry, 1);
+            if (dxc == 2) P[ry][2] = tap(ry, 2);
+            if (dxc >= 1) P[ry][3] = tap(ry, 3);
+        };
+        load_row(0);
+        load_row(1);
+        if (dyc == 2) load_row(2);
+        if (dyc >= 1) load_row(3);
+
+        V res;
+        switch (dyc * 3 + dxc) {
+        case 0: res = pool_box<VEC, 0, 0>(P, xl, xr, yt, yb, area); break;
+        case 1: res = pool_box<VEC, 0, 1>(P, xl, xr, yt, yb, area); break;
+        case 2: res = pool_box<VEC, 0, 2>(P, xl, xr, yt, yb, area); break;
+        case 3: res = pool_box<VEC, 1, 0>(P, xl, xr, yt, yb, area); break;
+        case 4: res = pool_box<VEC, 1, 1>(P, xl, xr, yt, yb, area); break;
+        case 5: res = pool_box<VEC, 1, 2>(P, xl, xr, yt, yb, area); break;
+        case 6: res = pool_box<VEC, 2, 0>(P, xl, xr, yt, yb, area); break;
+        case 7: res = pool_box<VEC, 2, 1>(P, xl, xr, yt, yb, area); break;
+        default: res = pool_box<VEC, 2, 2>(P, xl, xr, yt, yb, area); break;
+        }
+        if (d.vox_layout == VFA_VOX_LAYER_MAJOR) {
+            *reinterpret_cast<V *>(out_lm + c) = res;
+        } else {
+            const float *rs = reinterpret_cast<const float *>(&res);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) out_ref[(size_t)(c + k) * d.nl] = rs[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// collapse epilogues                                            reference vfa_op.py:124; vfanet.py:79, 82
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float relu_t(float x) { return (x < 0.0f) ? 0.0f : x; } // NaN stays NaN
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bias_relu_accumulate_kernel(const float *__restrict__ lin,
+                                                                   const float *__restrict__ bias,
+                                                                   float *__restrict__ out, int n_views, size_t MN,
+                                                                   int N, int accumulate)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * VEC;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < MN; i += stride) {
+        const int col = (int)(i % N);
+        float acc[VEC], bb[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            bb[k] = bias ? bias[col + k] : 0.0f;
+            acc[k] = accumulate ? out[i + k] : 0.0f;
+        }
+        for (int v = 0; v < n_views; ++v) {
+            float x[VEC];
+            if constexpr (VEC == 4) {
+                const float4 q = *reinterpret_cast<const float4 *>(lin + (size_t)v * MN + i);
+                x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+            } else {
+                x[0] = lin[(size_t)v * MN + i];
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] + relu_t(x[k] + bb[k]);
+        }
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(out + i) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else out[i] = acc[0];
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void scale_view_sum_kernel(const float *__restrict__ l8, const float *__restrict__ l16,
+                                                             const float *__restrict__ l32, const float *__restrict__ b8,
+                                                             const float *__restrict__ b16,
+                                                             const float *__restrict__ b32, float *__restrict__ ortho,
+                                                             int n_views, size_t MN, int N, int accumulate)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * VEC;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < MN; i += stride) {
+        const int col = (int)(i % N);
+        float acc[VEC], c8[VEC], c16[VEC], c32[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            c8[k] = b8 ? b8[col + k] : 0.0f;
+            c16[k] = b16 ? b16[col + k] : 0.0f;
+            c32[k] = b32 ? b32[col + k] : 0.0f;
+            acc[k] = accumulate ? ortho[i + k] : 0.0f;
+        }
+        for (int v = 0; v < n_views; ++v) {
+            float x8[VEC], x16[VEC], x32[VEC];
+            const size_t o = (size_t)v * MN + i;
+            if constexpr (VEC == 4) {
+                const float4 q8 = *reinterpret_cast<const float4 *>(l8 + o);
+                const float4 q16 = *reinterpret_cast<const float4 *>(l16 + o);
+                const float4 q32 = *reinterpret_cast<const float4 *>(l32 + o);
+                x8[0] = q8.x; x8[1] = q8.y; x8[2] = q8.z; x8[3] = q8.w;
+                x16[0] = q16.x; x16[1] = q16.y; x16[2] = q16.z; x16[3] = q16.w;
+                x32[0] = q32.x; x32[1] = q32.y; x32[2] = q32.z; x32[3] = q32.w;
+            } else {
+                x8[0] = l8[o]; x16[0] = l16[o]; x32[0] = l32[o];
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float s = relu_t(x8[k] + c8[k]) + relu_t(x16[k] + c16[k]); // vfanet.py:79
+                s = s + relu_t(x32[k] + c32[k]);
+                acc[k] = acc[k] + s;                                        // vfanet.py:82
+            }
+        }
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(ortho + i) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else ortho[i] = acc[0];
+    }
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+inline unsigned elementwise_blocks(size_t n_items)
+{
+    const size_t want = (n_items + 255) / 256;
+    const size_t cap = 256 * 8; // 256 CUs x 8 blocks, grid-stride beyond that
+    return (unsigned)(want < cap ? (want ? want : 1) : cap);
+}
+
+template <bool FUSED>
+int launch_gather(const float *integral, const float *box, const float *area, const uint8_t *visible, const BoxGeom &g,
+                  float *vox, int n_views, int C, int Hf, int Wf, int nl, int n_cells, int cell_begin, int cell_count,
+                  int vox_layout, hipStream_t s)
+{
+    if (n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0 || nl <= 0 || n_cells < 0 || cell_begin < 0 || cell_count < 0 ||
+        cell_begin + cell_count > n_cells || (vox_layout != VFA_VOX_REFERENCE && vox_layout != VFA_VOX_LAYER_MAJOR))
+        return VFA_ERR_BAD_ARGUMENT;
+    GatherDims d;
+    d.C = C; d.Hf = Hf; d.Wf = Wf; d.nl = nl; d.n_cells = n_cells; d.cell_begin = cell_begin;
+    d.cell_count = cell_count; d.vox_layout = vox_layout;
+    d.n_boxes = (long long)n_views * cell_count * nl;
+    if (d.n_boxes == 0) return 0;
+    const long long blocks = (d.n_boxes + 3) / 4;
+    d.per_xcd = (blocks + 7) / 8;
+    const dim3 grid((unsigned)(d.per_xcd * 8));
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((gather_kernel<4, FUSED>), grid, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
+                           g, d, vox);
+    else
+        hipLaunchKernelGGL((gather_kernel<1, FUSED>), grid, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
+                           g, d, vox);
+    return launch_status();
+}
+
+} // namespace
+
+extern "C" {
+
+int vfa_abi_version(void) { return VFA_ABI_VERSION; }
+
+int vfa_integral_image_f32(const float *feature, float *integral, int n_views, int C, int Hf, int Wf, void *stream)
+{
+    if (n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0) return VFA_ERR_BAD_ARGUMENT;
+    if (n_views == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(integral_rows_kernel, dim3(Hf, (C + kWave - 1) / kWave, n_views), dim3(kWave), 0, s, feature,
+                       integral, C, Hf, Wf);
+    int st = launch_status();
+    if (st) return st;
+    if (C % 4 == 0) {
+        const size_t row_vecs = (size_t)(Wf + 2) * C / 4, total = row_vecs * n_views;
+        hipLaunchKernelGGL((integral_cols_kernel<4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, integral, Hf,
+                           row_vecs, total);
+    } else {
+        const size_t row_vecs = (size_t)(Wf + 2) * C, total = row_vecs * n_views;
+        hipLaunchKernelGGL((integral_cols_kernel<1>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, integral, Hf,
+                           row_vecs, total);
+    }
+    return launch_status();
+}
+
+int vfa_box_params_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off,
+                       int n_views, int n_cells, int nl, int conv_kind, float img_w, float img_h, int Hf, int Wf,
+                       float cmin, float cmax, float *box, float *area, uint8_t *visible, void *stream)
+{
+    if (n_views < 0 || n_cells < 0 || nl <= 0 || Hf <= 0 || Wf <= 0 || conv_kind < 0 || conv_kind > 2)
+        return VFA_ERR_BAD_ARGUMENT;
+    const size_t total = (size_t)n_views * nl * n_cells;
+    if (total == 0) return 0;
+    BoxGeom g{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
+    hipLaunchKernelGGL(box_params_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       n_cells, nl, total, Hf, Wf, (float4 *)box, area, visible);
+    return launch_status();
+}
+
+int vfa_gather_f32(const float *integral, const float *box, const float *area, const uint8_t *visible, float *vox,
+                   int n_views, int C, int Hf, int Wf, int nl, int n_cells, int cell_begin, int cell_count,
+                   int vox_layout, void *stream)
+{
+    BoxGeom g{};
+    return launch_gather<false>(integral, box, area, visible, g, vox, n_views, C, Hf, Wf, nl, n_cells, cell_begin,
+                                cell_count, vox_layout, (hipStream_t)stream);
+}
+
+int vfa_project_gather_f32(const float *integral, const float *calibs, const float *grid, const float *z_layers,
+                           const float *corner_off, float *vox, int n_views, int C, int Hf, int Wf, int nl,
+                           int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w, float img_h,
+                           float cmin, float cmax, int vox_layout, void *stream)
+{
+    if (conv_kind < 0 || conv_kind > 2) return VFA_ERR_BAD_ARGUMENT;
+    BoxGeom g{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
+    return launch_gather<true>(integral, nullptr, nullptr, nullptr, g, vox, n_views, C, Hf, Wf, nl, n_cells, cell_begin,
+                               cell_count, vox_layout, (hipStream_t)stream);
+}
+
+int vfa_bias_relu_accumulate_f32(const float *lin, const float *bias, float *out, int n_views, size_t M, int N,
+                                 int accumulate, void *stream)
+{
+    if (n_views < 0 || N <= 0) return VFA_ERR_BAD_ARGUMENT;
+    const size_t MN = M * (size_t)N;
+    if (MN == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (N % 4 == 0)
+        hipLaunchKernelGGL((bias_relu_accumulate_kernel<4>), dim3(elementwise_blocks(MN / 4)), dim3(256), 0, s, lin, bias,
+                           out, n_views, MN, N, accumulate);
+    else
+        hipLaunchKernelGGL((bias_relu_accumulate_kernel<1>), dim3(elementwise_blocks(MN)), dim3(256), 0, s, lin, bias, out,
+                           n_views, MN, N, accumulate);
+    return launch_status();
+}
+
+int vfa_scale_view_sum_f32(const float *lin8, const float *lin16, const float *lin32, const float *bias8,
+                           const float *bias16, const float *bias32, float *ortho, int n_views, size_t M, int N,
+                           int accumulate, void *stream)
+{
+    if (n_views < 0 || N <= 0) return VFA_ERR_BAD_ARGUMENT;
+    const size_t MN = M * (size_t)N;
+    if (MN == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (N % 4 == 0)
+        hipLaunchKernelGGL((scale_view_sum_kernel<4>), dim3(elementwise_blocks(MN / 4)), dim3(256), 0, s, lin8, lin16, lin32,
+                           bias8, bias16, bias32, ortho, n_views, MN, N, accumulate);
+    else
+        hipLaunchKernelGGL((scale_view_sum_kernel<1>), dim3(elementwise_blocks(MN)), dim3(256), 0, s, lin8, lin16, lin32,
+                           bias8, bias16, bias32, ortho, n_views, MN, N, accumulate);
+    return launch_status();
+}
+
+} // extern "C"

@@ -1,0 +1,135 @@
+"""Functional wrappers, one per entry point of ``include/vfa_hip.h`` (no autograd, no fallback).
+
+Tensors are device tensors; every call is asynchronous on the current torch HIP stream.
+"""
+import torch
+
+from . import _lib
+
+
+def _f32c(t):
+    return t.to(dtype=torch.float32).contiguous()
+
+
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the entry points (bench.py's roofline leg).
+
+    Events are recorded on the current torch stream, which is the stream every kernel is launched on.
+    ``with KernelTimer() as kt: ...``; after a device synchronise ``kt.summary()`` gives, per entry point,
+    the number of launches and their total milliseconds.
+    """
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        out = {}
+        for name, e0, e1, tag in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, by_tag={}))
+            ms = e0.elapsed_time(e1)
+            d["launches"] += 1
+            d["ms"] += ms
+            t = d["by_tag"].setdefault(tag, dict(launches=0, ms=0.0))
+            t["launches"] += 1
+            t["ms"] += ms
+        return out
+
+
+def _launch(name, *args, tag=None):
+    kt = KernelTimer.active
+    if kt is None:
+        _lib.call(name, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call(name, *args)
+    e1.record()
+    kt.records.append((name, e0, e1, tag))
+
+
+def integral_image(features):
+    """(n,C,Hf,Wf) -> (n,Hf+2,Wf+2,C) zero-bordered channels-last integral images (reference vfa_op.py:172-173)."""
+    _lib.require_device(features)
+    features = _f32c(features)
+    n, C, Hf, Wf = features.shape
+    integral = torch.empty((n, Hf + 2, Wf + 2, C), dtype=torch.float32, device=features.device)
+    _launch("vfa_integral_image_f32", _lib.ptr(features), _lib.ptr(integral), n, C, Hf, Wf,
+            _lib.current_stream_handle(), tag=(n, C, Hf, Wf))
+    return integral
+
+
+def box_params(calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, feat_hw, crange=(-1, 0.95)):
+    """-> box (n,nl,cells,4), area (n,nl,cells), visible (n,nl,cells) uint8 (reference vfa_op.py:64-106)."""
+    _lib.require_device(calibs, grid_flat, z_layers, corner_off)
+    calibs = _f32c(calibs.reshape(-1, 12))
+    grid_flat, z_layers, corner_off = _f32c(grid_flat.reshape(-1, 3)), _f32c(z_layers), _f32c(corner_off.reshape(8, 3))
+    n, n_cells, nl = calibs.shape[0], grid_flat.shape[0], z_layers.numel()
+    dev = calibs.device
+    box = torch.empty((n, nl, n_cells, 4), dtype=torch.float32, device=dev)
+    area = torch.empty((n, nl, n_cells), dtype=torch.float32, device=dev)
+    visible = torch.empty((n, nl, n_cells), dtype=torch.uint8, device=dev)
+    _launch("vfa_box_params_f32", _lib.ptr(calibs), _lib.ptr(grid_flat), _lib.ptr(z_layers), _lib.ptr(corner_off),
+              n, n_cells, nl, int(conv_kind), float(image_wh[0]), float(image_wh[1]), int(feat_hw[0]), int(feat_hw[1]),
+              float(crange[0]), float(crange[1]), _lib.ptr(box), _lib.ptr(area), _lib.ptr(visible),
+              _lib.current_stream_handle())
+    return box, area, visible
+
+
+def gather(integral, box, area, visible, cell_begin=0, cell_count=None, layout=_lib.VOX_LAYER_MAJOR):
+    """Box pooling from precomputed box parameters -> vox (n, cell_count, nl*C) (reference vfa_op.py:112-120)."""
+    _lib.require_device(integral, box, area, visible)
+    n, Hp, Wp, C = integral.shape
+    _, nl, n_cells, _ = box.shape
+    cell_count = n_cells - cell_begin if cell_count is None else cell_count
+    vox = torch.empty((n, cell_count, nl * C), dtype=torch.float32, device=integral.device)
+    _launch("vfa_gather_f32", _lib.ptr(integral), _lib.ptr(box), _lib.ptr(area), _lib.ptr(visible), _lib.ptr(vox),
+              n, C, Hp - 2, Wp - 2, nl, n_cells, cell_begin, cell_count, layout, _lib.current_stream_handle())
+    return vox
+
+
+def project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, crange=(-1, 0.95),
+                   cell_begin=0, cell_count=None, layout=_lib.VOX_LAYER_MAJOR, out=None):
+    """Fused projection + box pooling -> vox (n, cell_count, nl*C) (reference vfa_op.py:64-120)."""
+    _lib.require_device(integral, calibs, grid_flat, z_layers, corner_off)
+    n, Hp, Wp, C = integral.shape
+    n_cells, nl = grid_flat.shape[0], z_layers.numel()
+    cell_count = n_cells - cell_begin if cell_count is None else cell_count
+    vox = out if out is not None else torch.empty((n, cell_count, nl * C), dtype=torch.float32,
+                                                  device=integral.device)
+    _launch("vfa_project_gather_f32", _lib.ptr(integral), _lib.ptr(calibs), _lib.ptr(grid_flat), _lib.ptr(z_layers),
+              _lib.ptr(corner_off), _lib.ptr(vox), n, C, Hp - 2, Wp - 2, nl, n_cells, cell_begin, cell_count,
+              int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), layout,
+              _lib.current_stream_handle(), tag=(n, C, Hp - 2, Wp - 2, nl, cell_count))
+    return vox
+
+
+def bias_relu_accumulate(lin, bias, out=None, accumulate=False):
+    """out (M,N) (+)= sum_v relu(lin[v] + bias) (reference vfa_op.py:124, vfanet.py:82)."""
+    _lib.require_device(lin, bias, out)
+    n, M, N = lin.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=lin.device)
+        accumulate = False
+    _launch("vfa_bias_relu_accumulate_f32", _lib.ptr(lin), _lib.ptr(bias), _lib.ptr(out), n, M, N,
+              1 if accumulate else 0, _lib.current_stream_handle())
+    return out
+
+
+def scale_view_sum(lin8, lin16, lin32, b8, b16, b32, out=None, accumulate=False):
+    """ortho (M,N) (+)= sum_v ((relu(lin8+b8) + relu(lin16+b16)) + relu(lin32+b32)) (reference vfanet.py:79, 82)."""
+    _lib.require_device(lin8, lin16, lin32, b8, b16, b32, out)
+    n, M, N = lin8.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=lin8.device)
+        accumulate = False
+    _launch("vfa_scale_view_sum_f32", _lib.ptr(lin8), _lib.ptr(lin16), _lib.ptr(lin32), _lib.ptr(b8), _lib.ptr(b16),
+              _lib.ptr(b32), _lib.ptr(out), n, M, N, 1 if accumulate else 0, _lib.current_stream_handle())
+    return out

@@ -1,0 +1,208 @@
+"""``VFA`` -- the voxel feature projector, MI355X-native, behind the reference's Python interface.
+
+Drop-in for the reference's ``vfa/model/vfa_op.py`` ``class VFA`` (:46-125): same constructor, same
+``forward(feature, calib, grid, crange, visualize)`` signature, same ``state_dict`` keys / shapes / dtypes
+(``z_corners`` int64 (nl,1,1,3), ``corners_offset`` f32 (1,1,1,1,8,3), ``collapse.weight`` (C, C*nl),
+``collapse.bias`` (C)), same error for an unknown dataset name.  What differs is where the work runs:
+
+    reference (stock torch ops, one camera at a time)          here (hand-written HIP, gfx950)
+    ---------------------------------------------------------  -------------------------------------------
+    cumsum(cumsum(f,-1),-2)                    vfa_op.py:173    vfa_integral_image_f32  (channels-last out)
+    corners + convert + project + clamp + bbox :64-88, :104-106 } vfa_project_gather_f32 (one wave per box,
+    4 x F.grid_sample + box mean + mask        :112-120         }   box parameters never leave the wave)
+    nn.Linear                                  :123             rocBLAS/hipBLASLt fp32 GEMM (torch.matmul)
+    relu, scale sum, view sum                  :124; vfanet.py:79,82   vfa_bias_relu_accumulate_f32 /
+                                                                        vfa_scale_view_sum_f32
+
+All cameras of one scale are processed by ONE launch of each kernel (``project_views``); the reference's
+per-camera ``forward`` is the ``n_views == 1`` case.  There is no CPU path: CPU tensors raise.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .utils import project  # noqa: F401  (re-exported like the reference module does)
+
+EPSILON = 1e-6
+MAXIMUM_AREA_RATIO = 0.3
+
+# bound on the transient voxel-feature buffer (n_views, cells, nl*C) fp32; larger grids are chunked over cells
+VOX_BYTES_LIMIT = int(os.environ.get("VFA_AMD_VOX_BYTES", str(8 << 30)))
+
+
+def _conv_kind(args):
+    """Dataset name -> world-unit conversion (reference ``convert``, vfa_op.py:37-44)."""
+    name = getattr(args, "data", None)
+    if name not in _lib.CONV_KIND:
+        # the reference falls off the end of its if/elif chain and hits an unbound local (vfa_op.py:38-44)
+        raise UnboundLocalError(f"local variable 'coord' referenced before assignment (args.data={name!r} is not one "
+                                f"of {sorted(_lib.CONV_KIND)})")
+    return _lib.CONV_KIND[name]
+
+
+class _IntegralImage(torch.autograd.Function):
+    """(n,C,Hf,Wf) feature maps -> (n,Hf+2,Wf+2,C) zero-bordered channels-last integral images."""
+
+    @staticmethod
+    def forward(ctx, feature):
+        return ops.integral_image(feature)
+
+    @staticmethod
+    def backward(ctx, grad_integral):
+        # d/df of a double cumsum = reverse double cumsum of the incoming gradient (interior only)
+        g = grad_integral[:, 1:-1, 1:-1, :]
+        g = g.flip(1).cumsum(1).flip(1).flip(2).cumsum(2).flip(2)
+        return g.permute(0, 3, 1, 2).contiguous()
+
+
+class _BoxPool(torch.autograd.Function):
+    """Integral images + camera geometry -> voxel features (n, cell_count, nl*C), column = layer*C + c."""
+
+    @staticmethod
+    def forward(ctx, integral, calibs, grid_flat, z_layers, corner_off, geom, cell_begin, cell_count):
+        conv_kind, img_w, img_h, cmin, cmax = geom
+        vox = ops.project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h),
+                                 (cmin, cmax), cell_begin, cell_count, _lib.VOX_LAYER_MAJOR)
+        ctx.save_for_backward(calibs, grid_flat, z_layers, corner_off)
+        ctx.meta = (geom, integral.shape, cell_begin, cell_count)
+        return vox
+
+    @staticmethod
+    def backward(ctx, grad_vox):
+        raise NotImplementedError("vfa_amd: the backward HIP kernels of the box pooling are not built yet")
+
+
+class _BiasReluSum(torch.autograd.Function):
+    """out (M,N) = sum_v relu(lin[v] + bias), views in index order (vfa_op.py:124 / vfanet.py:82)."""
+
+    @staticmethod
+    def forward(ctx, lin, bias):
+        out = ops.bias_relu_accumulate(lin, bias)
+        ctx.save_for_backward(lin, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lin, bias = ctx.saved_tensors
+        pre = lin if bias is None else lin + bias
+        g = grad_out.unsqueeze(0) * (pre > 0)
+        return g, (None if bias is None else g.sum(dim=(0, 1)))
+
+
+class VFA(nn.Module):
+    def __init__(self, channel, grid_height=160, cube_size=(25, 25, 32), feat_scale=1, args=None):
+        super().__init__()
+        self.cube_height = cube_size[2]
+        # (nl,1,1,3) rows (0, 0, z); dtype follows torch.arange exactly as in the reference (int64 for int sizes)
+        z = torch.arange(0, grid_height, cube_size[2])
+        z_corners = torch.zeros((z.numel(), 1, 1, 3), dtype=z.dtype)
+        z_corners[:, 0, 0, 2] = z
+        corners_offset = torch.Tensor(self.generate_cube(cube_size)).view(1, 1, 1, 1, 8, 3)
+        self.register_buffer("z_corners", z_corners)
+        self.register_buffer("corners_offset", corners_offset)
+        self.feat_scale = feat_scale  # kept for interface parity; unused by the reference too (vfa_op.py:57, :74)
+        self.args = args
+        self.channel = channel
+        self.num_grid_layer = z.numel()
+        self.collapse = nn.Linear(channel * self.num_grid_layer, channel)
+        self._geom_cache = None
+
+    # ------------------------------------------------------------------ geometry buffers for the kernels
+    def generate_cube(self, cub_size):
+        """(8,3) corner offsets: x -++--++-, y --++--++, z 0000hhhh (reference vfa_op.py:127-133)."""
+        l, w, h = cub_size
+        sx = np.array([-1, 1, 1, -1, -1, 1, 1, -1]) * (l / 2)
+        sy = np.array([-1, -1, 1, 1, -1, -1, 1, 1]) * (w / 2)
+        sz = np.array([0, 0, 0, 0, 1, 1, 1, 1]) * h
+        return np.stack([sx, sy, sz], axis=1)
+
+    def _kernel_geometry(self, device):
+        key = (str(device), self.z_corners._version, self.corners_offset._version, self.z_corners.data_ptr())
+        if self._geom_cache is None or self._geom_cache[0] != key:
+            z_layers = self.z_corners[:, 0, 0, 2].to(device=device, dtype=torch.float32).contiguous()
+            corner_off = self.corners_offset.to(device=device, dtype=torch.float32).reshape(8, 3).contiguous()
+            self._geom_cache = (key, z_layers, corner_off)
+        return self._geom_cache[1], self._geom_cache[2]
+
+    def layer_major_weight(self):
+        """collapse.weight with columns reordered from c*nl + layer (reference) to layer*C + c (kernel output)."""
+        w = self.collapse.weight
+        out_c = w.shape[0]
+        return w.view(out_c, self.channel, self.num_grid_layer).permute(0, 2, 1).reshape(out_c, -1)
+
+    # ------------------------------------------------------------------ batched projector
+    def project_views(self, features, calibs, grid, crange=(-1, 0.95)):
+        """All cameras of one scale at once.
+
+        features (n,C,Hf,Wf), calibs (n,3,4), grid (1,L,W,3) or (L,W,3)  ->  lin (n, L*W, C_out) =
+        vox . collapse.weight^T, WITHOUT bias and ReLU (the epilogue kernels add them while summing views).
+        """
+        _lib.require_device(features, calibs, grid)
+        conv_kind = _conv_kind(self.args)
+        img_h, img_w = (float(v) for v in self.args.image_size)  # the path uses image_size[::-1] (vfa_op.py:75)
+        n, C, Hf, Wf = features.shape
+        if C != self.channel:
+            raise ValueError(f"feature has {C} channels, VFA was built for {self.channel}")
+        dev = features.device
+        grid_flat = grid.reshape(-1, 3).to(dtype=torch.float32).contiguous()
+        calibs = calibs.reshape(n, 12).to(dtype=torch.float32).contiguous()
+        z_layers, corner_off = self._kernel_geometry(dev)
+        geom = (conv_kind, img_w, img_h, float(crange[0]), float(crange[1]))
+        n_cells, nl = grid_flat.shape[0], self.num_grid_layer
+
+        if n_cells == 0 or n == 0:
+            return features.new_zeros((n, n_cells, self.collapse.out_features))
+        integral = _IntegralImage.apply(features)
+        w_lm_t = self.layer_major_weight().t()
+        per_cell = n * nl * C * 4
+        chunk = max(1, min(n_cells, VOX_BYTES_LIMIT // max(per_cell, 1)))
+        outs = []
+        for begin in range(0, n_cells, chunk):
+            count = min(chunk, n_cells - begin)
+            vox = _BoxPool.apply(integral, calibs, grid_flat, z_layers, corner_off, geom, begin, count)
+            outs.append(torch.matmul(vox.view(n * count, nl * C), w_lm_t).view(n, count, -1))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+
+    # ------------------------------------------------------------------ reference interface
+    def forward(self, feature, calib, grid, crange=(-1, 0.95), visualize=False):
+        """feature (1,C,Hf,Wf), calib (3,4), grid (1,L,W,3) -> (1,C,L,W), ReLU'd (reference vfa_op.py:61-125)."""
+        if feature.shape[0] != 1:
+            raise ValueError("VFA.forward takes one camera (batch 1) like the reference; use project_views for many")
+        length, width = grid.shape[-3], grid.shape[-2]
+        if visualize:
+            self.visualize_cube(feature, calib, grid, crange)
+        lin = self.project_views(feature, calib.reshape(1, 3, 4), grid, crange)
+        ortho = _BiasReluSum.apply(lin, self.collapse.bias)
+        return ortho.view(1, length, width, -1).permute(0, 3, 1, 2)
+
+    def extra_repr(self):
+        return f"channel={self.channel}, layers={self.num_grid_layer}, data={getattr(self.args, 'data', None)}"
+
+    def visualize_cube(self, feature, calib, grid, crange=(-1, 0.95), viz_interval=10):
+        """Slow matplotlib side path (reference vfa_op.py:90-101, 135-168): draws every ``viz_interval``-th box."""
+        import matplotlib.pyplot as plt
+        import matplotlib.patches as patches
+        stages = box_parameters(self, calib.reshape(1, 3, 4), grid, feature.shape[-2:], crange)
+        box = ((stages["box"][0].cpu() + 1) / 2).numpy()
+        hf, wf = feature.shape[-2:]
+        fig, ax = plt.subplots()
+        ax.imshow(feature[0].detach().abs().sum(0).cpu().numpy())
+        for layer in range(box.shape[0]):
+            for l, t, r, b in box[layer, ::viz_interval]:
+                ax.add_patch(patches.Rectangle((l * wf, t * hf), (r - l) * wf, (b - t) * hf, fill=False, linewidth=0.5))
+        plt.show()
+        return fig
+
+
+def box_parameters(module, calibs, grid, feat_hw, crange=(-1, 0.95)):
+    """Stage output for tests / visualisation: box (n,nl,cells,4), area, visible of every view (vfa_op.py:64-106)."""
+    _lib.require_device(calibs, grid)
+    conv_kind = _conv_kind(module.args)
+    img_h, img_w = (float(v) for v in module.args.image_size)
+    z_layers, corner_off = module._kernel_geometry(calibs.device)
+    box, area, visible = ops.box_params(calibs, grid.reshape(-1, 3), z_layers, corner_off, conv_kind, (img_w, img_h),
+                                        feat_hw, crange)
+    return dict(box=box, area=area, visible=visible.bool())
