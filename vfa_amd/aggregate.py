@@ -85,4 +85,4 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
         ortho = torch.zeros((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
     if distributed:
         ortho = all_reduce_ortho(ortho, reduce_group)
-    return ortho.view(1, length, width, -1).permute(0, 3, 1, 2)
+    return ortho.view(1, length, width, vfa8.collapse.out_features).permute(0, 3, 1, 2)

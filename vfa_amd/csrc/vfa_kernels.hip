@@ -267,58 +267,35 @@ template <> __device__ __forceinline__ float4 vfma<4>(float4 a, float w, float4 
     return make_float4(fmaf(a.x, w, c.x), fmaf(a.y, w, c.y), fmaf(a.z, w, c.z), fmaf(a.w, w, c.w));
 }
 
-// bilinear sample, taps in the order nw, ne, sw, se: one rounded product then three FMAs (A.5)
-template <int VEC>
-__device__ __forceinline__ typename vec_of<VEC>::type bilinear(typename vec_of<VEC>::type nw, typename vec_of<VEC>::type ne,
-                                                               typename vec_of<VEC>::type sw, typename vec_of<VEC>::type se,
-                                                               const Axis &ax, const Axis &ay)
-{
-    const float wnw = ay.lo * ax.lo, wne = ay.lo * ax.hi, wsw = ay.hi * ax.lo, wse = ay.hi * ax.hi;
-    auto v = vmul<VEC>(nw, wnw);
-    v = vfma<VEC>(ne, wne, v);
-    v = vfma<VEC>(sw, wsw, v);
-    v = vfma<VEC>(se, wse, v);
-    return v;
-}
-
-// (((lt + rb) - rt) - lb) / area                                                        (A.6)
-__device__ __forceinline__ float box_mean(float lt, float rb, float rt, float lb, float area)
+// (((lt + rb) - rt) - lb) / area                                                         (A.6)
+// The quotient must be the correctly rounded IEEE quotient (the reference divides).  All channels of a box divide by
+// the same area, so the reciprocal r = RN(1/area) is formed once per box and each channel runs two Markstein
+// corrections:  q0 = RN(v r); q1 = RN(q0 + (v - area q0) r); q = RN(q1 + (v - area q1) r), residuals exact by FMA.
+// q1 is within half an ulp (+ o(ulp)) of v/area, i.e. faithful, and for a faithful q1 and r = RN(1/area) the last
+// step returns RN(v/area) (Markstein's theorem).  Holds while no intermediate leaves the normal range: v = 0 or
+// 2^-100 < |v / area| < 2^100, always true for feature maps (checked against true division: tools/check_division.c).
+__device__ __forceinline__ float box_mean(float lt, float rb, float rt, float lb, float area, float rcp)
 {
     float v = lt + rb;
     v = v - rt;
     v = v - lb;
-    return v / area;
+    const float q0 = v * rcp;
+    const float q1 = fmaf(fmaf(-area, q0, v), rcp, q0);
+    return fmaf(fmaf(-area, q1, v), rcp, q1);
 }
 template <int VEC>
 __device__ __forceinline__ typename vec_of<VEC>::type vbox_mean(typename vec_of<VEC>::type lt, typename vec_of<VEC>::type rb,
                                                                 typename vec_of<VEC>::type rt, typename vec_of<VEC>::type lb,
-                                                                float area);
-template <> __device__ __forceinline__ float vbox_mean<1>(float lt, float rb, float rt, float lb, float area)
+                                                                float area, float rcp);
+template <> __device__ __forceinline__ float vbox_mean<1>(float lt, float rb, float rt, float lb, float area, float rcp)
 {
-    return box_mean(lt, rb, rt, lb, area);
+    return box_mean(lt, rb, rt, lb, area, rcp);
 }
-template <> __device__ __forceinline__ float4 vbox_mean<4>(float4 lt, float4 rb, float4 rt, float4 lb, float area)
+template <>
+__device__ __forceinline__ float4 vbox_mean<4>(float4 lt, float4 rb, float4 rt, float4 lb, float area, float rcp)
 {
-    return make_float4(box_mean(lt.x, rb.x, rt.x, lb.x, area), box_mean(lt.y, rb.y, rt.y, lb.y, area),
-                       box_mean(lt.z, rb.z, rt.z, lb.z, area), box_mean(lt.w, rb.w, rt.w, lb.w, area));
-}
-
-// The 16 taps of a box are the product {top rows yt, yt+1, bottom rows yb, yb+1} x {left cols xl, xl+1,
-// right cols xr, xr+1}.  P[row][col] holds them; when the right pair coincides with / overlaps the left
-// pair (DXC = xr - xl = 0 or 1; boxes are often narrower than a feature pixel) the shared columns are
-// loaded once.  RB0/RB1 and CR0/CR1 name where the bottom rows / right columns live in P.
-template <int VEC, int DYC, int DXC>
-__device__ __forceinline__ typename vec_of<VEC>::type pool_box(const typename vec_of<VEC>::type (&P)[4][4], const Axis &xl,
-                                                               const Axis &xr, const Axis &yt, const Axis &yb,
-                                                               float area)
-{
-    constexpr int RB0 = DYC == 0 ? 0 : (DYC == 1 ? 1 : 2), RB1 = DYC == 0 ? 1 : 3;
-    constexpr int CR0 = DXC == 0 ? 0 : (DXC == 1 ? 1 : 2), CR1 = DXC == 0 ? 1 : 3;
-    const auto lt = bilinear<VEC>(P[0][0], P[0][1], P[1][0], P[1][1], xl, yt);
-    const auto rb = bilinear<VEC>(P[RB0][CR0], P[RB0][CR1], P[RB1][CR0], P[RB1][CR1], xr, yb);
-    const auto rt = bilinear<VEC>(P[0][CR0], P[0][CR1], P[1][CR0], P[1][CR1], xr, yt);
-    const auto lb = bilinear<VEC>(P[RB0][0], P[RB0][1], P[RB1][0], P[RB1][1], xl, yb);
-    return vbox_mean<VEC>(lt, rb, rt, lb, area);
+    return make_float4(box_mean(lt.x, rb.x, rt.x, lb.x, area, rcp), box_mean(lt.y, rb.y, rt.y, lb.y, area, rcp),
+                       box_mean(lt.z, rb.z, rt.z, lb.z, area, rcp), box_mean(lt.w, rb.w, rt.w, lb.w, area, rcp));
 }
 
 struct GatherDims {
@@ -327,124 +304,263 @@ struct GatherDims {
     long long per_xcd;    // blocks per XCD
 };
 
-// One wave per box; lanes are channels (VEC = 4: 64 lanes x float4 = 256 channels = one 1 KiB load per tap).
-// Box parameters are wave-uniform: they are computed once, moved to SGPRs and drive scalar branches
-// (invisible boxes exit before touching the integral image; duplicate taps are not loaded).
-// FUSED: the wave also projects the eight cube corners itself (lane k & 7 = corner k) and reduces
-// min / max with xor-shuffles, which is exact and order-insensitive.
+// Per-box record staged in LDS by phase 1 of the gather kernel (32 words = 8 x ds_read_b128, broadcast to the wave).
+// Tap offsets are BYTES relative to the view's padded image (unsigned 32-bit: one padded image is < 4 GiB); any
+// out-of-image tap is redirected to the zero border.  The 16 bilinear weights are formed here, once per box, in the
+// reference's rounding (each a single rounded product), so that phase 2 spends its VALU on the channel arithmetic.
+struct alignas(16) BoxHdr {  // what a wave needs before it can issue the tap loads of a run
+    int flags;       // bit 0 visible, bits 1-2 DXC, bits 3-4 DYC
+    int view;
+    int run_len;     // boxes from this one on (inside the wave's chunk) that are visible and share its tap set
+    float masked;    // value of a masked voxel: area * 0 (0, or NaN when the box itself is NaN)
+    unsigned col[4]; // xl, xl+1, xr, xr+1
+    unsigned row[4]; // yt, yt+1, yb, yb+1
+};
+struct alignas(16) BoxWeights { // what the channel arithmetic of one box needs
+    float lt[4];     // nw, ne, sw, se of sample (left, top)
+    float rb[4];
+    float rt[4];
+    float lb[4];
+    float area;
+    float rcp;       // RN(1 / area): the per-channel divisions share it (see box_mean)
+    unsigned out_row; // reference layout only: (view * cell_count + cell_local), column base = layer
+    int layer;
+};
+struct alignas(16) BoxRec {
+    BoxHdr h;
+    BoxWeights w;
+};
+static_assert(sizeof(BoxRec) == 128, "BoxRec must stay 8 x 16 bytes");
+
+constexpr int kTileBoxes = 128;           // boxes per workgroup
+constexpr int kPerWave = kTileBoxes / 4;  // contiguous boxes per wave in phase 2 (a power of two <= 64)
+
+__device__ __forceinline__ void bilinear_weights(float (&w)[4], const Axis &ax, const Axis &ay)
+{
+    w[0] = ay.lo * ax.lo; // nw
+    w[1] = ay.lo * ax.hi; // ne
+    w[2] = ay.hi * ax.lo; // sw
+    w[3] = ay.hi * ax.hi; // se
+}
+
+__device__ __forceinline__ void fill_record(BoxRec &rc, int view, float l, float t, float r, float b, float area, bool vis,
+                                            const GatherDims &d, unsigned &key_x, unsigned &key_y)
+{
+    const Axis xl = make_axis(l, d.Wf), xr = make_axis(r, d.Wf);
+    const Axis yt = make_axis(t, d.Hf), yb = make_axis(b, d.Hf);
+    const int dx = xr.i0 - xl.i0, dy = yb.i0 - yt.i0;
+    const int dxc = dx == 0 ? 0 : (dx == 1 ? 1 : 2), dyc = dy == 0 ? 0 : (dy == 1 ? 1 : 2);
+    rc.h.flags = (vis ? 1 : 0) | (dxc << 1) | (dyc << 3);
+    rc.h.view = view;
+    rc.w.area = area;
+    rc.w.rcp = 1.0f / area; // correctly rounded (hipcc's default fp32 division)
+    rc.h.masked = area * 0.0f;
+    const unsigned Wp = d.Wf + 2;
+    const int xs[4] = {xl.i0, xl.i0 + 1, xr.i0, xr.i0 + 1};
+    const int ys[4] = {yt.i0, yt.i0 + 1, yb.i0, yb.i0 + 1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        rc.h.col[k] = (unsigned)(min(max(xs[k], -1), d.Wf) + 1) * (unsigned)d.C * 4u;
+        rc.h.row[k] = (unsigned)(min(max(ys[k], -1), d.Hf) + 1) * Wp * (unsigned)d.C * 4u;
+    }
+    // the tap set of a box is named by (view, flags, clamped tap origins)
+    key_x = (unsigned)(min(max(xs[0], -1), 0xfffe) + 1) | ((unsigned)(min(max(xs[2], -1), 0xfffe) + 1) << 16);
+    key_y = (unsigned)(min(max(ys[0], -1), 0xfffe) + 1) | ((unsigned)(min(max(ys[2], -1), 0xfffe) + 1) << 16);
+    bilinear_weights(rc.w.lt, xl, yt);
+    bilinear_weights(rc.w.rb, xr, yb);
+    bilinear_weights(rc.w.rt, xr, yt);
+    bilinear_weights(rc.w.lb, xl, yb);
+}
+
+// bilinear sample from the four rounded weights, taps in the order nw, ne, sw, se: one product, three FMAs (A.5)
+template <int VEC>
+__device__ __forceinline__ typename vec_of<VEC>::type bilinear_w(typename vec_of<VEC>::type nw, typename vec_of<VEC>::type ne,
+                                                                 typename vec_of<VEC>::type sw, typename vec_of<VEC>::type se,
+                                                                 const float (&w)[4])
+{
+    auto v = vmul<VEC>(nw, w[0]);
+    v = vfma<VEC>(ne, w[1], v);
+    v = vfma<VEC>(sw, w[2], v);
+    v = vfma<VEC>(se, w[3], v);
+    return v;
+}
+
+
+// The 16 taps of a box are the product {top rows yt, yt+1, bottom rows yb, yb+1} x {left cols xl, xl+1, right cols
+// xr, xr+1}.  When the right pair coincides with / overlaps the left pair (DXC = xr - xl = 0 or 1; boxes are often
+// narrower than a feature pixel) the shared columns are loaded once, and likewise for rows (DYC).  Every (DYC, DXC)
+// variant is a straight-line body with its own register patch: NR x NC unique taps, all loads issued first.
+// `img` is wave-uniform (SGPR pair); `lane_off` and the record offsets are 32-bit VGPRs, so each tap costs one
+// v_add3_u32 and one global_load_dwordx4 with scalar base.
+template <int VEC, int DYC, int DXC>
+__device__ __forceinline__ void load_patch(typename vec_of<VEC>::type (&P)[4][4], const char *__restrict__ img,
+                                           unsigned lane_off, const unsigned (&row)[4], const unsigned (&col)[4])
+{
+    using V = typename vec_of<VEC>::type;
+    constexpr int NR = DYC == 0 ? 2 : (DYC == 1 ? 3 : 4), NC = DXC == 0 ? 2 : (DXC == 1 ? 3 : 4);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int rs = (DYC == 1 && r == 2) ? 3 : r; // unique rows: {0,1}, {0,1,3} or {0,1,2,3}
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int cs = (DXC == 1 && c == 2) ? 3 : c;
+            P[r][c] = *reinterpret_cast<const V *>(img + (row[rs] + col[cs] + lane_off));
+        }
+    }
+}
+
+template <int VEC, int DYC, int DXC>
+__device__ __forceinline__ typename vec_of<VEC>::type pool_patch(const typename vec_of<VEC>::type (&P)[4][4],
+                                                                 const BoxWeights &w)
+{
+    constexpr int RB0 = DYC == 0 ? 0 : (DYC == 1 ? 1 : 2), RB1 = RB0 + 1; // bottom row pair inside the patch
+    constexpr int CR0 = DXC == 0 ? 0 : (DXC == 1 ? 1 : 2), CR1 = CR0 + 1; // right column pair inside the patch
+    const auto lt = bilinear_w<VEC>(P[0][0], P[0][1], P[1][0], P[1][1], w.lt);
+    const auto rb = bilinear_w<VEC>(P[RB0][CR0], P[RB0][CR1], P[RB1][CR0], P[RB1][CR1], w.rb);
+    const auto rt = bilinear_w<VEC>(P[0][CR0], P[0][CR1], P[1][CR0], P[1][CR1], w.rt);
+    const auto lb = bilinear_w<VEC>(P[RB0][0], P[RB0][1], P[RB1][0], P[RB1][1], w.lb);
+    return vbox_mean<VEC>(lt, rb, rt, lb, w.area, w.rcp);
+}
+
+// Projection + box pooling.  A workgroup owns a tile of kTileBoxes consecutive boxes in (view, cell, layer) order.
+//   phase 1: one thread per box computes the box parameters (FUSED: projects the eight cube corners itself;
+//            otherwise reads box/area/visible) and stages a BoxRec in LDS;
+//   phase 2: the four waves walk the tile, one box per wave at a time, lanes = channels (VEC = 4: 64 lanes x float4 =
+//            256 channels = one 1 KiB load per tap).  The record is wave-uniform: masked boxes and duplicate taps are
+//            skipped by scalar branches.
 template <int VEC, bool FUSED>
-__global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ integral, const float4 *__restrict__ box,
+__global__ __launch_bounds__(256, 4) void gather_kernel(const float *__restrict__ integral, const float4 *__restrict__ box,
                                                      const float *__restrict__ area_in,
                                                      const uint8_t *__restrict__ visible_in, BoxGeom g, GatherDims d,
                                                      float *__restrict__ vox)
 {
     using V = typename vec_of<VEC>::type;
+    __shared__ BoxRec recs[kTileBoxes];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = uniform_i(threadIdx.x >> 6);
     const long long blk = xcd_contiguous(blockIdx.x, d.per_xcd);
-    const long long wid = blk * 4 + wave; // (view, cell_local, layer), layer fastest
-    if (wid >= d.n_boxes) return;
-    const int layer = (int)(wid % d.nl);
-    const long long vc = wid / d.nl;
-    const int cell_local = (int)(vc % d.cell_count), view = (int)(vc / d.cell_count);
-    const int cell = d.cell_begin + cell_local;
+    const long long tile0 = blk * kTileBoxes; // first box of the tile; box id = (view, cell_local, layer), layer fastest
+    if (tile0 >= d.n_boxes) return;
+    const int nb = (int)min((long long)kTileBoxes, d.n_boxes - tile0);
 
-    float l, t, r, b, area;
-    bool vis;
-    if constexpr (FUSED) {
-        const float *P = g.calibs + (size_t)view * 12;
-        const float gx = g.grid[cell * 3 + 0] + 0.0f;
-        const float gy = g.grid[cell * 3 + 1] + 0.0f;
-        const float gz = g.grid[cell * 3 + 2] + g.z_layers[layer];
-        float nu, nv;
-        project_corner(g, P, gx, gy, gz, lane & 7, nu, nv);
-        l = r = nu; t = b = nv;
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-            l = min_t(l, __shfl_xor(l, m));
-            r = max_t(r, __shfl_xor(r, m));
-            t = min_t(t, __shfl_xor(t, m));
-            b = max_t(b, __shfl_xor(b, m));
-        }
-        l = uniform_f(l); t = uniform_f(t); r = uniform_f(r); b = uniform_f(b);
-        area = box_area(l, t, r, b, d.Hf, d.Wf);
-        vis = box_visible(area, d.Hf, d.Wf);
-    } else {
-        const size_t bidx = ((size_t)view * d.nl + layer) * d.n_cells + cell;
-        const float4 bx = box[bidx];
-        l = uniform_f(bx.x); t = uniform_f(bx.y); r = uniform_f(bx.z); b = uniform_f(bx.w);
-        area = uniform_f(area_in[bidx]);
-        vis = uniform_i(visible_in[bidx]) != 0;
-    }
-
-    // output address of channel c of this box
-    const size_t row = (size_t)view * d.cell_count + cell_local;
-    const size_t K = (size_t)d.C * d.nl;
-    float *out_lm = vox + row * K + (size_t)layer * d.C; // layer-major: + c
-    float *out_ref = vox + row * K + layer;               // reference:   + c*nl
-
-    if (!vis) {
-        // (x / area) * 0: zero, or NaN when the box itself is NaN (reference: vox * visible)
-        const float z = area * 0.0f;
-        for (int c = lane * VEC; c < d.C; c += kWave * VEC) {
-            if (d.vox_layout == VFA_VOX_LAYER_MAJOR) {
-                if constexpr (VEC == 4) *reinterpret_cast<float4 *>(out_lm + c) = make_float4(z, z, z, z);
-                else out_lm[c] = z;
-            } else {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) out_ref[(size_t)(c + k) * d.nl] = z;
+    if ((int)threadIdx.x < nb) {
+        const long long wid = tile0 + threadIdx.x;
+        const int layer = (int)(wid % d.nl);
+        const long long vc = wid / d.nl;
+        const int cell = d.cell_begin + (int)(vc % d.cell_count), view = (int)(vc / d.cell_count);
+        float l, t, r, b, area;
+        bool vis;
+        if constexpr (FUSED) {
+            const float *P = g.calibs + (size_t)view * 12;
+            const float gx = g.grid[cell * 3 + 0] + 0.0f; // + the int64 zeros of z_corners (vfa_op.py:52, :64)
+            const float gy = g.grid[cell * 3 + 1] + 0.0f;
+            const float gz = g.grid[cell * 3 + 2] + g.z_layers[layer];
+            l = t = r = b = 0.0f;
+#pragma unroll 1
+            for (int k = 0; k < 8; ++k) {
+                float nu, nv;
+                project_corner(g, P, gx, gy, gz, k, nu, nv);
+                if (k == 0) { l = r = nu; t = b = nv; }
+                else { l = min_t(l, nu); r = max_t(r, nu); t = min_t(t, nv); b = max_t(b, nv); }
             }
-        }
-        return;
-    }
-
-    const Axis xl = make_axis(l, d.Wf), xr = make_axis(r, d.Wf);
-    const Axis yt = make_axis(t, d.Hf), yb = make_axis(b, d.Hf);
-    // padded coordinates: any out-of-image tap lands on the zero border
-    const int Wp = d.Wf + 2;
-    auto px = [&](int x) { return uniform_i(min(max(x, -1), d.Wf) + 1); };
-    auto py = [&](int y) { return uniform_i(min(max(y, -1), d.Hf) + 1); };
-    const int dx = uniform_i(xr.i0 - xl.i0), dy = uniform_i(yb.i0 - yt.i0);
-    const int dxc = dx == 0 ? 0 : (dx == 1 ? 1 : 2), dyc = dy == 0 ? 0 : (dy == 1 ? 1 : 2);
-    const int colx[4] = {px(xl.i0), px(xl.i0 + 1), px(xr.i0), px(xr.i0 + 1)};
-    const int rowy[4] = {py(yt.i0), py(yt.i0 + 1), py(yb.i0), py(yb.i0 + 1)};
-    const float *img = integral + (size_t)view * (d.Hf + 2) * Wp * d.C;
-
-    for (int c = lane * VEC; c < d.C; c += kWave * VEC) {
-        V P[4][4];
-        auto tap = [&](int ry, int cx) {
-            return *reinterpret_cast<const V *>(img + ((size_t)rowy[ry] * Wp + colx[cx]) * d.C + c);
-        };
-        auto load_row = [&](int ry) {
-            P[ry][0] = tap(ry, 0);
-            P[ry][1] = tap(ry, 1);
-            if (dxc == 2) P[ry][2] = tap(ry, 2);
-            if (dxc >= 1) P[ry][3] = tap(ry, 3);
-        };
-        load_row(0);
-        load_row(1);
-        if (dyc == 2) load_row(2);
-        if (dyc >= 1) load_row(3);
-
-        V res;
-        switch (dyc * 3 + dxc) {
-        case 0: res = pool_box<VEC, 0, 0>(P, xl, xr, yt, yb, area); break;
-        case 1: res = pool_box<VEC, 0, 1>(P, xl, xr, yt, yb, area); break;
-        case 2: res = pool_box<VEC, 0, 2>(P, xl, xr, yt, yb, area); break;
-        case 3: res = pool_box<VEC, 1, 0>(P, xl, xr, yt, yb, area); break;
-        case 4: res = pool_box<VEC, 1, 1>(P, xl, xr, yt, yb, area); break;
-        case 5: res = pool_box<VEC, 1, 2>(P, xl, xr, yt, yb, area); break;
-        case 6: res = pool_box<VEC, 2, 0>(P, xl, xr, yt, yb, area); break;
-        case 7: res = pool_box<VEC, 2, 1>(P, xl, xr, yt, yb, area); break;
-        default: res = pool_box<VEC, 2, 2>(P, xl, xr, yt, yb, area); break;
-        }
-        if (d.vox_layout == VFA_VOX_LAYER_MAJOR) {
-            *reinterpret_cast<V *>(out_lm + c) = res;
+            area = box_area(l, t, r, b, d.Hf, d.Wf);
+            vis = box_visible(area, d.Hf, d.Wf);
         } else {
-            const float *rs = reinterpret_cast<const float *>(&res);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) out_ref[(size_t)(c + k) * d.nl] = rs[k];
+            const size_t bidx = ((size_t)view * d.nl + layer) * d.n_cells + cell;
+            const float4 bx = box[bidx];
+            l = bx.x; t = bx.y; r = bx.z; b = bx.w;
+            area = area_in[bidx];
+            vis = visible_in[bidx] != 0;
         }
+        BoxRec &rc = recs[threadIdx.x];
+        unsigned key_x, key_y;
+        fill_record(rc, view, l, t, r, b, area, vis, d, key_x, key_y);
+        rc.w.out_row = (unsigned)vc;
+        rc.w.layer = layer;
+        // Runs of boxes with one tap set: lanes are consecutive boxes, a wave's chunk in phase 2 is kPerWave of them.
+        // cont = "this box continues the run of the previous lane"; run_len counts the set bits that follow.
+        const int tag = (view << 5) | rc.h.flags;
+        const bool cont = vis && (lane & (kPerWave - 1)) != 0 && __shfl_up(tag, 1) == tag &&
+                          __shfl_up(key_x, 1) == key_x && __shfl_up(key_y, 1) == key_y;
+        const unsigned long long mask = __ballot(cont);
+        const unsigned long long after = lane == 63 ? 0ull : (mask >> (lane + 1));
+        const int follow = after == ~0ull ? 64 : __builtin_ctzll(~after);
+        rc.h.run_len = 1 + min(follow, kPerWave - 1 - (lane & (kPerWave - 1)));
+    }
+    __syncthreads();
+
+    const size_t img_stride = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C * sizeof(float);
+    const bool layer_major = d.vox_layout == VFA_VOX_LAYER_MAJOR;
+    const unsigned c_bytes = (unsigned)d.C * 4u;
+    // Each wave walks a contiguous quarter of the tile, so consecutive boxes are neighbouring cells / layers.  Their
+    // tap sets often coincide (a cell is a fraction of a feature pixel wide): a run of such boxes loads its register
+    // patch once and pools it with each box's weights.
+    const int j_end = min(nb, (wave + 1) * kPerWave);
+    int j = wave * kPerWave;
+    while (j < j_end) {
+        const BoxHdr &h = recs[j].h;
+        const int flags = uniform_i(h.flags);
+        char *out0 = reinterpret_cast<char *>(vox) + (size_t)(tile0 + j) * c_bytes; // layer-major address of box j
+        if (!(flags & 1)) {
+            const float z = h.masked;
+            char *out = layer_major ? out0
+                                    : reinterpret_cast<char *>(vox + (size_t)uniform_i(recs[j].w.out_row) * d.C * d.nl +
+                                                               uniform_i(recs[j].w.layer));
+#pragma unroll 1
+            for (int c = lane * VEC; c < d.C; c += kWave * VEC) {
+                if (layer_major) {
+                    if constexpr (VEC == 4) *reinterpret_cast<float4 *>(out + c * 4) = make_float4(z, z, z, z);
+                    else *reinterpret_cast<float *>(out + c * 4) = z;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) reinterpret_cast<float *>(out)[(size_t)(c + k) * d.nl] = z;
+                }
+            }
+            ++j;
+            continue;
+        }
+        const int run = uniform_i(h.run_len);
+        const char *img = reinterpret_cast<const char *>(integral) + (size_t)uniform_i(h.view) * img_stride;
+        unsigned col[4], row[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            col[k] = h.col[k];
+            row[k] = h.row[k];
+        }
+#pragma unroll 1
+        for (int c = lane * VEC; c < d.C; c += kWave * VEC) {
+            const unsigned lane_off = (unsigned)c * 4u;
+#define VFA_VARIANT(DY, DX)                                                                                     \
+    {                                                                                                           \
+        V P[4][4];                                                                                              \
+        load_patch<VEC, DY, DX>(P, img, lane_off, row, col);                                                    \
+        for (int k = 0; k < run; ++k) {                                                                         \
+            const BoxWeights w = recs[j + k].w;                                                                 \
+            const V res = pool_patch<VEC, DY, DX>(P, w);                                                        \
+            if (layer_major) {                                                                                  \
+                *reinterpret_cast<V *>(out0 + (size_t)k * c_bytes + lane_off) = res;                            \
+            } else {                                                                                            \
+                float *o = vox + (size_t)uniform_i(w.out_row) * d.C * d.nl + uniform_i(w.layer);                \
+                const float *rs = reinterpret_cast<const float *>(&res);                                        \
+                _Pragma("unroll") for (int q = 0; q < VEC; ++q) o[(size_t)(c + q) * d.nl] = rs[q];             \
+            }                                                                                                   \
+        }                                                                                                       \
+    }                                                                                                           \
+    break;
+            switch (flags >> 1) { // DXC | DYC << 2
+            case 0: VFA_VARIANT(0, 0)
+            case 1: VFA_VARIANT(0, 1)
+            case 2: VFA_VARIANT(0, 2)
+            case 4: VFA_VARIANT(1, 0)
+            case 5: VFA_VARIANT(1, 1)
+            case 6: VFA_VARIANT(1, 2)
+            case 8: VFA_VARIANT(2, 0)
+            case 9: VFA_VARIANT(2, 1)
+            default: VFA_VARIANT(2, 2)
+            }
+#undef VFA_VARIANT
+        }
+        j += run;
     }
 }
 
@@ -549,7 +665,7 @@ int launch_gather(const float *integral, const float *box, const float *area, co
     d.cell_count = cell_count; d.vox_layout = vox_layout;
     d.n_boxes = (long long)n_views * cell_count * nl;
     if (d.n_boxes == 0) return 0;
-    const long long blocks = (d.n_boxes + 3) / 4;
+    const long long blocks = (d.n_boxes + kTileBoxes - 1) / kTileBoxes;
     d.per_xcd = (blocks + 7) / 8;
     const dim3 grid((unsigned)(d.per_xcd * 8));
     if (C % 4 == 0)

@@ -176,7 +176,7 @@ class VFA(nn.Module):
             self.visualize_cube(feature, calib, grid, crange)
         lin = self.project_views(feature, calib.reshape(1, 3, 4), grid, crange)
         ortho = _BiasReluSum.apply(lin, self.collapse.bias)
-        return ortho.view(1, length, width, -1).permute(0, 3, 1, 2)
+        return ortho.view(1, length, width, self.collapse.out_features).permute(0, 3, 1, 2)
 
     def extra_repr(self):
         return f"channel={self.channel}, layers={self.num_grid_layer}, data={getattr(self.args, 'data', None)}"
