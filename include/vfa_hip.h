@@ -21,7 +21,8 @@
  *
  * Layouts
  *   feature   (n_views, C, Hf, Wf)          NCHW, as the reference's lateral maps
- *   integral  (n_views, Hf, Wf, C)          channels-last, so one tap of one box is C contiguous floats
+ *   integral  (n_views, Hf+2, Wf+2, C)      channels-last with a one-pixel ZERO border: one tap of one box is C
+ *                                           contiguous floats and grid_sample's zeros padding is a plain load
  *   box       (n_views, nl, n_cells, 4)     left, top, right, bottom in normalised [-1,1] image coords
  *   area      (n_views, nl, n_cells)
  *   visible   (n_views, nl, n_cells)        0/1 bytes
@@ -54,7 +55,8 @@ extern "C" {
 int vfa_abi_version(void);
 
 /* Integral image of every feature map: cumsum over W then over H, double accumulator rounded to
- * fp32 at every element (what ATen's CPU cumsum does).        replaces vfa_op.py:110, 172-173 */
+ * fp32 at every element (what ATen's CPU cumsum does), written channels-last inside a zero border.
+ *                                                               replaces vfa_op.py:110, 172-173 */
 int vfa_integral_image_f32(const float *feature, float *integral, int n_views, int C, int Hf, int Wf,
                            void *stream);
 
@@ -75,12 +77,27 @@ int vfa_gather_f32(const float *integral, const float *box, const float *area, c
                    int n_views, int C, int Hf, int Wf, int nl, int n_cells, int cell_begin, int cell_count,
                    int vox_layout, void *stream);
 
-/* Fused form of the two entry points above: every wave projects the eight cube corners of its box on
- * eight lanes, reduces min/max with wave shuffles and pools; box/area/visible never touch memory. */
+/* Fused form of the two entry points above: each workgroup computes the box parameters of its tile of
+ * boxes itself (one thread per box) and stages them in LDS; box/area/visible never touch HBM.
+ *                                                               replaces vfa_op.py:64-120 */
 int vfa_project_gather_f32(const float *integral, const float *calibs, const float *grid, const float *z_layers,
                            const float *corner_off, float *vox, int n_views, int C, int Hf, int Wf, int nl,
                            int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w, float img_h,
                            float cmin, float cmax, int vox_layout, void *stream);
+
+/* Backward of vfa_project_gather_f32 with respect to the integral images (training: the reference back-propagates
+ * through the path with autograd, trainer.py:41; calib and grid carry no gradient).  grad_vox is layer-major
+ * (n_views, cell_count, nl*C); grad_integral (n_views, Hf+2, Wf+2, C) is zeroed first unless `accumulate`.
+ * Scatter-add with float atomics: results are not bit-reproducible run to run. */
+int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, const float *grid, const float *z_layers,
+                                    const float *corner_off, float *grad_integral, int n_views, int C, int Hf, int Wf,
+                                    int nl, int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w,
+                                    float img_h, float cmin, float cmax, int accumulate, void *stream);
+
+/* Backward of vfa_integral_image_f32: reverse cumsum over H (in place on grad_integral, which is destroyed) then over
+ * W, written as NCHW grad_feature (n_views, C, Hf, Wf). */
+int vfa_integral_image_backward_f32(float *grad_integral, float *grad_feature, int n_views, int C, int Hf, int Wf,
+                                    void *stream);
 
 /* Epilogue of `collapse` for one VFA call batch:  out = (accumulate ? out : 0) + sum_v relu(lin[v] + bias)
  * with views added in index order.            replaces vfa_op.py:124 (ReLU) and vfanet.py:82 (view sum)

@@ -35,10 +35,6 @@ __device__ __forceinline__ float min_t(float a, float b) { return (a != a || a <
 __device__ __forceinline__ float max_t(float a, float b) { return (a != a || a > b) ? a : b; }
 
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float uniform_f(float v)
-{
-    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-}
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Give every XCD one
 // contiguous eighth of the logical work so that neighbouring boxes -- whose image footprints overlap --
@@ -422,27 +418,14 @@ __device__ __forceinline__ typename vec_of<VEC>::type pool_patch(const typename 
     return vbox_mean<VEC>(lt, rb, rt, lb, w.area, w.rcp);
 }
 
-// Projection + box pooling.  A workgroup owns a tile of kTileBoxes consecutive boxes in (view, cell, layer) order.
-//   phase 1: one thread per box computes the box parameters (FUSED: projects the eight cube corners itself;
-//            otherwise reads box/area/visible) and stages a BoxRec in LDS;
-//   phase 2: the four waves walk the tile, one box per wave at a time, lanes = channels (VEC = 4: 64 lanes x float4 =
-//            256 channels = one 1 KiB load per tap).  The record is wave-uniform: masked boxes and duplicate taps are
-//            skipped by scalar branches.
-template <int VEC, bool FUSED>
-__global__ __launch_bounds__(256, 4) void gather_kernel(const float *__restrict__ integral, const float4 *__restrict__ box,
-                                                     const float *__restrict__ area_in,
-                                                     const uint8_t *__restrict__ visible_in, BoxGeom g, GatherDims d,
-                                                     float *__restrict__ vox)
+// Phase 1 of the gather kernels: thread i of the workgroup computes the parameters of box tile0 + i (FUSED: projects
+// the eight cube corners itself; otherwise reads box/area/visible) and stages its BoxRec in LDS.
+template <bool FUSED>
+__device__ __forceinline__ void stage_box_records(BoxRec *recs, long long tile0, int nb, int lane,
+                                                  const float4 *__restrict__ box, const float *__restrict__ area_in,
+                                                  const uint8_t *__restrict__ visible_in, const BoxGeom &g,
+                                                  const GatherDims &d)
 {
-    using V = typename vec_of<VEC>::type;
-    __shared__ BoxRec recs[kTileBoxes];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = uniform_i(threadIdx.x >> 6);
-    const long long blk = xcd_contiguous(blockIdx.x, d.per_xcd);
-    const long long tile0 = blk * kTileBoxes; // first box of the tile; box id = (view, cell_local, layer), layer fastest
-    if (tile0 >= d.n_boxes) return;
-    const int nb = (int)min((long long)kTileBoxes, d.n_boxes - tile0);
-
     if ((int)threadIdx.x < nb) {
         const long long wid = tile0 + threadIdx.x;
         const int layer = (int)(wid % d.nl);
@@ -487,6 +470,30 @@ __global__ __launch_bounds__(256, 4) void gather_kernel(const float *__restrict_
         const int follow = after == ~0ull ? 64 : __builtin_ctzll(~after);
         rc.h.run_len = 1 + min(follow, kPerWave - 1 - (lane & (kPerWave - 1)));
     }
+}
+
+// Projection + box pooling.  A workgroup owns a tile of kTileBoxes consecutive boxes in (view, cell, layer) order.
+//   phase 1: one thread per box computes the box parameters (FUSED: projects the eight cube corners itself;
+//            otherwise reads box/area/visible) and stages a BoxRec in LDS;
+//   phase 2: the four waves walk the tile, one box per wave at a time, lanes = channels (VEC = 4: 64 lanes x float4 =
+//            256 channels = one 1 KiB load per tap).  The record is wave-uniform: masked boxes and duplicate taps are
+//            skipped by scalar branches.
+template <int VEC, bool FUSED>
+__global__ __launch_bounds__(256, 4) void gather_kernel(const float *__restrict__ integral, const float4 *__restrict__ box,
+                                                     const float *__restrict__ area_in,
+                                                     const uint8_t *__restrict__ visible_in, BoxGeom g, GatherDims d,
+                                                     float *__restrict__ vox)
+{
+    using V = typename vec_of<VEC>::type;
+    __shared__ BoxRec recs[kTileBoxes];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = uniform_i(threadIdx.x >> 6);
+    const long long blk = xcd_contiguous(blockIdx.x, d.per_xcd);
+    const long long tile0 = blk * kTileBoxes; // first box of the tile; box id = (view, cell_local, layer), layer fastest
+    if (tile0 >= d.n_boxes) return;
+    const int nb = (int)min((long long)kTileBoxes, d.n_boxes - tile0);
+
+    stage_box_records<FUSED>(recs, tile0, nb, lane, box, area_in, visible_in, g, d);
     __syncthreads();
 
     const size_t img_stride = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C * sizeof(float);
@@ -561,6 +568,121 @@ __global__ __launch_bounds__(256, 4) void gather_kernel(const float *__restrict_
 #undef VFA_VARIANT
         }
         j += run;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of the box pooling: d vox -> d integral (scatter-add), then d integral -> d feature (reverse scans).
+// The reference trains through this path with autograd (trainer.py:41); there is no reference code to mirror, only
+// the derivative of vfa_op.py:112-119.  Not bit-reproducible: float atomics sum in arrival order.
+// ------------------------------------------------------------------------------------------------
+// Combined weight of every unique tap of a box: + lt + rb - rt - lb, scaled by 1/area.
+template <int DYC, int DXC>
+__device__ __forceinline__ void scatter_box(float *__restrict__ gimg, int C, int lane, const BoxHdr &h, const BoxWeights &w,
+                                            const float *__restrict__ gvox)
+{
+    constexpr int NR = DYC == 0 ? 2 : (DYC == 1 ? 3 : 4), NC = DXC == 0 ? 2 : (DXC == 1 ? 3 : 4);
+    constexpr int RB0 = DYC == 0 ? 0 : (DYC == 1 ? 1 : 2), RB1 = RB0 + 1;
+    constexpr int CR0 = DXC == 0 ? 0 : (DXC == 1 ? 1 : 2), CR1 = CR0 + 1;
+    float W[NR][NC];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) W[r][c] = 0.0f;
+    W[0][0] += w.lt[0]; W[0][1] += w.lt[1]; W[1][0] += w.lt[2]; W[1][1] += w.lt[3];
+    W[RB0][CR0] += w.rb[0]; W[RB0][CR1] += w.rb[1]; W[RB1][CR0] += w.rb[2]; W[RB1][CR1] += w.rb[3];
+    W[0][CR0] -= w.rt[0]; W[0][CR1] -= w.rt[1]; W[1][CR0] -= w.rt[2]; W[1][CR1] -= w.rt[3];
+    W[RB0][0] -= w.lb[0]; W[RB0][1] -= w.lb[1]; W[RB1][0] -= w.lb[2]; W[RB1][1] -= w.lb[3];
+    for (int c = lane; c < C; c += kWave) { // one dword per lane: 256 contiguous bytes per atomic wave-instruction
+        const float gv = gvox[c] / w.area;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int rs = (DYC == 1 && r == 2) ? 3 : r;
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) {
+                const int cs = (DXC == 1 && cc == 2) ? 3 : cc;
+                unsafeAtomicAdd(gimg + ((h.row[rs] + h.col[cs]) >> 2) + c, gv * W[r][cc]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_backward_kernel(const float *__restrict__ grad_vox, BoxGeom g, GatherDims d,
+                                                              float *__restrict__ grad_integral)
+{
+    __shared__ BoxRec recs[kTileBoxes];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = uniform_i(threadIdx.x >> 6);
+    const long long blk = xcd_contiguous(blockIdx.x, d.per_xcd);
+    const long long tile0 = blk * kTileBoxes;
+    if (tile0 >= d.n_boxes) return;
+    const int nb = (int)min((long long)kTileBoxes, d.n_boxes - tile0);
+    stage_box_records<true>(recs, tile0, nb, lane, nullptr, nullptr, nullptr, g, d);
+    __syncthreads();
+    const size_t img_floats = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C;
+    for (int j = wave; j < nb; j += 4) {
+        const BoxHdr h = recs[j].h;
+        const int flags = uniform_i(h.flags);
+        if (!(flags & 1)) continue; // masked voxels pass no gradient
+        const BoxWeights w = recs[j].w;
+        float *gimg = grad_integral + (size_t)uniform_i(h.view) * img_floats;
+        const float *gvox = grad_vox + (size_t)(tile0 + j) * d.C; // layer-major
+        switch (flags >> 1) {
+        case 0: scatter_box<0, 0>(gimg, d.C, lane, h, w, gvox); break;
+        case 1: scatter_box<0, 1>(gimg, d.C, lane, h, w, gvox); break;
+        case 2: scatter_box<0, 2>(gimg, d.C, lane, h, w, gvox); break;
+        case 4: scatter_box<1, 0>(gimg, d.C, lane, h, w, gvox); break;
+        case 5: scatter_box<1, 1>(gimg, d.C, lane, h, w, gvox); break;
+        case 6: scatter_box<1, 2>(gimg, d.C, lane, h, w, gvox); break;
+        case 8: scatter_box<2, 0>(gimg, d.C, lane, h, w, gvox); break;
+        case 9: scatter_box<2, 1>(gimg, d.C, lane, h, w, gvox); break;
+        default: scatter_box<2, 2>(gimg, d.C, lane, h, w, gvox); break;
+        }
+    }
+}
+
+// d integral (n, Hf+2, Wf+2, C) -> reverse cumsum along H, in place on the interior (the border carries no gradient
+// to the features: it is constant zero in the forward pass).
+__global__ __launch_bounds__(256) void integral_cols_backward_kernel(float *__restrict__ io, int H, size_t row_elems,
+                                                                     size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t v = i / row_elems, r = i % row_elems;
+    float *p = io + v * (size_t)(H + 2) * row_elems + r + row_elems; // first interior row
+    double acc = 0.0;
+    for (int y = H - 1; y >= 0; --y) {
+        acc += (double)p[(size_t)y * row_elems];
+        p[(size_t)y * row_elems] = (float)acc;
+    }
+}
+
+// reverse cumsum along W of the (already H-scanned) channels-last gradient, written as NCHW d feature.
+// One wave owns 64 channels of one image row; grid = (Hf, ceil(C/64), n_views), block = 64.
+__global__ __launch_bounds__(kWave) void integral_rows_backward_kernel(const float *__restrict__ gi, float *__restrict__ gf,
+                                                                       int C, int H, int W)
+{
+    __shared__ float tile[kWave][kRowChunk + 1];
+    const int lane = threadIdx.x;
+    const int y = blockIdx.x, c0 = blockIdx.y * kWave, v = blockIdx.z;
+    const int nch = min(kWave, C - c0);
+    const size_t plane = (size_t)H * W;
+    float *dst = gf + ((size_t)v * C + c0) * plane + (size_t)y * W;
+    const float *src = gi + (((size_t)v * (H + 2) + (y + 1)) * (W + 2) + 1) * C + c0; // interior pixel (y, 0)
+    const bool active = lane < nch;
+    double acc = 0.0;
+    for (int x1 = W; x1 > 0; x1 -= kRowChunk) { // chunks from the right
+        const int x0 = max(0, x1 - kRowChunk), nx = x1 - x0;
+        if (active)
+            for (int k = nx - 1; k >= 0; --k) {
+                acc += (double)src[(size_t)(x0 + k) * C + lane];
+                tile[lane][k] = (float)acc;
+            }
+        __syncthreads();
+        const int j = lane & (kRowChunk - 1);
+        for (int r = lane >> 5; r < nch; r += 2)
+            if (j < nx) dst[(size_t)r * plane + x0 + j] = tile[r][j];
+        __syncthreads();
     }
 }
 
@@ -736,6 +858,51 @@ int vfa_project_gather_f32(const float *integral, const float *calibs, const flo
     BoxGeom g{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
     return launch_gather<true>(integral, nullptr, nullptr, nullptr, g, vox, n_views, C, Hf, Wf, nl, n_cells, cell_begin,
                                cell_count, vox_layout, (hipStream_t)stream);
+}
+
+int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, const float *grid, const float *z_layers,
+                                    const float *corner_off, float *grad_integral, int n_views, int C, int Hf, int Wf,
+                                    int nl, int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w,
+                                    float img_h, float cmin, float cmax, int accumulate, void *stream)
+{
+    if (n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0 || nl <= 0 || n_cells < 0 || cell_begin < 0 || cell_count < 0 ||
+        cell_begin + cell_count > n_cells || conv_kind < 0 || conv_kind > 2)
+        return VFA_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        const size_t bytes = (size_t)n_views * (Hf + 2) * (Wf + 2) * C * sizeof(float);
+        if (bytes) {
+            const hipError_t e = hipMemsetAsync(grad_integral, 0, bytes, s);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    BoxGeom g{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
+    GatherDims d;
+    d.C = C; d.Hf = Hf; d.Wf = Wf; d.nl = nl; d.n_cells = n_cells; d.cell_begin = cell_begin;
+    d.cell_count = cell_count; d.vox_layout = VFA_VOX_LAYER_MAJOR;
+    d.n_boxes = (long long)n_views * cell_count * nl;
+    if (d.n_boxes == 0) return 0;
+    const long long blocks = (d.n_boxes + kTileBoxes - 1) / kTileBoxes;
+    d.per_xcd = (blocks + 7) / 8;
+    hipLaunchKernelGGL(gather_backward_kernel, dim3((unsigned)(d.per_xcd * 8)), dim3(256), 0, s, grad_vox, g, d,
+                       grad_integral);
+    return launch_status();
+}
+
+int vfa_integral_image_backward_f32(float *grad_integral, float *grad_feature, int n_views, int C, int Hf, int Wf,
+                                    void *stream)
+{
+    if (n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0) return VFA_ERR_BAD_ARGUMENT;
+    if (n_views == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t row_elems = (size_t)(Wf + 2) * C, total = row_elems * n_views;
+    hipLaunchKernelGGL(integral_cols_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, grad_integral,
+                       Hf, row_elems, total);
+    int st = launch_status();
+    if (st) return st;
+    hipLaunchKernelGGL(integral_rows_backward_kernel, dim3(Hf, (C + kWave - 1) / kWave, n_views), dim3(kWave), 0, s,
+                       grad_integral, grad_feature, C, Hf, Wf);
+    return launch_status();
 }
 
 int vfa_bias_relu_accumulate_f32(const float *lin, const float *bias, float *out, int n_views, size_t M, int N,

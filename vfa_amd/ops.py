@@ -111,6 +111,35 @@ def project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind,
     return vox
 
 
+def project_gather_backward(grad_vox, integral_shape, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh,
+                            crange=(-1, 0.95), cell_begin=0, cell_count=None, out=None, accumulate=False):
+    """d vox (n, cell_count, nl*C) layer-major -> d integral (n, Hf+2, Wf+2, C) by scatter-add (float atomics)."""
+    _lib.require_device(grad_vox, calibs, grid_flat, z_layers, corner_off, out)
+    n, Hp, Wp, C = integral_shape
+    n_cells, nl = grid_flat.shape[0], z_layers.numel()
+    cell_count = n_cells - cell_begin if cell_count is None else cell_count
+    grad_vox = _f32c(grad_vox)
+    if out is None:
+        out = torch.empty(tuple(integral_shape), dtype=torch.float32, device=grad_vox.device)
+        accumulate = False
+    _launch("vfa_project_gather_backward_f32", _lib.ptr(grad_vox), _lib.ptr(calibs), _lib.ptr(grid_flat),
+            _lib.ptr(z_layers), _lib.ptr(corner_off), _lib.ptr(out), n, C, Hp - 2, Wp - 2, nl, n_cells, cell_begin,
+            cell_count, int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]),
+            1 if accumulate else 0, _lib.current_stream_handle())
+    return out
+
+
+def integral_image_backward(grad_integral):
+    """d integral (n, Hf+2, Wf+2, C) -> d feature (n, C, Hf, Wf).  Destroys ``grad_integral`` (scans it in place)."""
+    _lib.require_device(grad_integral)
+    grad_integral = _f32c(grad_integral)
+    n, Hp, Wp, C = grad_integral.shape
+    grad_feature = torch.empty((n, C, Hp - 2, Wp - 2), dtype=torch.float32, device=grad_integral.device)
+    _launch("vfa_integral_image_backward_f32", _lib.ptr(grad_integral), _lib.ptr(grad_feature), n, C, Hp - 2, Wp - 2,
+            _lib.current_stream_handle())
+    return grad_feature
+
+
 def bias_relu_accumulate(lin, bias, out=None, accumulate=False):
     """out (M,N) (+)= sum_v relu(lin[v] + bias) (reference vfa_op.py:124, vfanet.py:82)."""
     _lib.require_device(lin, bias, out)

@@ -52,10 +52,9 @@ class _IntegralImage(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_integral):
-        # d/df of a double cumsum = reverse double cumsum of the incoming gradient (interior only)
-        g = grad_integral[:, 1:-1, 1:-1, :]
-        g = g.flip(1).cumsum(1).flip(1).flip(2).cumsum(2).flip(2)
-        return g.permute(0, 3, 1, 2).contiguous()
+        # d/df of a double cumsum = reverse double cumsum of the incoming gradient (interior only); the kernel scans
+        # its input in place, so hand it a private copy unless autograd already gave us a temporary
+        return ops.integral_image_backward(grad_integral.clone())
 
 
 class _BoxPool(torch.autograd.Function):
@@ -67,12 +66,16 @@ class _BoxPool(torch.autograd.Function):
         vox = ops.project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h),
                                  (cmin, cmax), cell_begin, cell_count, _lib.VOX_LAYER_MAJOR)
         ctx.save_for_backward(calibs, grid_flat, z_layers, corner_off)
-        ctx.meta = (geom, integral.shape, cell_begin, cell_count)
+        ctx.meta = (geom, tuple(integral.shape), cell_begin, cell_count)
         return vox
 
     @staticmethod
     def backward(ctx, grad_vox):
-        raise NotImplementedError("vfa_amd: the backward HIP kernels of the box pooling are not built yet")
+        calibs, grid_flat, z_layers, corner_off = ctx.saved_tensors
+        (conv_kind, img_w, img_h, cmin, cmax), shape, cell_begin, cell_count = ctx.meta
+        grad_integral = ops.project_gather_backward(grad_vox, shape, calibs, grid_flat, z_layers, corner_off, conv_kind,
+                                                    (img_w, img_h), (cmin, cmax), cell_begin, cell_count)
+        return grad_integral, None, None, None, None, None, None, None
 
 
 class _BiasReluSum(torch.autograd.Function):
