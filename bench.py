@@ -142,12 +142,20 @@ def main():
     alg_bytes = 0
     for (nv, Ct, Hf, Wf, nlt, cells), rec in g["by_tag"].items():
         alg_bytes += rec["launches"] * (nv * Ct * Hf * Wf * 4 + nv * nlt * cells * Ct * 4 + cells * 12 + nv * 48)
+    # HBM traffic of that kernel from the PMC counters: collected by separate `rocprofv3 --pmc FETCH_SIZE` /
+    # `--pmc WRITE_SIZE` passes over this same command (tools/pmc_to_traffic.py, summary committed under profiles/)
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if a.workload == "multiviewc_200x200x1" and os.path.exists(tpath):
+        for name, rec in json.load(open(tpath))["kernels"].items():
+            if "gather_kernel<4, true>" in name:
+                traffic = rec["hbm_bytes_per_dispatch"]
     roofline = None
     if g["launches"]:
         avg_ms = g["ms"] / g["launches"]
         achieved = alg_bytes / g["launches"] / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "gather_kernel<4,true> (vfa_project_gather_f32)", "achieved": achieved,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes / g["launches"],
                     "launches": g["launches"]}
     kernels = {k: {"launches": v["launches"], "avg_us": 1e3 * v["ms"] / max(v["launches"], 1)} for k, v in ks.items()}

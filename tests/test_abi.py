@@ -86,3 +86,17 @@ def test_unknown_dataset_raises_like_the_reference():
     from vfa_amd.vfa_op import _conv_kind
     with pytest.raises(UnboundLocalError):
         _conv_kind(SimpleNamespace(data="KITTI", image_size=(1, 1)))
+
+
+def test_vfanet_state_dict_matches_reference_checkpoint_layout():
+    """Names, shapes and dtypes of every entry of the reference VFANet's state_dict (fixture generated from the
+    reference by tests/golden/make_state_keys.py), so that its checkpoints load key-for-key."""
+    import json
+    from types import SimpleNamespace
+    from conftest import golden_path
+    from vfa_amd.vfanet import VFANet
+    ref = json.load(open(golden_path("vfanet_state_keys.json")))
+    for key, (base, mode) in {"resnet18_3D": ("resnet18", "3D"), "resnet34_2D": ("resnet34", "2D")}.items():
+        m = VFANet(SimpleNamespace(data="MultiviewC", image_size=(720, 1280)), base=base, mode=mode)
+        mine = [[k, list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()]
+        assert mine == ref[key]

@@ -1,0 +1,77 @@
+"""Camera-sharded aggregation over ranks (the N>1 path), on CPU with gloo, world_size 2.
+
+The HIP kernels cannot run here, so each rank forms the partial BEV map of ITS cameras with the CPU oracle
+(test infrastructure) and the product's own sharding + all-reduce code (vfa_amd.aggregate) fuses them; the sum
+must match the reference's full VFANet fixture.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, golden_path
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import vfa_oracle as oracle
+        from vfa_amd.aggregate import all_reduce_ortho, camera_shard
+        d = np.load(golden_path(case))
+        n_cam = d["calibs"].shape[0]
+        mine = camera_shard(n_cam)  # rank / world from the process group
+        assert mine == list(range(rank, n_cam, world))
+        meta = dict(data=str(d["data"]), image_size=tuple(int(v) for v in d["image_size"]),
+                    cube_size=tuple(float(v) for v in d["cube_size"]), grid_height=float(d["grid_height"]))
+        C, (L, W) = d["ortho"].shape[0], d["grid"].shape[:2]
+        if mine:
+            part = oracle.vfanet_aggregate({s: d[f"lat{s}"][mine] for s in (8, 16, 32)}, d["calibs"][mine], d["grid"],
+                                           {s: d[f"weight{s}"] for s in (8, 16, 32)},
+                                           {s: d[f"bias{s}"] for s in (8, 16, 32)}, **meta)
+        else:
+            part = np.zeros((C, L, W), np.float32)
+        # the product keeps the map channels-last (L*W, C); reduce it in that layout
+        t = torch.from_numpy(np.ascontiguousarray(part.reshape(C, L * W).T))
+        t = all_reduce_ortho(t)
+        got = t.numpy().T.reshape(C, L, W)
+        ref = d["ortho"]
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["vfanet_mc.npz", "vfanet_wt.npz"])
+def test_camera_sharded_sum_matches_reference_world2(case, tmp_path, oracle):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_camera_shard_partitions_every_rig():
+    from vfa_amd.aggregate import camera_shard
+    for n_cam in (1, 6, 7, 8, 13):
+        for world in (1, 2, 4, 6, 8):
+            shards = [camera_shard(n_cam, r, world) for r in range(world)]
+            assert sorted(c for s in shards for c in s) == list(range(n_cam))
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    assert camera_shard(7, 7, 8) == []  # 7 cameras on 8 GPUs: the last rank contributes zeros
+
+
+def test_all_reduce_is_identity_without_a_process_group():
+    from vfa_amd.aggregate import all_reduce_ortho
+    t = torch.arange(6.).view(3, 2)
+    assert all_reduce_ortho(t) is t

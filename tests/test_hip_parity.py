@@ -334,3 +334,33 @@ def test_empty_and_degenerate_inputs():
     # zero views
     z = ops.integral_image(torch.zeros(0, 8, 4, 4, device=dev))
     assert z.shape == (0, 6, 6, 8)
+
+
+def test_vfanet_forward_interface():
+    """The caller of the path with the reference's interface: output dict, shapes, and its BEV map equals the
+    per-camera loop over its own laterals."""
+    import vfa_amd
+    from vfa_amd.vfanet import VFANet
+    from vfa_amd.synthetic import ring_cameras
+    dev = _dev()
+    args = SimpleNamespace(data="MultiviewC", image_size=(192, 320))
+    torch.manual_seed(0)
+    net = VFANet(args, grid_height=96, cube_size=(50, 50, 32), angle_range=36).to(dev).eval()
+    images = torch.rand(3, 3, 192, 320, device=dev)
+    calibs = ring_cameras(3, (600., 500., 0.), 1500., 500., 250., (320, 192)).to(dev)
+    grid = vfa_amd.make_grid((1000, 1200), cube_LW=(50, 50), dataset="MultiviewC").to(dev)[None]
+    with torch.no_grad():
+        out = net(images, calibs, grid)
+        ortho = net.ortho_features(images, calibs, grid)
+        lats = net.laterals(images)
+        acc = 0
+        for cam in range(3):
+            f = [getattr(net, f"vfa{s}")(lats[i][[cam]], calibs[cam], grid) for i, s in enumerate((8, 16, 32))]
+            acc = acc + (f[0] + f[1] + f[2])
+    L, W = grid.shape[1:3]
+    assert tuple(out["heatmap"].shape) == (1, 1, L, W)
+    assert tuple(out["loc_offset"].shape) == (1, L, W, 2)
+    assert tuple(out["dim_offset"].shape) == (1, L, W, 3)
+    assert tuple(out["rotation"].shape) == (1, L, W, 36)
+    assert ortho.abs().max() > 0
+    torch.testing.assert_close(ortho, acc, rtol=RTOL, atol=ATOL_REL * acc.abs().max().item())

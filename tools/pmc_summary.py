@@ -8,7 +8,7 @@ from collections import defaultdict
 root = sys.argv[1]
 filt = sys.argv[2] if len(sys.argv) > 2 else ""
 acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(f"{root}/pass*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         if filt and filt not in name:
