@@ -85,6 +85,15 @@ int vfa_project_gather_f32(const float *integral, const float *calibs, const flo
                            int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w, float img_h,
                            float cmin, float cmax, int vox_layout, void *stream);
 
+/* Two-kernel form of vfa_project_gather_f32: a records kernel writes one 128-byte record per box into `workspace`
+ * (vfa_gather_workspace_bytes() bytes, caller-owned scratch) and the pooling waves fetch them with scalar loads.
+ * Same results, bit for bit. */
+size_t vfa_gather_workspace_bytes(int n_views, int nl, int cell_count);
+int vfa_project_gather_ws_f32(const float *integral, const float *calibs, const float *grid, const float *z_layers,
+                              const float *corner_off, float *vox, void *workspace, size_t workspace_bytes, int n_views,
+                              int C, int Hf, int Wf, int nl, int n_cells, int cell_begin, int cell_count, int conv_kind,
+                              float img_w, float img_h, float cmin, float cmax, int vox_layout, void *stream);
+
 /* Backward of vfa_project_gather_f32 with respect to the integral images (training: the reference back-propagates
  * through the path with autograd, trainer.py:41; calib and grid carry no gradient).  grad_vox is layer-major
  * (n_views, cell_count, nl*C); grad_integral (n_views, Hf+2, Wf+2, C) is zeroed first unless `accumulate`.

@@ -56,6 +56,12 @@ def main():
             ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, out=vox)
         t_int = timed(lambda: ops.integral_image(lat), a.rounds)
         t_fused = timed(lambda: ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, out=vox), a.rounds)
+        ws = torch.empty(_lib.lib().vfa_gather_workspace_bytes(n, nl, cells), dtype=torch.uint8, device=dev)
+        vox2 = ops.project_gather_ws(integral, calibs, grid_flat, zl, co, kind, img_wh, workspace=ws)
+        same = torch.equal(vox2.view(torch.int32), vox.view(torch.int32))
+        t_ws = timed(lambda: ops.project_gather_ws(integral, calibs, grid_flat, zl, co, kind, img_wh, out=vox2,
+                                                   workspace=ws), a.rounds)
+        del vox2
         t_unf = timed(lambda: ops.gather(integral, box, area, vis), a.rounds)
         t_box = timed(lambda: ops.box_params(calibs, grid_flat, zl, co, kind, img_wh, (Hf, Wf)), a.rounds)
         nbox = n * cells * nl
@@ -63,7 +69,7 @@ def main():
         bytes_i = 2 * n * C * Hf * Wf * 4
         print(f" scale {Hf}x{Wf}: visible {visfrac:.2f} | integral {t_int[0]:.1f} us ({bytes_i / t_int[0] / 1e3:.0f} GB/s alg) | "
               f"project_gather med {t_fused[0]:.1f} min {t_fused[1]:.1f} us = {nbox / t_fused[0] / 1e3:.2f} Gbox/s, "
-              f"{bytes_g / t_fused[0] / 1e3:.0f} GB/s alg | gather(unfused) {t_unf[0]:.1f} us | box_params {t_box[0]:.1f} us")
+              f"{bytes_g / t_fused[0] / 1e3:.0f} GB/s alg | ws-form med {t_ws[0]:.1f} min {t_ws[1]:.1f} us bitwise_same={same} | gather(unfused) {t_unf[0]:.1f} us | box_params {t_box[0]:.1f} us")
 
 
 if __name__ == "__main__":

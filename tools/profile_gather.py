@@ -15,6 +15,7 @@ p = argparse.ArgumentParser()
 p.add_argument("--workload", default="multiviewc_200x200x1")
 p.add_argument("--scale", type=int, default=2)
 p.add_argument("--launches", type=int, default=5)
+p.add_argument("--ws", action="store_true")
 a = p.parse_args()
 dev = torch.device("cuda:0")
 wl = make_workload(a.workload, channels=256, seed=0)
@@ -26,7 +27,12 @@ calibs = wl["calibs"].reshape(n, 12).to(dev).contiguous()
 lat = torch.cat([wl["features"][c][a.scale] for c in range(n)]).to(dev)
 integral = ops.integral_image(lat)
 vox = torch.empty((n, grid_flat.shape[0], zl.numel() * 256), device=dev)
+ws = torch.empty(_lib.lib().vfa_gather_workspace_bytes(n, zl.numel(), grid_flat.shape[0]), dtype=torch.uint8, device=dev)
 for _ in range(a.launches):
+    if a.ws:
+        ops.project_gather_ws(integral, calibs, grid_flat, zl, co, _lib.CONV_KIND[wl["args"].data],
+                              wl["args"].image_size[::-1], out=vox, workspace=ws)
+        continue
     ops.project_gather(integral, calibs, grid_flat, zl, co, _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1],
                        out=vox)
 torch.cuda.synchronize()

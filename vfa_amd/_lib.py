@@ -25,6 +25,9 @@ SIGNATURES = {
                        _vp],
     "vfa_project_gather_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],
+    "vfa_gather_workspace_bytes": [_c_int, _c_int, _c_int],
+    "vfa_project_gather_ws_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                  _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],
     "vfa_project_gather_backward_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],
     "vfa_integral_image_backward_f32": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
@@ -51,7 +54,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_size_t if name.endswith("_bytes") else ctypes.c_int
         got = handle.vfa_abi_version()
         if got != ABI_VERSION:
             raise VFAHipError(f"libvfa_hip.so has ABI version {got}, the Python side expects {ABI_VERSION}; rebuild")

@@ -14,6 +14,8 @@
 // zero border, (n_views, Hf+2, Wf+2, C).  One bilinear tap of one box is then C contiguous floats (1 KiB at
 // C = 256 = one 16 B/lane wave64 load), and grid_sample's zeros padding is a plain load of the border.
 #include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdlib>
 
 #include "vfa_hip.h"
 
@@ -41,7 +43,10 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 // are served by the same L2.  Speed only; any placement is correct.
 __device__ __forceinline__ long long xcd_contiguous(long long block, long long per_xcd)
 {
-    return (block & 7) * per_xcd + (block >> 3);
+    if (per_xcd > 0) return (block & 7) * per_xcd + (block >> 3); // contiguous eighths
+    if (per_xcd == 0) return block;
+    const long long G = -per_xcd, i = block >> 3;                 // groups of G consecutive tiles, dealt round-robin
+    return ((i / G) * 8 + (block & 7)) * G + i % G;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -572,6 +577,158 @@ __global__ __launch_bounds__(256, 4) void gather_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two-kernel form of the projection + box pooling: box records through HBM, scalar-loaded by the pooling waves.
+// ------------------------------------------------------------------------------------------------
+// records kernel: one thread per box, 256 boxes per workgroup; writes the same BoxRec the tiled kernel stages in LDS
+// (runs are delimited per 32-box chunk = the unit of work of one pooling wave).
+template <bool FUSED>
+__global__ __launch_bounds__(256) void box_records_kernel(BoxRec *__restrict__ recs, const float4 *__restrict__ box,
+                                                          const float *__restrict__ area_in,
+                                                          const uint8_t *__restrict__ visible_in, BoxGeom g, GatherDims d)
+{
+    const long long tile0 = (long long)blockIdx.x * 256;
+    if (tile0 >= d.n_boxes) return;
+    const int nb = (int)min(256ll, d.n_boxes - tile0);
+    stage_box_records<FUSED>(recs + tile0, tile0, nb, threadIdx.x & (kWave - 1), box, area_in, visible_in, g, d);
+}
+
+// Scalar-memory prefetch of box records.  hipcc sinks a plain load to its first use, which would put the record fetch
+// of box k+1 behind the arithmetic of box k; the loads are therefore issued by hand (s_load into SGPRs) one step
+// ahead and waited for (lgkmcnt(0), scalar loads return out of order) right before the registers are consumed.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct ScalarWeights { f32x16 w; f32x4 t; };  // BoxRec::w: 16 tap weights | area, rcp, out_row, layer
+struct ScalarHeader { i32x8 a; i32x4 b; };    // BoxRec::h: flags, view, run_len, masked, col[4] | row[4]
+static_assert(offsetof(BoxRec, w) == 48 && sizeof(BoxHdr) == 48 && sizeof(BoxWeights) == 80, "record layout");
+
+__device__ __forceinline__ void sload_weights(ScalarWeights &o, const BoxRec *p)
+{
+    asm volatile("s_load_dwordx16 %0, %2, 0x30\n\ts_load_dwordx4 %1, %2, 0x70" : "=&s"(o.w), "=&s"(o.t) : "s"(p));
+}
+__device__ __forceinline__ void swait_weights(ScalarWeights &o)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(o.w), "+s"(o.t));
+}
+__device__ __forceinline__ void sload_header(ScalarHeader &o, const BoxRec *p)
+{
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(o.a), "=&s"(o.b) : "s"(p));
+}
+__device__ __forceinline__ void swait_header(ScalarHeader &o)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(o.a), "+s"(o.b));
+}
+__device__ __forceinline__ BoxWeights unpack(const ScalarWeights &s)
+{
+    BoxWeights w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        w.lt[q] = s.w[q]; w.rb[q] = s.w[4 + q]; w.rt[q] = s.w[8 + q]; w.lb[q] = s.w[12 + q];
+    }
+    w.area = s.t[0];
+    w.rcp = s.t[1];
+    w.out_row = __float_as_uint(s.t[2]);
+    w.layer = __float_as_int(s.t[3]);
+    return w;
+}
+
+// pooling kernel: one wave (= one workgroup) per chunk of kPerWave consecutive boxes.  Records are wave-uniform and
+// fetched with scalar loads: offsets, weights and control live in SGPRs, the SALU forms tap addresses, and the VALU is
+// left with the channel arithmetic.  No LDS, no barrier.
+template <int VEC>
+__global__ __launch_bounds__(kWave) void gather_records_kernel(const float *__restrict__ integral,
+                                                               const BoxRec *__restrict__ recs, GatherDims d,
+                                                               float *__restrict__ vox)
+{
+    using V = typename vec_of<VEC>::type;
+    const int lane = threadIdx.x;
+    const long long chunk = xcd_contiguous(blockIdx.x, d.per_xcd);
+    const long long j0 = chunk * kPerWave;
+    if (j0 >= d.n_boxes) return;
+    const long long j_end = min(d.n_boxes, j0 + kPerWave);
+    const size_t img_stride = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C * sizeof(float);
+    const bool layer_major = d.vox_layout == VFA_VOX_LAYER_MAJOR;
+    const unsigned c_bytes = (unsigned)d.C * 4u;
+    long long j = j0;
+    ScalarHeader sh;
+    sload_header(sh, recs + j);
+    swait_header(sh);
+    while (j < j_end) {
+        const int flags = sh.a[0];
+        const bool vis = (flags & 1) != 0;
+        const int run = vis ? sh.a[2] : 1;
+        const int view = sh.a[1];
+        const float masked = __int_as_float(sh.a[3]);
+        const unsigned col[4] = {(unsigned)sh.a[4], (unsigned)sh.a[5], (unsigned)sh.a[6], (unsigned)sh.a[7]};
+        const unsigned row[4] = {(unsigned)sh.b[0], (unsigned)sh.b[1], (unsigned)sh.b[2], (unsigned)sh.b[3]};
+        ScalarHeader sh_next;
+        sload_header(sh_next, recs + j + run); // the workspace holds one spare record past the last box
+        char *out0 = reinterpret_cast<char *>(vox) + (size_t)j * c_bytes; // layer-major address of box j
+        if (!vis) {
+            char *out = layer_major ? out0
+                                    : reinterpret_cast<char *>(vox + (size_t)recs[j].w.out_row * d.C * d.nl + recs[j].w.layer);
+#pragma unroll 1
+            for (int c = lane * VEC; c < d.C; c += kWave * VEC) {
+                if (layer_major) {
+                    if constexpr (VEC == 4) *reinterpret_cast<float4 *>(out + c * 4) = make_float4(masked, masked, masked, masked);
+                    else *reinterpret_cast<float *>(out + c * 4) = masked;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) reinterpret_cast<float *>(out)[(size_t)(c + k) * d.nl] = masked;
+                }
+            }
+        } else {
+            const char *img = reinterpret_cast<const char *>(integral) + (size_t)view * img_stride;
+#pragma unroll 1
+            for (int c = lane * VEC; c < d.C; c += kWave * VEC) {
+                const unsigned lane_off = (unsigned)c * 4u;
+#define VFA_VARIANT(DY, DX)                                                                                     \
+    {                                                                                                           \
+        ScalarWeights sw;                                                                                       \
+        sload_weights(sw, recs + j);                                                                            \
+        V P[4][4];                                                                                              \
+        load_patch<VEC, DY, DX>(P, img, lane_off, row, col);                                                    \
+        swait_weights(sw);                                                                                      \
+        for (int k = 0; k < run; ++k) {                                                                         \
+            ScalarWeights sw_next;                                                                              \
+            sload_weights(sw_next, recs + j + k + 1);                                                           \
+            const BoxWeights w = unpack(sw);                                                                    \
+            const V res = pool_patch<VEC, DY, DX>(P, w);                                                        \
+            if (layer_major) {                                                                                  \
+                *reinterpret_cast<V *>(out0 + (size_t)k * c_bytes + lane_off) = res;                            \
+            } else {                                                                                            \
+                float *o = vox + (size_t)w.out_row * d.C * d.nl + w.layer;                                      \
+                const float *rs = reinterpret_cast<const float *>(&res);                                        \
+                _Pragma("unroll") for (int q = 0; q < VEC; ++q) o[(size_t)(c + q) * d.nl] = rs[q];             \
+            }                                                                                                   \
+            swait_weights(sw_next);                                                                             \
+            sw = sw_next;                                                                                       \
+        }                                                                                                       \
+    }                                                                                                           \
+    break;
+                switch (flags >> 1) { // DXC | DYC << 2
+                case 0: VFA_VARIANT(0, 0)
+                case 1: VFA_VARIANT(0, 1)
+                case 2: VFA_VARIANT(0, 2)
+                case 4: VFA_VARIANT(1, 0)
+                case 5: VFA_VARIANT(1, 1)
+                case 6: VFA_VARIANT(1, 2)
+                case 8: VFA_VARIANT(2, 0)
+                case 9: VFA_VARIANT(2, 1)
+                default: VFA_VARIANT(2, 2)
+                }
+#undef VFA_VARIANT
+            }
+        }
+        j += run;
+        swait_header(sh_next);
+        sh = sh_next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward of the box pooling: d vox -> d integral (scatter-add), then d integral -> d feature (reverse scans).
 // The reference trains through this path with autograd (trainer.py:41); there is no reference code to mirror, only
 // the derivative of vfa_op.py:112-119.  Not bit-reproducible: float atomics sum in arrival order.
@@ -790,12 +947,47 @@ int launch_gather(const float *integral, const float *box, const float *area, co
     const long long blocks = (d.n_boxes + kTileBoxes - 1) / kTileBoxes;
     d.per_xcd = (blocks + 7) / 8;
     const dim3 grid((unsigned)(d.per_xcd * 8));
+    { static int noxcd = getenv("VFA_NO_XCD") ? atoi(getenv("VFA_NO_XCD")) : 0; if (noxcd) d.per_xcd = 0; }
+    static int xg = getenv("VFA_XCD_GROUP") ? atoi(getenv("VFA_XCD_GROUP")) : 0;
+    dim3 grid2 = grid;
+    if (xg > 0) { const long long per = ((d.per_xcd > 0 ? d.per_xcd : (blocks + 7) / 8) + xg - 1) / xg * xg; grid2 = dim3((unsigned)(per * 8)); d.per_xcd = -xg; }
     if (C % 4 == 0)
-        hipLaunchKernelGGL((gather_kernel<4, FUSED>), grid, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
+        hipLaunchKernelGGL((gather_kernel<4, FUSED>), grid2, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
                            g, d, vox);
     else
-        hipLaunchKernelGGL((gather_kernel<1, FUSED>), grid, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
+        hipLaunchKernelGGL((gather_kernel<1, FUSED>), grid2, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
                            g, d, vox);
+    return launch_status();
+}
+
+template <bool FUSED>
+int launch_gather_ws(const float *integral, const float *box, const float *area, const uint8_t *visible, const BoxGeom &g,
+                     float *vox, void *workspace, size_t workspace_bytes, int n_views, int C, int Hf, int Wf, int nl,
+                     int n_cells, int cell_begin, int cell_count, int vox_layout, hipStream_t s)
+{
+    if (n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0 || nl <= 0 || n_cells < 0 || cell_begin < 0 || cell_count < 0 ||
+        cell_begin + cell_count > n_cells || (vox_layout != VFA_VOX_REFERENCE && vox_layout != VFA_VOX_LAYER_MAJOR))
+        return VFA_ERR_BAD_ARGUMENT;
+    GatherDims d;
+    d.C = C; d.Hf = Hf; d.Wf = Wf; d.nl = nl; d.n_cells = n_cells; d.cell_begin = cell_begin;
+    d.cell_count = cell_count; d.vox_layout = vox_layout;
+    d.n_boxes = (long long)n_views * cell_count * nl;
+    if (d.n_boxes == 0) return 0;
+    if (!workspace || workspace_bytes < ((size_t)d.n_boxes + 1) * sizeof(BoxRec)) return VFA_ERR_BAD_ARGUMENT;
+    BoxRec *recs = reinterpret_cast<BoxRec *>(workspace);
+    d.per_xcd = 0;
+    hipLaunchKernelGGL((box_records_kernel<FUSED>), dim3((unsigned)((d.n_boxes + 255) / 256)), dim3(256), 0, s, recs,
+                       (const float4 *)box, area, visible, g, d);
+    int st = launch_status();
+    if (st) return st;
+    const long long chunks = (d.n_boxes + kPerWave - 1) / kPerWave;
+    d.per_xcd = (chunks + 7) / 8;
+    const dim3 grid((unsigned)(d.per_xcd * 8));
+    { static int noxcd = getenv("VFA_NO_XCD") ? atoi(getenv("VFA_NO_XCD")) : 0; if (noxcd) d.per_xcd = 0; }
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((gather_records_kernel<4>), grid, dim3(kWave), 0, s, integral, recs, d, vox);
+    else
+        hipLaunchKernelGGL((gather_records_kernel<1>), grid, dim3(kWave), 0, s, integral, recs, d, vox);
     return launch_status();
 }
 
@@ -858,6 +1050,22 @@ int vfa_project_gather_f32(const float *integral, const float *calibs, const flo
     BoxGeom g{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
     return launch_gather<true>(integral, nullptr, nullptr, nullptr, g, vox, n_views, C, Hf, Wf, nl, n_cells, cell_begin,
                                cell_count, vox_layout, (hipStream_t)stream);
+}
+
+size_t vfa_gather_workspace_bytes(int n_views, int nl, int cell_count)
+{
+    return ((size_t)n_views * (size_t)nl * (size_t)cell_count + 1) * sizeof(BoxRec); // + 1: prefetch past the end
+}
+
+int vfa_project_gather_ws_f32(const float *integral, const float *calibs, const float *grid, const float *z_layers,
+                              const float *corner_off, float *vox, void *workspace, size_t workspace_bytes, int n_views,
+                              int C, int Hf, int Wf, int nl, int n_cells, int cell_begin, int cell_count, int conv_kind,
+                              float img_w, float img_h, float cmin, float cmax, int vox_layout, void *stream)
+{
+    if (conv_kind < 0 || conv_kind > 2) return VFA_ERR_BAD_ARGUMENT;
+    BoxGeom g{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
+    return launch_gather_ws<true>(integral, nullptr, nullptr, nullptr, g, vox, workspace, workspace_bytes, n_views, C, Hf,
+                                  Wf, nl, n_cells, cell_begin, cell_count, vox_layout, (hipStream_t)stream);
 }
 
 int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, const float *grid, const float *z_layers,

@@ -111,6 +111,25 @@ def project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind,
     return vox
 
 
+def project_gather_ws(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, crange=(-1, 0.95),
+                      cell_begin=0, cell_count=None, layout=_lib.VOX_LAYER_MAJOR, out=None, workspace=None):
+    """Two-kernel form of ``project_gather`` (records through HBM, scalar-loaded by the pooling waves)."""
+    _lib.require_device(integral, calibs, grid_flat, z_layers, corner_off)
+    n, Hp, Wp, C = integral.shape
+    n_cells, nl = grid_flat.shape[0], z_layers.numel()
+    cell_count = n_cells - cell_begin if cell_count is None else cell_count
+    vox = out if out is not None else torch.empty((n, cell_count, nl * C), dtype=torch.float32,
+                                                  device=integral.device)
+    need = _lib.lib().vfa_gather_workspace_bytes(n, nl, cell_count)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=integral.device)
+    _launch("vfa_project_gather_ws_f32", _lib.ptr(integral), _lib.ptr(calibs), _lib.ptr(grid_flat), _lib.ptr(z_layers),
+            _lib.ptr(corner_off), _lib.ptr(vox), _lib.ptr(workspace), workspace.numel(), n, C, Hp - 2, Wp - 2, nl, n_cells,
+            cell_begin, cell_count, int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]),
+            float(crange[1]), layout, _lib.current_stream_handle(), tag=(n, C, Hp - 2, Wp - 2, nl, cell_count))
+    return vox
+
+
 def project_gather_backward(grad_vox, integral_shape, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh,
                             crange=(-1, 0.95), cell_begin=0, cell_count=None, out=None, accumulate=False):
     """d vox (n, cell_count, nl*C) layer-major -> d integral (n, Hf+2, Wf+2, C) by scatter-add (float atomics)."""
