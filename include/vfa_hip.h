@@ -50,6 +50,7 @@ extern "C" {
 #define VFA_VOX_LAYER_MAJOR 1 /* vox[cell, layer*C + c]    (coalesced; collapse.weight columns permuted by the host) */
 
 #define VFA_ERR_BAD_ARGUMENT 10001
+#define VFA_ERR_UNSUPPORTED 10002 /* shape outside what a specialised kernel was built for; use the general entry points */
 
 /* ABI version of the loaded library (VFA_ABI_VERSION at build time). */
 int vfa_abi_version(void);
@@ -84,6 +85,17 @@ int vfa_project_gather_f32(const float *integral, const float *calibs, const flo
                            const float *corner_off, float *vox, int n_views, int C, int Hf, int Wf, int nl,
                            int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w, float img_h,
                            float cmin, float cmax, int vox_layout, void *stream);
+
+/* Fused projection + box pooling + collapse product (fp32 MFMA) for C = c_out = 256:
+ *   lin[view, cell, :] = sum_layer vox[view, cell, layer, :] . W_layer^T          (no bias, no ReLU)
+ * without materialising vox.  weight_t is collapse.weight re-laid as (nl*C, c_out): row layer*C + c, i.e. the
+ * transpose of the layer-major weight.  Voxel features are formed exactly as in vfa_project_gather_f32; the
+ * product is a k-ordered fp32 fmaf chain (within the collapse tolerance, not bitwise -- no GEMM order is).
+ * Returns VFA_ERR_UNSUPPORTED for other channel counts.               replaces vfa_op.py:64-123 */
+int vfa_project_collapse_f32(const float *integral, const float *calibs, const float *grid, const float *z_layers,
+                             const float *corner_off, const float *weight_t, float *lin, int n_views, int C, int Hf, int Wf,
+                             int nl, int n_cells, int c_out, int conv_kind, float img_w, float img_h, float cmin, float cmax,
+                             void *stream);
 
 /* Two-kernel form of vfa_project_gather_f32: a records kernel writes one 128-byte record per box into `workspace`
  * (vfa_gather_workspace_bytes() bytes, caller-owned scratch) and the pooling waves fetch them with scalar loads.

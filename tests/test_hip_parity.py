@@ -364,3 +364,33 @@ def test_vfanet_forward_interface():
     assert tuple(out["rotation"].shape) == (1, L, W, 36)
     assert ortho.abs().max() > 0
     torch.testing.assert_close(ortho, acc, rtol=RTOL, atol=ATOL_REL * acc.abs().max().item())
+
+
+@pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 2, (70, 93)), ("multiviewc_156x156x5", 2, (40, 50)),
+                                             ("wildtrack_120x360x8", 2, (30, 45)), ("multiviewx_160x250x8", 1, (64, 64))])
+def test_fused_collapse_matches_unfused(name, n_cam, crop):
+    """Fused pooling + MFMA collapse (inference path) vs gather kernel + library GEMM, all three scales; grid sizes that
+    are not multiples of the 64-cell tile."""
+    import vfa_amd
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload(name, channels=256, seed=2, n_cam=n_cam)
+    grid_flat = wl["grid"][0, :crop[0], :crop[1]].reshape(-1, 3).contiguous().to(dev)
+    calibs = wl["calibs"].reshape(n_cam, 12).to(dev)
+    torch.manual_seed(3)
+    mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+    zl, co = mod._kernel_geometry(dev)
+    nl = zl.numel()
+    kind, img_wh = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
+    w_lm = mod.layer_major_weight().detach()
+    for s in range(3):
+        lat = torch.cat([wl["features"][c][s] for c in range(n_cam)]).to(dev)
+        integral = ops.integral_image(lat)
+        vox = ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh)
+        want = torch.matmul(vox.double(), w_lm.double().t())           # fp64 product of the (bitwise-checked) vox
+        got = ops.project_collapse(integral, calibs, grid_flat, zl, co, w_lm.t().contiguous(), kind, img_wh)
+        assert got.shape == want.shape
+        scale = want.abs().max().item()
+        assert scale > 0
+        torch.testing.assert_close(got.double(), want, rtol=RTOL, atol=ATOL_REL * scale)

@@ -62,6 +62,12 @@ def main():
         t_ws = timed(lambda: ops.project_gather_ws(integral, calibs, grid_flat, zl, co, kind, img_wh, out=vox2,
                                                    workspace=ws), a.rounds)
         del vox2
+        w_lm = mod.layer_major_weight().detach()
+        w_t = w_lm.t().contiguous()
+        lin = ops.project_collapse(integral, calibs, grid_flat, zl, co, w_t, kind, img_wh)
+        t_fc = timed(lambda: ops.project_collapse(integral, calibs, grid_flat, zl, co, w_t, kind, img_wh, out=lin), a.rounds)
+        t_mm = timed(lambda: torch.matmul(vox.view(-1, nl * C), w_lm.t()), a.rounds)
+        gflop = 2.0 * n * cells * nl * C * C / 1e9
         t_unf = timed(lambda: ops.gather(integral, box, area, vis), a.rounds)
         t_box = timed(lambda: ops.box_params(calibs, grid_flat, zl, co, kind, img_wh, (Hf, Wf)), a.rounds)
         nbox = n * cells * nl
@@ -69,7 +75,7 @@ def main():
         bytes_i = 2 * n * C * Hf * Wf * 4
         print(f" scale {Hf}x{Wf}: visible {visfrac:.2f} | integral {t_int[0]:.1f} us ({bytes_i / t_int[0] / 1e3:.0f} GB/s alg) | "
               f"project_gather med {t_fused[0]:.1f} min {t_fused[1]:.1f} us = {nbox / t_fused[0] / 1e3:.2f} Gbox/s, "
-              f"{bytes_g / t_fused[0] / 1e3:.0f} GB/s alg | ws-form med {t_ws[0]:.1f} min {t_ws[1]:.1f} us bitwise_same={same} | gather(unfused) {t_unf[0]:.1f} us | box_params {t_box[0]:.1f} us")
+              f"{bytes_g / t_fused[0] / 1e3:.0f} GB/s alg | ws-form med {t_ws[0]:.1f} min {t_ws[1]:.1f} us bitwise_same={same} | FUSED collapse med {t_fc[0]:.1f} us ({gflop / t_fc[0] * 1e3:.1f} TF) vs gather+GEMM {t_fused[0] + t_mm[0]:.1f} us (GEMM {t_mm[0]:.1f} us, {gflop / t_mm[0] * 1e3:.1f} TF) | gather(unfused) {t_unf[0]:.1f} us | box_params {t_box[0]:.1f} us")
 
 
 if __name__ == "__main__":

@@ -25,6 +25,8 @@ SIGNATURES = {
                        _vp],
     "vfa_project_gather_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],
+    "vfa_project_collapse_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                 _c_int, _c_float, _c_float, _c_float, _c_float, _vp],
     "vfa_gather_workspace_bytes": [_c_int, _c_int, _c_int],
     "vfa_project_gather_ws_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],

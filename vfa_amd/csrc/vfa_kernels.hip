@@ -15,7 +15,6 @@
 // C = 256 = one 16 B/lane wave64 load), and grid_sample's zeros padding is a plain load of the border.
 #include <hip/hip_runtime.h>
 #include <cstddef>
-#include <cstdlib>
 
 #include "vfa_hip.h"
 
@@ -43,10 +42,7 @@ __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfi
 // are served by the same L2.  Speed only; any placement is correct.
 __device__ __forceinline__ long long xcd_contiguous(long long block, long long per_xcd)
 {
-    if (per_xcd > 0) return (block & 7) * per_xcd + (block >> 3); // contiguous eighths
-    if (per_xcd == 0) return block;
-    const long long G = -per_xcd, i = block >> 3;                 // groups of G consecutive tiles, dealt round-robin
-    return ((i / G) * 8 + (block & 7)) * G + i % G;
+    return (block & 7) * per_xcd + (block >> 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -729,6 +725,237 @@ __global__ __launch_bounds__(kWave) void gather_records_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused projection + box pooling + collapse (fp32 MFMA):  lin[view, cell, :] = sum_layer vox[view, cell, layer, :] . W_layer^T
+//                                               replaces vfa_op.py:64-123 without the vox round trip through HBM.
+// One persistent workgroup of 12 waves per CU.  A tile is 64 cells of one view; a sub-tile is one z-layer of it: a
+// 64 x 256 block of voxel features, i.e. the A operand of a 64 x 256 x 256 product with W_layer^T.
+//   waves 4-11 (producers, VALU): project + pool 8 boxes each -- the same arithmetic as gather_kernel, bit for bit --
+//                                 and write the rows into the LDS A buffer of the NEXT sub-tile;
+//   waves 0-3 (consumers, MFMA):  v_mfma_f32_32x32x2_f32 over the CURRENT A buffer; wave (rh, ch) owns rows 32 rh.. and
+//                                 columns 128 ch.. as four 32x32 blocks (column 4j+q of the block belongs to MFMA block
+//                                 q, so one float4 load of W feeds four MFMAs and one float4 store covers a row piece).
+// The matrix pipe and the VALU are separate, so the two wave groups of a SIMD overlap; one barrier per sub-tile swaps
+// the double-buffered A tile.  MFMA fp32 is a k-ordered fmaf chain, so results are within the collapse tolerance of
+// the reference GEMM (not bitwise; no GEMM order is).
+// ------------------------------------------------------------------------------------------------
+constexpr int kFusedRows = 64;            // cells per tile
+constexpr int kFusedK = 256;              // channels per layer == K of one sub-tile (C must equal this)
+constexpr int kFusedN = 256;              // output channels
+constexpr int kProducers = 8;             // producer waves per workgroup (waves 4..4+kProducers-1)
+constexpr int kRowsPerProducer = kFusedRows / kProducers;
+
+struct FusedDims {
+    int Hf, Wf, nl, n_cells, n_views;
+    int tiles_per_view; // ceil(n_cells / 64)
+    int n_tiles;        // n_views * tiles_per_view
+};
+
+typedef float mfma_acc_t __attribute__((ext_vector_type(16)));
+
+// position of element (row, k) inside a 64 x 256 A buffer: XOR swizzle so that the 32 rows read by one MFMA operand
+// fetch (fixed k, rows r..r+31) fall into 32 different banks
+__device__ __forceinline__ int a_index(int row, int k) { return row * kFusedK + (k ^ (row & 31)); }
+
+__global__ __launch_bounds__(64 * (4 + kProducers)) void fused_collapse_kernel(const float *__restrict__ integral, BoxGeom g, FusedDims fd,
+                                                                const float *__restrict__ w_t, // (nl*256, 256): [l*256+k][n]
+                                                                float *__restrict__ lin)      // (n_views, n_cells, 256)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *a_buf = reinterpret_cast<float *>(smem);                                         // 2 x 64 x 256 floats
+    BoxRec *recs = reinterpret_cast<BoxRec *>(smem + 2 * kFusedRows * kFusedK * sizeof(float)); // 2 x 64 records
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = uniform_i(threadIdx.x >> 6);
+    const bool producer = wave >= 4;
+
+    // contiguous range of tiles for this workgroup (neighbouring workgroups of an XCD get neighbouring ranges)
+    const int nblk = gridDim.x;
+    const int lb = (int)xcd_contiguous(blockIdx.x, (nblk + 7) / 8);
+    if (lb >= nblk) return; // (grid is a multiple of 8 by construction)
+    const int t_begin = (int)((long long)fd.n_tiles * lb / nblk), t_end = (int)((long long)fd.n_tiles * (lb + 1) / nblk);
+    const int total_sub = (t_end - t_begin) * fd.nl;
+    if (total_sub == 0) return;
+
+    GatherDims d;
+    d.C = kFusedK; d.Hf = fd.Hf; d.Wf = fd.Wf; d.nl = fd.nl; d.n_cells = fd.n_cells; d.cell_begin = 0;
+    d.cell_count = fd.n_cells; d.vox_layout = VFA_VOX_LAYER_MAJOR; d.n_boxes = 0; d.per_xcd = 0;
+    const size_t img_stride = (size_t)(fd.Hf + 2) * (fd.Wf + 2) * kFusedK * sizeof(float);
+
+    // ---- producer: sub-tile `sub` -> a_buf[sub & 1]
+    auto produce = [&](int sub) {
+        const int tile = t_begin + sub / fd.nl, layer = sub % fd.nl;
+        const int view = tile / fd.tiles_per_view, cell0 = (tile % fd.tiles_per_view) * kFusedRows;
+        const int pw = wave - 4;
+        float *A = a_buf + (size_t)(sub & 1) * kFusedRows * kFusedK;
+        BoxRec *rr = recs + (sub & 1) * kFusedRows + pw * kRowsPerProducer;
+        // records of this wave's 16 rows (lanes 0..15)
+        {
+            const int cell = cell0 + pw * kRowsPerProducer + lane;
+            const bool valid = lane < kRowsPerProducer && cell < fd.n_cells;
+            float l = 0.f, t = 0.f, r = 0.f, b = 0.f, area = 0.f;
+            bool vis = false;
+            if (valid) {
+                const float *P = g.calibs + (size_t)view * 12;
+                const float gx = g.grid[cell * 3 + 0] + 0.0f;
+                const float gy = g.grid[cell * 3 + 1] + 0.0f;
+                const float gz = g.grid[cell * 3 + 2] + g.z_layers[layer];
+#pragma unroll 1
+                for (int k = 0; k < 8; ++k) {
+                    float nu, nv;
+                    project_corner(g, P, gx, gy, gz, k, nu, nv);
+                    if (k == 0) { l = r = nu; t = b = nv; }
+                    else { l = min_t(l, nu); r = max_t(r, nu); t = min_t(t, nv); b = max_t(b, nv); }
+                }
+                area = box_area(l, t, r, b, fd.Hf, fd.Wf);
+                vis = box_visible(area, fd.Hf, fd.Wf);
+            }
+            unsigned key_x = 0, key_y = 0;
+            int tag = -1 - lane;
+            if (lane < kRowsPerProducer) {
+                BoxRec &rc = rr[lane];
+                fill_record(rc, view, l, t, r, b, area, vis, d, key_x, key_y);
+                if (!valid) { rc.h.flags = 0; rc.h.masked = 0.0f; }
+                tag = valid ? rc.h.flags : (-1 - lane);
+            }
+            const bool cont = vis && lane != 0 && lane < kRowsPerProducer && __shfl_up(tag, 1) == tag &&
+                              __shfl_up(key_x, 1) == key_x && __shfl_up(key_y, 1) == key_y;
+            const unsigned long long mask = __ballot(cont);
+            const unsigned long long after = lane == 63 ? 0ull : (mask >> (lane + 1));
+            const int follow = after == ~0ull ? 64 : __builtin_ctzll(~after);
+            if (lane < kRowsPerProducer) rr[lane].h.run_len = 1 + min(follow, kRowsPerProducer - 1 - lane);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS record writes are visible to its own reads
+        __builtin_amdgcn_wave_barrier();
+        const char *img = reinterpret_cast<const char *>(integral) + (size_t)view * img_stride;
+        const unsigned lane_off = (unsigned)lane * 16u;
+        int j = 0;
+        while (j < kRowsPerProducer) {
+            const BoxHdr &h = rr[j].h;
+            const int flags = uniform_i(h.flags);
+            const int row0 = pw * kRowsPerProducer + j;
+            if (!(flags & 1)) {
+                const float z = h.masked;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) A[a_index(row0, lane * 4 + q)] = z;
+                ++j;
+                continue;
+            }
+            const int run = uniform_i(h.run_len);
+            unsigned col[4], row[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { col[k] = h.col[k]; row[k] = h.row[k]; }
+#define VFA_VARIANT(DY, DX)                                                                     \
+    {                                                                                           \
+        float4 P[4][4];                                                                         \
+        load_patch<4, DY, DX>(P, img, lane_off, row, col);                                      \
+        for (int k = 0; k < run; ++k) {                                                         \
+            const BoxWeights w = rr[j + k].w;                                                   \
+            const float4 res = pool_patch<4, DY, DX>(P, w);                                     \
+            const int rw = row0 + k;                                                            \
+            A[a_index(rw, lane * 4 + 0)] = res.x;                                               \
+            A[a_index(rw, lane * 4 + 1)] = res.y;                                               \
+            A[a_index(rw, lane * 4 + 2)] = res.z;                                               \
+            A[a_index(rw, lane * 4 + 3)] = res.w;                                               \
+        }                                                                                       \
+    }                                                                                           \
+    break;
+            switch (flags >> 1) {
+            case 0: VFA_VARIANT(0, 0)
+            case 1: VFA_VARIANT(0, 1)
+            case 2: VFA_VARIANT(0, 2)
+            case 4: VFA_VARIANT(1, 0)
+            case 5: VFA_VARIANT(1, 1)
+            case 6: VFA_VARIANT(1, 2)
+            case 8: VFA_VARIANT(2, 0)
+            case 9: VFA_VARIANT(2, 1)
+            default: VFA_VARIANT(2, 2)
+            }
+#undef VFA_VARIANT
+            j += run;
+        }
+    };
+
+    // ---- consumer state: wave (rh, ch) owns rows 32 rh + (0..31), columns 128 ch + 4 j + q
+    const int rh = wave >> 1, ch = wave & 1;
+    mfma_acc_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
+
+    auto consume = [&](int sub) {
+        const int layer = sub % fd.nl;
+        const float *A = a_buf + (size_t)(sub & 1) * kFusedRows * kFusedK;
+        const int arow = 32 * rh + (lane & 31), khalf = lane >> 5;
+        // W_layer^T rows k, columns n: lane reads W[k = 2 s + khalf][128 ch + 4 (lane & 31) .. + 3]
+        const float4 *wp = reinterpret_cast<const float4 *>(w_t + ((size_t)layer * kFusedK + khalf) * kFusedN + 128 * ch) +
+                           (lane & 31);
+        // Software pipeline without register copies: two operand sets (R0, R1) of U k-steps each; the loads of one set
+        // are issued before the U x 4 MFMAs (U x 256 cycles) of the other.
+        constexpr int U = 8;
+        constexpr int G = kFusedK / 2 / U; // groups per sub-tile (16)
+        float4 b0[U], b1[U];
+        float a0[U], a1[U];
+        auto load_group = [&](int grp, float4 (&bb)[U], float (&aa)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                bb[u] = wp[(size_t)(2 * (grp * U + u)) * (kFusedN / 4)];
+                aa[u] = A[a_index(arow, 2 * (grp * U + u) + khalf)];
+            }
+        };
+        auto mfma_group = [&](const float4 (&bb)[U], const float (&aa)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u].y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u].z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u].w, acc[3], 0, 0, 0);
+            }
+        };
+        load_group(0, b0, a0);
+#pragma unroll 1
+        for (int grp = 0; grp < G; grp += 2) {
+            load_group(grp + 1, b1, a1);
+            mfma_group(b0, a0);
+            if (grp + 2 < G) load_group(grp + 2, b0, a0);
+            mfma_group(b1, a1);
+        }
+        if (layer == fd.nl - 1) { // tile finished: write the 32 x 128 piece, reset the accumulators
+            const int tile = t_begin + sub / fd.nl;
+            const int view = tile / fd.tiles_per_view, cell0 = (tile % fd.tiles_per_view) * kFusedRows;
+            float *out = lin + ((size_t)view * fd.n_cells + cell0) * kFusedN + 128 * ch + 4 * (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rloc = 32 * rh + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (cell0 + rloc < fd.n_cells)
+                    *reinterpret_cast<float4 *>(out + (size_t)rloc * kFusedN) =
+                        make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
+        }
+    };
+
+    // The two roles run separate loops (same number of barriers) so that neither carries the other's registers.
+    if (producer) {
+        __builtin_amdgcn_s_setprio(1); // VALU-heavy role first: an MFMA wave needs one issue slot per 64 cycles (+3 %)
+        produce(0);
+        __syncthreads();
+        for (int i = 0; i < total_sub; ++i) {
+            if (i + 1 < total_sub) produce(i + 1);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (int i = 0; i < total_sub; ++i) {
+            consume(i);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward of the box pooling: d vox -> d integral (scatter-add), then d integral -> d feature (reverse scans).
 // The reference trains through this path with autograd (trainer.py:41); there is no reference code to mirror, only
 // the derivative of vfa_op.py:112-119.  Not bit-reproducible: float atomics sum in arrival order.
@@ -947,15 +1174,11 @@ int launch_gather(const float *integral, const float *box, const float *area, co
     const long long blocks = (d.n_boxes + kTileBoxes - 1) / kTileBoxes;
     d.per_xcd = (blocks + 7) / 8;
     const dim3 grid((unsigned)(d.per_xcd * 8));
-    { static int noxcd = getenv("VFA_NO_XCD") ? atoi(getenv("VFA_NO_XCD")) : 0; if (noxcd) d.per_xcd = 0; }
-    static int xg = getenv("VFA_XCD_GROUP") ? atoi(getenv("VFA_XCD_GROUP")) : 0;
-    dim3 grid2 = grid;
-    if (xg > 0) { const long long per = ((d.per_xcd > 0 ? d.per_xcd : (blocks + 7) / 8) + xg - 1) / xg * xg; grid2 = dim3((unsigned)(per * 8)); d.per_xcd = -xg; }
     if (C % 4 == 0)
-        hipLaunchKernelGGL((gather_kernel<4, FUSED>), grid2, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
+        hipLaunchKernelGGL((gather_kernel<4, FUSED>), grid, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
                            g, d, vox);
     else
-        hipLaunchKernelGGL((gather_kernel<1, FUSED>), grid2, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
+        hipLaunchKernelGGL((gather_kernel<1, FUSED>), grid, dim3(256), 0, s, integral, (const float4 *)box, area, visible,
                            g, d, vox);
     return launch_status();
 }
@@ -983,7 +1206,6 @@ int launch_gather_ws(const float *integral, const float *box, const float *area,
     const long long chunks = (d.n_boxes + kPerWave - 1) / kPerWave;
     d.per_xcd = (chunks + 7) / 8;
     const dim3 grid((unsigned)(d.per_xcd * 8));
-    { static int noxcd = getenv("VFA_NO_XCD") ? atoi(getenv("VFA_NO_XCD")) : 0; if (noxcd) d.per_xcd = 0; }
     if (C % 4 == 0)
         hipLaunchKernelGGL((gather_records_kernel<4>), grid, dim3(kWave), 0, s, integral, recs, d, vox);
     else
@@ -1066,6 +1288,41 @@ int vfa_project_gather_ws_f32(const float *integral, const float *calibs, const 
     BoxGeom g{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
     return launch_gather_ws<true>(integral, nullptr, nullptr, nullptr, g, vox, workspace, workspace_bytes, n_views, C, Hf,
                                   Wf, nl, n_cells, cell_begin, cell_count, vox_layout, (hipStream_t)stream);
+}
+
+int vfa_project_collapse_f32(const float *integral, const float *calibs, const float *grid, const float *z_layers,
+                             const float *corner_off, const float *weight_t, float *lin, int n_views, int C, int Hf, int Wf,
+                             int nl, int n_cells, int c_out, int conv_kind, float img_w, float img_h, float cmin, float cmax,
+                             void *stream)
+{
+    if (n_views < 0 || Hf <= 0 || Wf <= 0 || nl <= 0 || n_cells < 0 || conv_kind < 0 || conv_kind > 2)
+        return VFA_ERR_BAD_ARGUMENT;
+    if (C != kFusedK || c_out != kFusedN) return VFA_ERR_UNSUPPORTED; // the fused tile is built for 256 -> 256 channels
+    if (n_views == 0 || n_cells == 0) return 0;
+    BoxGeom g{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
+    FusedDims fd;
+    fd.Hf = Hf; fd.Wf = Wf; fd.nl = nl; fd.n_cells = n_cells; fd.n_views = n_views;
+    fd.tiles_per_view = (n_cells + kFusedRows - 1) / kFusedRows;
+    fd.n_tiles = n_views * fd.tiles_per_view;
+    const size_t lds = 2 * kFusedRows * kFusedK * sizeof(float) + 2 * kFusedRows * sizeof(BoxRec);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void *)fused_collapse_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+    }
+    int nblk = n_cu < fd.n_tiles ? n_cu : fd.n_tiles;
+    nblk = (nblk + 7) / 8 * 8;
+    hipLaunchKernelGGL(fused_collapse_kernel, dim3(nblk), dim3(64 * (4 + kProducers)), lds, (hipStream_t)stream, integral, g, fd, weight_t, lin);
+    return launch_status();
 }
 
 int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, const float *grid, const float *z_layers,

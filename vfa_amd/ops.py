@@ -111,6 +111,23 @@ def project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind,
     return vox
 
 
+def project_collapse(integral, calibs, grid_flat, z_layers, corner_off, weight_t, conv_kind, image_wh,
+                     crange=(-1, 0.95), out=None):
+    """Fused projection + box pooling + collapse product -> lin (n, cells, 256), no bias / ReLU (reference
+    vfa_op.py:64-123).  ``weight_t`` (nl*C, C_out) = transpose of the layer-major collapse weight.  C = C_out = 256 only."""
+    _lib.require_device(integral, calibs, grid_flat, z_layers, corner_off, weight_t)
+    n, Hp, Wp, C = integral.shape
+    n_cells, nl = grid_flat.shape[0], z_layers.numel()
+    c_out = weight_t.shape[1]
+    assert weight_t.shape[0] == nl * C and weight_t.is_contiguous()
+    lin = out if out is not None else torch.empty((n, n_cells, c_out), dtype=torch.float32, device=integral.device)
+    _launch("vfa_project_collapse_f32", _lib.ptr(integral), _lib.ptr(calibs), _lib.ptr(grid_flat), _lib.ptr(z_layers),
+            _lib.ptr(corner_off), _lib.ptr(weight_t), _lib.ptr(lin), n, C, Hp - 2, Wp - 2, nl, n_cells, c_out,
+            int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]),
+            _lib.current_stream_handle(), tag=(n, C, Hp - 2, Wp - 2, nl, n_cells))
+    return lin
+
+
 def project_gather_ws(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, crange=(-1, 0.95),
                       cell_begin=0, cell_count=None, layout=_lib.VOX_LAYER_MAJOR, out=None, workspace=None):
     """Two-kernel form of ``project_gather`` (records through HBM, scalar-loaded by the pooling waves)."""

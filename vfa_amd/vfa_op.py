@@ -31,6 +31,10 @@ MAXIMUM_AREA_RATIO = 0.3
 
 # bound on the transient voxel-feature buffer (n_views, cells, nl*C) fp32; larger grids are chunked over cells
 VOX_BYTES_LIMIT = int(os.environ.get("VFA_AMD_VOX_BYTES", str(8 << 30)))
+# fused pooling + fp32-MFMA collapse kernel (256 -> 256 channels, no gradient needed): never materialises vox, so it is
+# the memory-lean path for very large grids.  On MI355X it runs at the speed of pooling kernel + library GEMM (fp32 MFMA
+# is clock/power-bound either way), so it is opt-in: VFA_AMD_FUSED=1.
+USE_FUSED = os.environ.get("VFA_AMD_FUSED", "0") == "1"
 
 
 def _conv_kind(args):
@@ -159,6 +163,12 @@ class VFA(nn.Module):
         if n_cells == 0 or n == 0:
             return features.new_zeros((n, n_cells, self.collapse.out_features))
         integral = _IntegralImage.apply(features)
+        needs_grad = torch.is_grad_enabled() and (features.requires_grad or self.collapse.weight.requires_grad)
+        if USE_FUSED and not needs_grad and C == 256 and self.collapse.out_features == 256:
+            # inference: pooling feeds the fp32-MFMA collapse product through LDS, vox never reaches HBM
+            w_t = self.layer_major_weight().t().contiguous()
+            return ops.project_collapse(integral, calibs, grid_flat, z_layers, corner_off, w_t, conv_kind,
+                                        (img_w, img_h), (geom[3], geom[4]))
         w_lm_t = self.layer_major_weight().t()
         per_cell = n * nl * C * 4
         chunk = max(1, min(n_cells, VOX_BYTES_LIMIT // max(per_cell, 1)))
