@@ -83,11 +83,18 @@ def main():
     if world != a.gpus and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    # functional test hook for 1-GPU boxes: all ranks on device 0 with gloo (VFA_BENCH_BACKEND=gloo); never used for numbers
+    backend = os.environ.get("VFA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     import vfa_amd
     from vfa_amd import ops

@@ -394,3 +394,63 @@ def test_fused_collapse_matches_unfused(name, n_cam, crop):
         scale = want.abs().max().item()
         assert scale > 0
         torch.testing.assert_close(got.double(), want, rtol=RTOL, atol=ATOL_REL * scale)
+
+
+@pytest.mark.parametrize("name,n_cam", [("wildtrack_480x1440x1", 2), ("synthetic4k_512x512x32", 1)])
+def test_large_grids_chunking_and_index_ranges(name, n_cam, monkeypatch):
+    """BASELINE configs 3 and 5 at full grid size (fewer cameras): 64-bit indexing, cell chunking of the voxel buffer,
+    and agreement of the chunked module path with a direct un-chunked launch on a sample of cells."""
+    import vfa_amd
+    from vfa_amd import _lib, ops, vfa_op
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload(name, channels=256, seed=4, n_cam=n_cam)
+    torch.manual_seed(5)
+    mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+    zl, co = mod._kernel_geometry(dev)
+    nl = zl.numel()
+    grid = wl["grid"].to(dev)
+    grid_flat = grid.reshape(-1, 3).contiguous()
+    n_cells = grid_flat.shape[0]
+    calibs = wl["calibs"].to(dev)
+    lat = torch.cat([wl["features"][c][1] for c in range(n_cam)]).to(dev)  # stride-16 maps
+    monkeypatch.setattr(vfa_op, "VOX_BYTES_LIMIT", 1 << 30)  # force several cell chunks
+    assert n_cam * n_cells * nl * 256 * 4 > (1 << 30)
+    with torch.no_grad():
+        lin = mod.project_views(lat, calibs, grid)
+    assert tuple(lin.shape) == (n_cam, n_cells, 256) and torch.isfinite(lin).all()
+    # direct launch on three windows of cells (start, middle, end), compared through the same GEMM
+    kind, img_wh = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
+    integral = ops.integral_image(lat)
+    w_t = mod.layer_major_weight().detach().t()
+    for begin in (0, n_cells // 2 - 1000, n_cells - 4096):
+        vox = ops.project_gather(integral, calibs.reshape(n_cam, 12), grid_flat, zl, co, kind, img_wh, cell_begin=begin,
+                                 cell_count=4096)
+        want = torch.matmul(vox.view(n_cam * 4096, -1), w_t).view(n_cam, 4096, 256)
+        got = lin[:, begin:begin + 4096]
+        torch.testing.assert_close(got, want, rtol=RTOL, atol=ATOL_REL * want.abs().max().item())
+    assert lin.abs().max() > 0
+
+
+def test_two_kernel_form_is_bitwise_identical():
+    """vfa_project_gather_ws_f32 (records through HBM, scalar-loaded) == vfa_project_gather_f32, both layouts."""
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    import vfa_amd
+    dev = _dev()
+    wl = make_workload("wildtrack_120x360x8", channels=256, seed=9, n_cam=2)
+    mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+    zl, co = mod._kernel_geometry(dev)
+    grid_flat = wl["grid"][0, :50, :77].reshape(-1, 3).contiguous().to(dev)
+    calibs = wl["calibs"].reshape(2, 12).to(dev)
+    lat = torch.cat([wl["features"][c][0] for c in range(2)]).to(dev)
+    integral = ops.integral_image(lat)
+    kind, img_wh = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
+    for layout in (_lib.VOX_LAYER_MAJOR, _lib.VOX_REFERENCE):
+        a = ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, layout=layout)
+        b = ops.project_gather_ws(integral, calibs, grid_flat, zl, co, kind, img_wh, layout=layout)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # a window of cells
+    a = ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, cell_begin=100, cell_count=333)
+    b = ops.project_gather_ws(integral, calibs, grid_flat, zl, co, kind, img_wh, cell_begin=100, cell_count=333)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))

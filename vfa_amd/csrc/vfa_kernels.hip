@@ -299,6 +299,7 @@ struct GatherDims {
     int C, Hf, Wf, nl, n_cells, cell_begin, cell_count, vox_layout;
     long long n_boxes;    // n_views * cell_count * nl
     long long per_xcd;    // blocks per XCD
+    int ws_chunk;         // two-kernel form: boxes per pooling wave (power of two <= 64)
 };
 
 // Per-box record staged in LDS by phase 1 of the gather kernel (32 words = 8 x ds_read_b128, broadcast to the wave).
@@ -425,7 +426,7 @@ template <bool FUSED>
 __device__ __forceinline__ void stage_box_records(BoxRec *recs, long long tile0, int nb, int lane,
                                                   const float4 *__restrict__ box, const float *__restrict__ area_in,
                                                   const uint8_t *__restrict__ visible_in, const BoxGeom &g,
-                                                  const GatherDims &d)
+                                                  const GatherDims &d, int chunk = kPerWave)
 {
     if ((int)threadIdx.x < nb) {
         const long long wid = tile0 + threadIdx.x;
@@ -461,15 +462,15 @@ __device__ __forceinline__ void stage_box_records(BoxRec *recs, long long tile0,
         fill_record(rc, view, l, t, r, b, area, vis, d, key_x, key_y);
         rc.w.out_row = (unsigned)vc;
         rc.w.layer = layer;
-        // Runs of boxes with one tap set: lanes are consecutive boxes, a wave's chunk in phase 2 is kPerWave of them.
+        // Runs of boxes with one tap set: lanes are consecutive boxes, a wave's chunk in phase 2 is `chunk` of them.
         // cont = "this box continues the run of the previous lane"; run_len counts the set bits that follow.
         const int tag = (view << 5) | rc.h.flags;
-        const bool cont = vis && (lane & (kPerWave - 1)) != 0 && __shfl_up(tag, 1) == tag &&
+        const bool cont = vis && (lane & (chunk - 1)) != 0 && __shfl_up(tag, 1) == tag &&
                           __shfl_up(key_x, 1) == key_x && __shfl_up(key_y, 1) == key_y;
         const unsigned long long mask = __ballot(cont);
         const unsigned long long after = lane == 63 ? 0ull : (mask >> (lane + 1));
         const int follow = after == ~0ull ? 64 : __builtin_ctzll(~after);
-        rc.h.run_len = 1 + min(follow, kPerWave - 1 - (lane & (kPerWave - 1)));
+        rc.h.run_len = 1 + min(follow, chunk - 1 - (lane & (chunk - 1)));
     }
 }
 
@@ -585,7 +586,8 @@ __global__ __launch_bounds__(256) void box_records_kernel(BoxRec *__restrict__ r
     const long long tile0 = (long long)blockIdx.x * 256;
     if (tile0 >= d.n_boxes) return;
     const int nb = (int)min(256ll, d.n_boxes - tile0);
-    stage_box_records<FUSED>(recs + tile0, tile0, nb, threadIdx.x & (kWave - 1), box, area_in, visible_in, g, d);
+    stage_box_records<FUSED>(recs + tile0, tile0, nb, threadIdx.x & (kWave - 1), box, area_in, visible_in, g, d,
+                             d.ws_chunk);
 }
 
 // Scalar-memory prefetch of box records.  hipcc sinks a plain load to its first use, which would put the record fetch
@@ -641,9 +643,9 @@ __global__ __launch_bounds__(kWave) void gather_records_kernel(const float *__re
     using V = typename vec_of<VEC>::type;
     const int lane = threadIdx.x;
     const long long chunk = xcd_contiguous(blockIdx.x, d.per_xcd);
-    const long long j0 = chunk * kPerWave;
+    const long long j0 = chunk * d.ws_chunk;
     if (j0 >= d.n_boxes) return;
-    const long long j_end = min(d.n_boxes, j0 + kPerWave);
+    const long long j_end = min(d.n_boxes, j0 + d.ws_chunk);
     const size_t img_stride = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C * sizeof(float);
     const bool layer_major = d.vox_layout == VFA_VOX_LAYER_MAJOR;
     const unsigned c_bytes = (unsigned)d.C * 4u;
@@ -1199,11 +1201,12 @@ int launch_gather_ws(const float *integral, const float *box, const float *area,
     if (!workspace || workspace_bytes < ((size_t)d.n_boxes + 1) * sizeof(BoxRec)) return VFA_ERR_BAD_ARGUMENT;
     BoxRec *recs = reinterpret_cast<BoxRec *>(workspace);
     d.per_xcd = 0;
+    d.ws_chunk = 16; // boxes per pooling wave
     hipLaunchKernelGGL((box_records_kernel<FUSED>), dim3((unsigned)((d.n_boxes + 255) / 256)), dim3(256), 0, s, recs,
                        (const float4 *)box, area, visible, g, d);
     int st = launch_status();
     if (st) return st;
-    const long long chunks = (d.n_boxes + kPerWave - 1) / kPerWave;
+    const long long chunks = (d.n_boxes + d.ws_chunk - 1) / d.ws_chunk;
     d.per_xcd = (chunks + 7) / 8;
     const dim3 grid((unsigned)(d.per_xcd * 8));
     if (C % 4 == 0)
