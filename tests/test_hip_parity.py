@@ -454,3 +454,46 @@ def test_two_kernel_form_is_bitwise_identical():
     a = ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, cell_begin=100, cell_count=333)
     b = ops.project_gather_ws(integral, calibs, grid_flat, zl, co, kind, img_wh, cell_begin=100, cell_count=333)
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_crange_variants_and_signed_features_vs_oracle(oracle):
+    """crange other than the default (taps land on the right / bottom zero border), signed features, two views."""
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import ring_cameras
+    from vfa_amd.utils import make_grid
+    dev = _dev()
+    gen = torch.Generator().manual_seed(21)
+    C, Hf, Wf = 32, 23, 40
+    feat = torch.randn(2, C, Hf, Wf, generator=gen)
+    calibs = ring_cameras(2, (700.0, 600.0, 0.0), 1500.0, 500.0, 900.0, (640, 368), phase=1.1)
+    grid = make_grid(world_size=(1200, 1400), cube_LW=(50, 50), dataset="MultiviewC")
+    cube = (50, 50, 60)
+    zl = oracle.z_layers_of(180, cube)
+    co = oracle.corner_offsets(cube)
+    integral = ops.integral_image(feat.to(dev))
+    for crange in ((-1.0, 1.0), (-0.5, 0.5), (-1.0, 0.95)):
+        got = ops.project_gather(integral, calibs.reshape(2, 12).to(dev), grid.reshape(-1, 3).to(dev),
+                                 torch.from_numpy(zl).to(dev), torch.from_numpy(co).to(dev), 0, (640, 368),
+                                 crange=crange).cpu().numpy()
+        for v in range(2):
+            I = oracle.integral_image(feat[v].numpy())
+            box, area, vis = oracle.box_params(calibs[v].numpy(), grid.numpy(), zl, co, "MultiviewC", (368, 640), Hf, Wf,
+                                               crange)
+            vox = oracle.gather(I, box, area, vis)
+            assert 0.05 < vis.mean() < 1.0
+            assert_bitwise(f"vox crange={crange}", got[v], _to_layer_major(vox, C, len(zl)), zero_sign_free=True)
+
+
+def test_nan_box_propagates_like_the_reference():
+    """A projection with h2 == 0 and h0 == 0 gives NaN box coordinates; the reference's `vox * visible` is then NaN
+    (NaN * 0), not 0.  The kernel reproduces that (masked value = area * 0)."""
+    from vfa_amd import ops
+    dev = _dev()
+    feat = torch.rand(1, 8, 6, 8, device=dev)
+    integral = ops.integral_image(feat)
+    calib = torch.zeros(1, 12, device=dev)  # every homogeneous coordinate is 0 -> 0/0
+    grid = torch.tensor([[0., 0., 0.], [25., 0., 0.]], device=dev)
+    zl = torch.tensor([0.], device=dev)
+    co = torch.zeros(8, 3, device=dev)
+    vox = ops.project_gather(integral, calib, grid, zl, co, 0, (64, 48))
+    assert torch.isnan(vox).all()
