@@ -733,9 +733,8 @@ __global__ __launch_bounds__(kWave) void gather_records_kernel(const float *__re
 // 64 x 256 block of voxel features, i.e. the A operand of a 64 x 256 x 256 product with W_layer^T.
 //   waves 4-11 (producers, VALU): project + pool 8 boxes each -- the same arithmetic as gather_kernel, bit for bit --
 //                                 and write the rows into the LDS A buffer of the NEXT sub-tile;
-//   waves 0-3 (consumers, MFMA):  v_mfma_f32_32x32x2_f32 over the CURRENT A buffer; wave (rh, ch) owns rows 32 rh.. and
-//                                 columns 128 ch.. as four 32x32 blocks (column 4j+q of the block belongs to MFMA block
-//                                 q, so one float4 load of W feeds four MFMAs and one float4 store covers a row piece).
+//   waves 0-3 (consumers, MFMA):  v_mfma_f32_32x32x2_f32 over the CURRENT A buffer; wave w owns all 64 rows and columns
+//                                 64 w.. as 2 x 2 blocks of 32 x 32 (W streamed from L2 once per wave and sub-tile).
 // The matrix pipe and the VALU are separate, so the two wave groups of a SIMD overlap; one barrier per sub-tile swaps
 // the double-buffered A tile.  MFMA fp32 is a k-ordered fmaf chain, so results are within the collapse tolerance of
 // the reference GEMM (not bitwise; no GEMM order is).
@@ -876,66 +875,84 @@ __global__ __launch_bounds__(64 * (4 + kProducers)) void fused_collapse_kernel(c
         }
     };
 
-    // ---- consumer state: wave (rh, ch) owns rows 32 rh + (0..31), columns 128 ch + 4 j + q
-    const int rh = wave >> 1, ch = wave & 1;
-    mfma_acc_t acc[4];
+    // ---- consumer state: wave w owns all 64 rows x columns 64 w + 2 j + q: two row blocks x two column blocks of 32 x 32
+    // (column 2j+q of the wave's strip belongs to MFMA column block q, so one 8-byte load of W feeds both column blocks
+    // and one 8-byte store covers a row piece).  Every wave reads its own 64 columns of W exactly once per sub-tile.
+    mfma_acc_t acc[2][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][q][e] = 0.0f;
+    constexpr int U = 4;               // k-steps per software-pipeline group
+    constexpr int G = kFusedK / 2 / U; // groups per sub-tile (16)
+    float2 b0[U], b1[U];
+    float a0[U][2], a1[U][2];
+    const int khalf = lane >> 5;
+    auto w_ptr = [&](int sub) {
+        const int layer = sub % fd.nl;
+        return reinterpret_cast<const float2 *>(w_t + ((size_t)layer * kFusedK + khalf) * kFusedN + 64 * wave) + (lane & 31);
+    };
+    auto load_b = [&](const float2 *wp, int grp, float2 (&bb)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) bb[u] = wp[(size_t)(2 * (grp * U + u)) * (kFusedN / 2)];
+    };
+    auto load_a = [&](const float *A, int grp, float (&aa)[U][2]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = 2 * (grp * U + u) + khalf;
+            aa[u][0] = A[a_index(lane & 31, k)];
+            aa[u][1] = A[a_index(32 + (lane & 31), k)];
+        }
+    };
+    auto mfma_group = [&](const float2 (&bb)[U], const float (&aa)[U][2]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u][0], bb[u].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u][0], bb[u].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u][1], bb[u].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u][1], bb[u].y, acc[1][1], 0, 0, 0);
+        }
+    };
 
+    // W of the first group is already in b0 when consume() is entered (fetched before the barrier)
     auto consume = [&](int sub) {
         const int layer = sub % fd.nl;
         const float *A = a_buf + (size_t)(sub & 1) * kFusedRows * kFusedK;
-        const int arow = 32 * rh + (lane & 31), khalf = lane >> 5;
-        // W_layer^T rows k, columns n: lane reads W[k = 2 s + khalf][128 ch + 4 (lane & 31) .. + 3]
-        const float4 *wp = reinterpret_cast<const float4 *>(w_t + ((size_t)layer * kFusedK + khalf) * kFusedN + 128 * ch) +
-                           (lane & 31);
-        // Software pipeline without register copies: two operand sets (R0, R1) of U k-steps each; the loads of one set
-        // are issued before the U x 4 MFMAs (U x 256 cycles) of the other.
-        constexpr int U = 8;
-        constexpr int G = kFusedK / 2 / U; // groups per sub-tile (16)
-        float4 b0[U], b1[U];
-        float a0[U], a1[U];
-        auto load_group = [&](int grp, float4 (&bb)[U], float (&aa)[U]) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                bb[u] = wp[(size_t)(2 * (grp * U + u)) * (kFusedN / 4)];
-                aa[u] = A[a_index(arow, 2 * (grp * U + u) + khalf)];
-            }
-        };
-        auto mfma_group = [&](const float4 (&bb)[U], const float (&aa)[U]) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u].x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u].y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u].z, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[u], bb[u].w, acc[3], 0, 0, 0);
-            }
-        };
-        load_group(0, b0, a0);
+        const float2 *wp = w_ptr(sub);
+        load_a(A, 0, a0);
 #pragma unroll 1
         for (int grp = 0; grp < G; grp += 2) {
-            load_group(grp + 1, b1, a1);
+            load_b(wp, grp + 1, b1);
+            load_a(A, grp + 1, a1);
             mfma_group(b0, a0);
-            if (grp + 2 < G) load_group(grp + 2, b0, a0);
+            if (grp + 2 < G) {
+                load_b(wp, grp + 2, b0);
+                load_a(A, grp + 2, a0);
+            } else if (sub + 1 < total_sub) {
+                load_b(w_ptr(sub + 1), 0, b0); // W of the next sub-tile does not depend on the barrier
+            }
             mfma_group(b1, a1);
         }
-        if (layer == fd.nl - 1) { // tile finished: write the 32 x 128 piece, reset the accumulators
+        if (layer == fd.nl - 1) { // tile finished: write the 64 x 64 strip, reset the accumulators
             const int tile = t_begin + sub / fd.nl;
             const int view = tile / fd.tiles_per_view, cell0 = (tile % fd.tiles_per_view) * kFusedRows;
-            float *out = lin + ((size_t)view * fd.n_cells + cell0) * kFusedN + 128 * ch + 4 * (lane & 31);
+            float *out = lin + ((size_t)view * fd.n_cells + cell0) * kFusedN + 64 * wave + 2 * (lane & 31);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rloc = 32 * rh + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (cell0 + rloc < fd.n_cells)
-                    *reinterpret_cast<float4 *>(out + (size_t)rloc * kFusedN) =
-                        make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
-            }
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int e = 0; e < 16; ++e) {
+                    const int rloc = 32 * r + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (cell0 + rloc < fd.n_cells)
+                        *reinterpret_cast<float2 *>(out + (size_t)rloc * kFusedN) = make_float2(acc[r][0][e], acc[r][1][e]);
+                }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[r][q][e] = 0.0f;
         }
     };
 
@@ -949,6 +966,7 @@ __global__ __launch_bounds__(64 * (4 + kProducers)) void fused_collapse_kernel(c
             __syncthreads();
         }
     } else {
+        load_b(w_ptr(0), 0, b0);
         __syncthreads();
         for (int i = 0; i < total_sub; ++i) {
             consume(i);
