@@ -15,6 +15,7 @@
 // C = 256 = one 16 B/lane wave64 load), and grid_sample's zeros padding is a plain load of the border.
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <cstdint>
 
 #include "vfa_hip.h"
 
@@ -58,7 +59,8 @@ constexpr int kRowChunk = 32;
 __global__ __launch_bounds__(kWave) void integral_rows_kernel(const float *__restrict__ feat,
                                                               float *__restrict__ out, int C, int H, int W)
 {
-    __shared__ float tile[kWave][kRowChunk + 1];
+    // tile[channel][x]: row stride 33 floats -> the per-lane scans (lane = channel) are bank-conflict free
+    __shared__ __align__(16) float tile[kWave][kRowChunk + 1];
     const int lane = threadIdx.x;
     const int y = blockIdx.x, c0 = blockIdx.y * kWave, v = blockIdx.z;
     const int nch = min(kWave, C - c0);
@@ -71,20 +73,48 @@ __global__ __launch_bounds__(kWave) void integral_rows_kernel(const float *__res
         dst[lane] = 0.0f;                        // left border
         dst[(size_t)(W + 1) * C + lane] = 0.0f;  // right border
     }
+    // 16-byte paths need aligned rows (loads) and channel quads (stores)
+    const bool vec_load = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0);
+    const bool vec_store = (C % 4 == 0) && (nch == kWave) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     double acc = 0.0;
     for (int x0 = 0; x0 < W; x0 += kRowChunk) {
         const int nx = min(kRowChunk, W - x0);
-        const int j = lane & (kRowChunk - 1);
-        for (int r = lane >> 5; r < nch; r += 2)
-            if (j < nx) tile[r][j] = src[(size_t)r * plane + x0 + j];
+        if (vec_load && nx == kRowChunk) {
+            // 8 lanes x float4 cover one 32-column row piece: 8 channels per load instruction, 1 KiB per wave
+            const int q = lane & 7;
+            for (int r = lane >> 3; r < nch; r += 8) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)r * plane + x0 + 4 * q);
+                tile[r][4 * q + 0] = t.x; tile[r][4 * q + 1] = t.y; tile[r][4 * q + 2] = t.z; tile[r][4 * q + 3] = t.w;
+            }
+        } else {
+            const int j = lane & (kRowChunk - 1);
+            for (int r = lane >> 5; r < nch; r += 2)
+                if (j < nx) tile[r][j] = src[(size_t)r * plane + x0 + j];
+        }
         __syncthreads();
         if (active) {
-            for (int k = 0; k < nx; ++k) {
-                acc += (double)tile[lane][k];
-                dst[(size_t)(x0 + k + 1) * C + lane] = (float)acc;
+            if (vec_store) {
+                for (int k = 0; k < nx; ++k) { // scan in place; the stores follow as 16-byte accesses
+                    acc += (double)tile[lane][k];
+                    tile[lane][k] = (float)acc;
+                }
+            } else {
+                for (int k = 0; k < nx; ++k) {
+                    acc += (double)tile[lane][k];
+                    dst[(size_t)(x0 + k + 1) * C + lane] = (float)acc;
+                }
             }
         }
         __syncthreads();
+        if (vec_store) {
+            // lane -> (x = lane / 16, channel quad = lane % 16): 4 x-positions x 256 B per store instruction
+            const int cq = lane & 15;
+            for (int k = lane >> 4; k < nx; k += 4) {
+                const float4 t = make_float4(tile[4 * cq + 0][k], tile[4 * cq + 1][k], tile[4 * cq + 2][k], tile[4 * cq + 3][k]);
+                *reinterpret_cast<float4 *>(dst + (size_t)(x0 + k + 1) * C + 4 * cq) = t;
+            }
+            __syncthreads();
+        }
     }
 }
 
