@@ -127,9 +127,22 @@ def main():
     units_rank = n * 3 * nl * L * W
     units_total = units_rank * world if a.scaling == "weak" else n_frame * 3 * nl * L * W
 
+    # N > 1: the all-reduce of frame i is launched asynchronously and overlaps the projection of frame i+1 (one map in
+    # flight); every collective completes inside the timed region.  VFA_BENCH_SYNC_REDUCE=1 reduces synchronously.
+    overlap = world > 1 and os.environ.get("VFA_BENCH_SYNC_REDUCE", "0") != "1"
+    pending = []
+
     def step():
         with torch.no_grad():
-            return vfa_amd.aggregate_views(*mods, *lats, calibs, grid, distributed=world > 1)
+            if not overlap:
+                return vfa_amd.aggregate_views(*mods, *lats, calibs, grid, distributed=world > 1)
+            while pending:
+                pending.pop().wait()  # frame i-1 is fused before frame i's collective is queued
+            pending.append(vfa_amd.aggregate_views(*mods, *lats, calibs, grid, distributed="async"))
+
+    def drain():
+        while pending:
+            pending.pop().wait()
 
     def fence():
         if world > 1:
@@ -138,11 +151,13 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    drain()
     fence()
     with ops.KernelTimer() as kt:
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
+        drain()
         fence()
         dt = time.perf_counter() - t0
     if world > 1:
@@ -187,7 +202,8 @@ def main():
             "config": {"workload": a.workload, "cameras_per_rank": n, "cameras_total": n * world if a.scaling == "weak"
                        else n_frame, "channels": C, "feature_maps": [list(s) for s in wl["feat_sizes"]],
                        "grid": [L, W, nl], "units_per_step": units_total,
-                       "parallelism": f"camera-sharded dp{world}, RCCL all-reduce of the BEV map" if world > 1
+                       "parallelism": (f"camera-sharded dp{world}, RCCL all-reduce of the BEV map"
+                                       + (" overlapped with the next frame" if overlap else "")) if world > 1
                        else "single GPU"},
             "bev_cells_per_s": nl * L * W * a.steps / dt,
             "roofline": roofline,

@@ -75,3 +75,32 @@ def test_all_reduce_is_identity_without_a_process_group():
     from vfa_amd.aggregate import all_reduce_ortho
     t = torch.arange(6.).view(3, 2)
     assert all_reduce_ortho(t) is t
+
+
+def _async_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vfa_amd.aggregate import PendingOrtho
+        # what aggregate_views(distributed="async") does after forming the partial map, on CPU tensors
+        maps = []
+        for frame in range(3):
+            part = torch.full((6, 4), float(rank + 1 + 10 * frame))
+            work = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True)
+            maps.append(PendingOrtho(part, work, (2, 3, 4)))
+        for frame, p in enumerate(maps):
+            got = p.wait()
+            assert tuple(got.shape) == (1, 4, 2, 3)
+            assert torch.all(got == sum(r + 1 + 10 * frame for r in range(world)))
+            assert p.wait() is not None  # idempotent
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pending_ortho_async_all_reduce_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_async_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]

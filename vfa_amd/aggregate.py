@@ -82,13 +82,33 @@ def all_reduce_ortho(ortho_nhwc, group=None):
     return ortho_nhwc
 
 
+class PendingOrtho:
+    """A fused BEV map whose all-reduce is still in flight (``aggregate_views(..., distributed="async")``).
+
+    The collective runs on RCCL's own stream while this process goes on with the next frame; ``wait()`` makes the
+    current stream wait for it and returns the (1,C,L,W) map.  Keep at most one or two pending (each holds a map).
+    """
+
+    def __init__(self, ortho_nhwc, work, shape):
+        self._ortho, self._work, self._shape = ortho_nhwc, work, shape
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        length, width, c = self._shape
+        return self._ortho.view(1, length, width, c).permute(0, 3, 1, 2)
+
+
 def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange=(-1, 0.95), reduce_group=None,
                     distributed=False):
     """The camera loop of ``VFANet.forward`` for the cameras held by this process.
 
     lat* (n,C,h,w) lateral maps of the local cameras, calibs (n,3,4), grid (1,L,W,3)
     -> ortho (1,C,L,W): a permuted view of the channels-last buffer, like the reference returns.
-    With ``distributed=True`` the partial sums of all ranks are all-reduced.
+    With ``distributed=True`` the partial sums of all ranks are all-reduced before returning; with
+    ``distributed="async"`` (inference) the all-reduce is only launched and a ``PendingOrtho`` is returned, so that
+    the collective of frame i overlaps the projection of frame i+1.
     """
     length, width = grid.shape[-3], grid.shape[-2]
     n = calibs.shape[0]
@@ -114,6 +134,12 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
         ortho = _ScaleViewSum.apply(lin8, lin16, lin32, vfa8.collapse.bias, vfa16.collapse.bias, vfa32.collapse.bias)
     else:  # a rank without cameras (8 GPUs, 7 cameras) contributes zeros
         ortho = torch.zeros((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
+    c_out = vfa8.collapse.out_features
+    if distributed == "async":
+        work = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(reduce_group) > 1:
+            work = dist.all_reduce(ortho, op=dist.ReduceOp.SUM, group=reduce_group, async_op=True)
+        return PendingOrtho(ortho, work, (length, width, c_out))
     if distributed:
         ortho = all_reduce_ortho(ortho, reduce_group)
-    return ortho.view(1, length, width, vfa8.collapse.out_features).permute(0, 3, 1, 2)
+    return ortho.view(1, length, width, c_out).permute(0, 3, 1, 2)
