@@ -120,6 +120,12 @@ int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, 
 int vfa_integral_image_backward_f32(float *grad_integral, float *grad_feature, int n_views, int C, int Hf, int Wf,
                                     void *stream);
 
+/* Backward of the two epilogues below with respect to `lin` and `bias` (per scale):
+ *   grad_lin[v] = grad * (lin[v] + bias > 0);  grad_bias = column sums of grad_lin (zeroed first; NULL to skip).
+ * grad (M, N); lin, grad_lin (n_views, M, N).  Needs 4 | N and N | 1024, otherwise VFA_ERR_UNSUPPORTED. */
+int vfa_relu_mask_backward_f32(const float *grad, const float *lin, const float *bias, float *grad_lin, float *grad_bias,
+                               int n_views, size_t M, int N, void *stream);
+
 /* Epilogue of `collapse` for one VFA call batch:  out = (accumulate ? out : 0) + sum_v relu(lin[v] + bias)
  * with views added in index order.            replaces vfa_op.py:124 (ReLU) and vfanet.py:82 (view sum)
  *   lin (n_views, M, N) = vox . W^T without bias; bias (N) or NULL; out (M, N). */

@@ -21,7 +21,7 @@ def built_lib():
 def _declared_symbols():
     text = open(os.path.join(REPO, "include", "vfa_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(vfa_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|size_t)\s+(vfa_\w+)\s*\(", text)))
 
 
 def test_header_declares_the_expected_entry_points():

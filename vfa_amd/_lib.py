@@ -33,6 +33,7 @@ SIGNATURES = {
     "vfa_project_gather_backward_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],
     "vfa_integral_image_backward_f32": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
+    "vfa_relu_mask_backward_f32": [_vp, _vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _vp],
     "vfa_bias_relu_accumulate_f32": [_vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _vp],
     "vfa_scale_view_sum_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _vp],
 }

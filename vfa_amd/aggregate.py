@@ -44,9 +44,9 @@ class _ScaleViewSum(torch.autograd.Function):
         lin8, lin16, lin32, b8, b16, b32 = ctx.saved_tensors
         outs, bias_grads = [], []
         for lin, b in ((lin8, b8), (lin16, b16), (lin32, b32)):
-            g = grad.unsqueeze(0) * ((lin + b) > 0)
+            g, gb = ops.relu_mask_backward(grad, lin, b)
             outs.append(g)
-            bias_grads.append(g.sum(dim=(0, 1)))
+            bias_grads.append(gb)
         return (*outs, *bias_grads)
 
 

@@ -1010,32 +1010,59 @@ __global__ __launch_bounds__(64 * (4 + kProducers)) void fused_collapse_kernel(c
 // The reference trains through this path with autograd (trainer.py:41); there is no reference code to mirror, only
 // the derivative of vfa_op.py:112-119.  Not bit-reproducible: float atomics sum in arrival order.
 // ------------------------------------------------------------------------------------------------
-// Combined weight of every unique tap of a box: + lt + rb - rt - lb, scaled by 1/area.
+// Combined weight of every unique tap of a box: + lt + rb - rt - lb (the 1/area factor rides on the gradient).
+// A run of consecutive boxes with one tap set (forward: register-patch reuse) is summed in registers first, so each
+// distinct tap of the run receives ONE atomic per channel instead of one per box.
 template <int DYC, int DXC>
-__device__ __forceinline__ void scatter_box(float *__restrict__ gimg, int C, int lane, const BoxHdr &h, const BoxWeights &w,
+__device__ __forceinline__ void scatter_run(float *__restrict__ gimg, int C, int lane, const BoxRec *__restrict__ rr, int run,
                                             const float *__restrict__ gvox)
 {
     constexpr int NR = DYC == 0 ? 2 : (DYC == 1 ? 3 : 4), NC = DXC == 0 ? 2 : (DXC == 1 ? 3 : 4);
     constexpr int RB0 = DYC == 0 ? 0 : (DYC == 1 ? 1 : 2), RB1 = RB0 + 1;
     constexpr int CR0 = DXC == 0 ? 0 : (DXC == 1 ? 1 : 2), CR1 = CR0 + 1;
-    float W[NR][NC];
+    const BoxHdr h = rr[0].h;
+    for (int cb = 0; cb < C; cb += 4 * kWave) { // 256 channels per sweep: lane owns channels cb + lane + 64 q
+        float T[NR][NC][4];
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) W[r][c] = 0.0f;
-    W[0][0] += w.lt[0]; W[0][1] += w.lt[1]; W[1][0] += w.lt[2]; W[1][1] += w.lt[3];
-    W[RB0][CR0] += w.rb[0]; W[RB0][CR1] += w.rb[1]; W[RB1][CR0] += w.rb[2]; W[RB1][CR1] += w.rb[3];
-    W[0][CR0] -= w.rt[0]; W[0][CR1] -= w.rt[1]; W[1][CR0] -= w.rt[2]; W[1][CR1] -= w.rt[3];
-    W[RB0][0] -= w.lb[0]; W[RB0][1] -= w.lb[1]; W[RB1][0] -= w.lb[2]; W[RB1][1] -= w.lb[3];
-    for (int c = lane; c < C; c += kWave) { // one dword per lane: 256 contiguous bytes per atomic wave-instruction
-        const float gv = gvox[c] / w.area;
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) T[r][c][q] = 0.0f;
+        for (int k = 0; k < run; ++k) {
+            const BoxWeights w = rr[k].w;
+            float W[NR][NC];
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) W[r][c] = 0.0f;
+            W[0][0] += w.lt[0]; W[0][1] += w.lt[1]; W[1][0] += w.lt[2]; W[1][1] += w.lt[3];
+            W[RB0][CR0] += w.rb[0]; W[RB0][CR1] += w.rb[1]; W[RB1][CR0] += w.rb[2]; W[RB1][CR1] += w.rb[3];
+            W[0][CR0] -= w.rt[0]; W[0][CR1] -= w.rt[1]; W[1][CR0] -= w.rt[2]; W[1][CR1] -= w.rt[3];
+            W[RB0][0] -= w.lb[0]; W[RB0][1] -= w.lb[1]; W[RB1][0] -= w.lb[2]; W[RB1][1] -= w.lb[3];
+            float gv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cb + lane + kWave * q;
+                gv[q] = c < C ? gvox[(size_t)k * C + c] / w.area : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) T[r][c][q] = fmaf(gv[q], W[r][c], T[r][c][q]);
+        }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int rs = (DYC == 1 && r == 2) ? 3 : r;
 #pragma unroll
-            for (int cc = 0; cc < NC; ++cc) {
-                const int cs = (DXC == 1 && cc == 2) ? 3 : cc;
-                unsafeAtomicAdd(gimg + ((h.row[rs] + h.col[cs]) >> 2) + c, gv * W[r][cc]);
+            for (int c = 0; c < NC; ++c) {
+                const int cs = (DXC == 1 && c == 2) ? 3 : c;
+                float *tap = gimg + ((h.row[rs] + h.col[cs]) >> 2) + cb + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (cb + lane + kWave * q < C) unsafeAtomicAdd(tap + kWave * q, T[r][c][q]); // 256 contiguous bytes per wave
             }
         }
     }
@@ -1054,24 +1081,27 @@ __global__ __launch_bounds__(256) void gather_backward_kernel(const float *__res
     stage_box_records<true>(recs, tile0, nb, lane, nullptr, nullptr, nullptr, g, d);
     __syncthreads();
     const size_t img_floats = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C;
-    for (int j = wave; j < nb; j += 4) {
-        const BoxHdr h = recs[j].h;
+    const int j_end = min(nb, (wave + 1) * kPerWave);
+    int j = wave * kPerWave;
+    while (j < j_end) {
+        const BoxHdr &h = recs[j].h;
         const int flags = uniform_i(h.flags);
-        if (!(flags & 1)) continue; // masked voxels pass no gradient
-        const BoxWeights w = recs[j].w;
+        if (!(flags & 1)) { ++j; continue; } // masked voxels pass no gradient
+        const int run = uniform_i(h.run_len);
         float *gimg = grad_integral + (size_t)uniform_i(h.view) * img_floats;
-        const float *gvox = grad_vox + (size_t)(tile0 + j) * d.C; // layer-major
+        const float *gvox = grad_vox + (size_t)(tile0 + j) * d.C; // layer-major: box j + k at + k * C
         switch (flags >> 1) {
-        case 0: scatter_box<0, 0>(gimg, d.C, lane, h, w, gvox); break;
-        case 1: scatter_box<0, 1>(gimg, d.C, lane, h, w, gvox); break;
-        case 2: scatter_box<0, 2>(gimg, d.C, lane, h, w, gvox); break;
-        case 4: scatter_box<1, 0>(gimg, d.C, lane, h, w, gvox); break;
-        case 5: scatter_box<1, 1>(gimg, d.C, lane, h, w, gvox); break;
-        case 6: scatter_box<1, 2>(gimg, d.C, lane, h, w, gvox); break;
-        case 8: scatter_box<2, 0>(gimg, d.C, lane, h, w, gvox); break;
-        case 9: scatter_box<2, 1>(gimg, d.C, lane, h, w, gvox); break;
-        default: scatter_box<2, 2>(gimg, d.C, lane, h, w, gvox); break;
+        case 0: scatter_run<0, 0>(gimg, d.C, lane, recs + j, run, gvox); break;
+        case 1: scatter_run<0, 1>(gimg, d.C, lane, recs + j, run, gvox); break;
+        case 2: scatter_run<0, 2>(gimg, d.C, lane, recs + j, run, gvox); break;
+        case 4: scatter_run<1, 0>(gimg, d.C, lane, recs + j, run, gvox); break;
+        case 5: scatter_run<1, 1>(gimg, d.C, lane, recs + j, run, gvox); break;
+        case 6: scatter_run<1, 2>(gimg, d.C, lane, recs + j, run, gvox); break;
+        case 8: scatter_run<2, 0>(gimg, d.C, lane, recs + j, run, gvox); break;
+        case 9: scatter_run<2, 1>(gimg, d.C, lane, recs + j, run, gvox); break;
+        default: scatter_run<2, 2>(gimg, d.C, lane, recs + j, run, gvox); break;
         }
+        j += run;
     }
 }
 
@@ -1196,6 +1226,50 @@ __global__ __launch_bounds__(256) void scale_view_sum_kernel(const float *__rest
         }
         if constexpr (VEC == 4) *reinterpret_cast<float4 *>(ortho + i) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         else ortho[i] = acc[0];
+    }
+}
+
+// backward of the collapse epilogues: glin[v] = grad * (lin[v] + bias > 0), gbias += column sums of glin.
+// Fast path (4 | N, N | 1024): a thread keeps its four columns over the whole grid-stride loop, so the bias gradient
+// is reduced in registers, then across the workgroup's waves in LDS, and costs N atomics per workgroup.
+__global__ __launch_bounds__(256) void relu_mask_backward_kernel(const float *__restrict__ grad, const float *__restrict__ lin,
+                                                                 const float *__restrict__ bias, float *__restrict__ glin,
+                                                                 float *__restrict__ gbias, int n_views, size_t MN, int N)
+{
+    __shared__ float red[256 * 4];
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    const size_t first = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int col = (int)(first % N);
+    float bb[4], cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bb[k] = bias ? bias[col + k] : 0.0f;
+    for (size_t i = first; i < MN; i += stride) {
+        const float4 g = *reinterpret_cast<const float4 *>(grad + i);
+        for (int v = 0; v < n_views; ++v) {
+            const float4 x = *reinterpret_cast<const float4 *>(lin + (size_t)v * MN + i);
+            float4 o;
+            o.x = (x.x + bb[0] > 0.0f) ? g.x : 0.0f;
+            o.y = (x.y + bb[1] > 0.0f) ? g.y : 0.0f;
+            o.z = (x.z + bb[2] > 0.0f) ? g.z : 0.0f;
+            o.w = (x.w + bb[3] > 0.0f) ? g.w : 0.0f;
+            *reinterpret_cast<float4 *>(glin + (size_t)v * MN + i) = o;
+            cs[0] += o.x; cs[1] += o.y; cs[2] += o.z; cs[3] += o.w;
+        }
+    }
+    if (gbias) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] = cs[k];
+        __syncthreads();
+        // threads t and t + N/4 (mod 256) own the same columns
+        const int per = N / 4; // threads per distinct column group
+        if ((int)threadIdx.x < per) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = 0.0f;
+                for (int t = threadIdx.x; t < 256; t += per) a += red[t * 4 + k];
+                unsafeAtomicAdd(gbias + col + k, a);
+            }
+        }
     }
 }
 
@@ -1418,6 +1492,22 @@ int vfa_integral_image_backward_f32(float *grad_integral, float *grad_feature, i
     if (st) return st;
     hipLaunchKernelGGL(integral_rows_backward_kernel, dim3(Hf, (C + kWave - 1) / kWave, n_views), dim3(kWave), 0, s,
                        grad_integral, grad_feature, C, Hf, Wf);
+    return launch_status();
+}
+
+int vfa_relu_mask_backward_f32(const float *grad, const float *lin, const float *bias, float *grad_lin, float *grad_bias,
+                               int n_views, size_t M, int N, void *stream)
+{
+    if (n_views < 0 || N <= 0 || N % 4 != 0 || 1024 % N != 0) return N > 0 && n_views >= 0 ? VFA_ERR_UNSUPPORTED : VFA_ERR_BAD_ARGUMENT;
+    const size_t MN = M * (size_t)N;
+    hipStream_t s = (hipStream_t)stream;
+    if (grad_bias) {
+        const hipError_t e = hipMemsetAsync(grad_bias, 0, (size_t)N * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (MN == 0 || n_views == 0) return 0;
+    hipLaunchKernelGGL(relu_mask_backward_kernel, dim3(elementwise_blocks(MN / 4)), dim3(256), 0, s, grad, lin, bias, grad_lin,
+                       grad_bias, n_views, MN, N);
     return launch_status();
 }
 

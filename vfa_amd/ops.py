@@ -176,6 +176,22 @@ def integral_image_backward(grad_integral):
     return grad_feature
 
 
+def relu_mask_backward(grad, lin, bias):
+    """-> (grad_lin (n,M,N) = grad * (lin + bias > 0), grad_bias (N) or None).  Backward of both epilogues."""
+    _lib.require_device(grad, lin, bias)
+    n, M, N = lin.shape
+    grad = _f32c(grad)
+    if N % 4 != 0 or 1024 % N != 0:  # shapes outside the kernel's fast path: plain torch on the GPU
+        pre = lin if bias is None else lin + bias
+        g = grad.unsqueeze(0) * (pre > 0)
+        return g, (None if bias is None else g.sum(dim=(0, 1)))
+    glin = torch.empty_like(lin)
+    gbias = None if bias is None else torch.empty_like(bias)
+    _launch("vfa_relu_mask_backward_f32", _lib.ptr(grad), _lib.ptr(lin), _lib.ptr(bias), _lib.ptr(glin), _lib.ptr(gbias),
+            n, M, N, _lib.current_stream_handle())
+    return glin, gbias
+
+
 def bias_relu_accumulate(lin, bias, out=None, accumulate=False):
     """out (M,N) (+)= sum_v relu(lin[v] + bias) (reference vfa_op.py:124, vfanet.py:82)."""
     _lib.require_device(lin, bias, out)

@@ -94,9 +94,7 @@ class _BiasReluSum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         lin, bias = ctx.saved_tensors
-        pre = lin if bias is None else lin + bias
-        g = grad_out.unsqueeze(0) * (pre > 0)
-        return g, (None if bias is None else g.sum(dim=(0, 1)))
+        return ops.relu_mask_backward(grad_out, lin, bias)
 
 
 class VFA(nn.Module):
