@@ -49,11 +49,21 @@ extern "C" {
 #define VFA_VOX_REFERENCE 0   /* vox[cell, c*nl + layer]   (vfa_op.py:120) */
 #define VFA_VOX_LAYER_MAJOR 1 /* vox[cell, layer*C + c]    (coalesced; collapse.weight columns permuted by the host) */
 
+/* optional kernel choice for vfa_project_gather_f32, OR-ed into vox_layout (same results bit for bit):
+ * neither flag = library default (tap cache on single-layer grids with C = 256, direct kernel otherwise) */
+#define VFA_VOX_KERNEL_DIRECT 0x100
+#define VFA_VOX_KERNEL_TAP_CACHE 0x200
+
 #define VFA_ERR_BAD_ARGUMENT 10001
 #define VFA_ERR_UNSUPPORTED 10002 /* shape outside what a specialised kernel was built for; use the general entry points */
 
 /* ABI version of the loaded library (VFA_ABI_VERSION at build time). */
 int vfa_abi_version(void);
+
+/* Process-wide tuning switches (do not change results).  VFA_OPT_TAP_CACHE: 1 (default) = vfa_project_gather_f32 may
+ * pool through the LDS tap cache by default (see VFA_VOX_KERNEL_*); 0 = the default is always the direct kernel. */
+#define VFA_OPT_TAP_CACHE 1
+int vfa_set_option(int option, int value);
 
 /* Integral image of every feature map: cumsum over W then over H, double accumulator rounded to
  * fp32 at every element (what ATen's CPU cumsum does), written channels-last inside a zero border.

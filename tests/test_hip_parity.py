@@ -523,3 +523,61 @@ def test_hipgraph_replay_equals_eager():
         got2 = g(*lats2, calibs2)
         assert torch.equal(got2, want2)
         assert not torch.equal(got2, want)
+
+
+@pytest.mark.parametrize("name,cam,si,crop,window", [
+    ("multiviewc_200x200x1", 2, 0, (57, 200), None),        # tall boxes at stride 8: tiles that overflow the 32 slots
+    ("multiviewc_200x200x1", 5, 2, (200, 200), (1234, 5003)),  # a window of cells that is not a multiple of 8
+    ("multiviewc_156x156x5", 0, 1, (60, 156), None),
+    ("wildtrack_120x360x8", 1, 0, (40, 360), (7, 4001)),
+    ("multiviewx_160x250x8", 2, 2, (64, 250), None),
+])
+def test_tap_cache_kernel_bitwise_vs_direct_and_oracle(oracle, name, cam, si, crop, window):
+    """The LDS tap-cache pooling kernel against the direct kernel (bitwise, both forced) and the CPU oracle."""
+    import vfa_amd
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload(name, channels=256, seed=31 + cam, n_cam=cam + 1)
+    feat = torch.cat([wl["features"][c][si] for c in (cam, 0)])          # two views
+    calibs = torch.stack([wl["calibs"][cam], wl["calibs"][0]])
+    grid = wl["grid"][0, :crop[0], :crop[1]].contiguous()
+    mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+    zl_d, co_d = mod._kernel_geometry(dev)
+    nl = zl_d.numel()
+    kind, img_wh = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
+    integral = ops.integral_image(feat.to(dev))
+    gflat = grid.reshape(-1, 3).to(dev)
+    begin, count = (0, gflat.shape[0]) if window is None else window
+    kw = dict(cell_begin=begin, cell_count=count)
+    direct = ops.project_gather(integral, calibs.reshape(2, 12).to(dev), gflat, zl_d, co_d, kind, img_wh, kernel="direct", **kw)
+    cached = ops.project_gather(integral, calibs.reshape(2, 12).to(dev), gflat, zl_d, co_d, kind, img_wh, kernel="tap_cache",
+                                **kw)
+    assert torch.equal(direct.view(torch.int32), cached.view(torch.int32))
+    # and against the oracle for the first view
+    zl = oracle.z_layers_of(wl["grid_height"], wl["cube_size"])
+    co = oracle.corner_offsets(wl["cube_size"])
+    Hf, Wf = feat.shape[-2:]
+    I = oracle.integral_image(feat[0].numpy())
+    box, area, vis = oracle.box_params(calibs[0].numpy(), grid.numpy(), zl, co, wl["args"].data, wl["args"].image_size, Hf, Wf)
+    vox = _to_layer_major(oracle.gather(I, box, area, vis), 256, nl)[begin:begin + count]
+    assert_bitwise("tap-cache vox", cached.cpu().numpy()[0], vox, zero_sign_free=True)
+
+
+def test_tap_cache_kernel_all_masked_and_tiny_inputs():
+    from vfa_amd import ops
+    dev = _dev()
+    feat = torch.rand(1, 256, 6, 8, device=dev)
+    integral = ops.integral_image(feat)
+    zl = torch.tensor([0., 30.], device=dev)
+    co = torch.zeros(8, 3, device=dev)
+    co[:, 0] = torch.tensor([-5., 5, 5, -5, -5, 5, 5, -5]); co[:, 1] = torch.tensor([-5., -5, 5, 5, -5, -5, 5, 5])
+    co[4:, 2] = 30.0
+    for n_cells in (1, 3, 8, 9):
+        grid = torch.rand(n_cells, 3, device=dev) * 50
+        far = torch.tensor([[900., 0, 640, 1e9, 0, 900., 360, 1e9, 0, 0, 0, 1.]], device=dev)  # everything clamps: masked
+        near = torch.tensor([[40., 0, 32, 100., 0, 40., 24, 100., 0, 0, 0, 50.]], device=dev)
+        for calib in (far, near):
+            a = ops.project_gather(integral, calib, grid, zl, co, 0, (64, 48), kernel="direct")
+            b = ops.project_gather(integral, calib, grid, zl, co, 0, (64, 48), kernel="tap_cache")
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))

@@ -55,7 +55,14 @@ def main():
         for _ in range(3):
             ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, out=vox)
         t_int = timed(lambda: ops.integral_image(lat), a.rounds)
-        t_fused = timed(lambda: ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, out=vox), a.rounds)
+        ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, out=vox, kernel="direct")
+        t_fused = timed(lambda: ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, out=vox,
+                                                   kernel="direct"), a.rounds)
+        voxc = ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, kernel="tap_cache")
+        same_c = torch.equal(voxc.view(torch.int32), vox.view(torch.int32))
+        t_cache = timed(lambda: ops.project_gather(integral, calibs, grid_flat, zl, co, kind, img_wh, out=voxc,
+                                                   kernel="tap_cache"), a.rounds)
+        del voxc
         ws = torch.empty(_lib.lib().vfa_gather_workspace_bytes(n, nl, cells), dtype=torch.uint8, device=dev)
         vox2 = ops.project_gather_ws(integral, calibs, grid_flat, zl, co, kind, img_wh, workspace=ws)
         same = torch.equal(vox2.view(torch.int32), vox.view(torch.int32))
@@ -75,7 +82,7 @@ def main():
         bytes_i = 2 * n * C * Hf * Wf * 4
         print(f" scale {Hf}x{Wf}: visible {visfrac:.2f} | integral {t_int[0]:.1f} us ({bytes_i / t_int[0] / 1e3:.0f} GB/s alg) | "
               f"project_gather med {t_fused[0]:.1f} min {t_fused[1]:.1f} us = {nbox / t_fused[0] / 1e3:.2f} Gbox/s, "
-              f"{bytes_g / t_fused[0] / 1e3:.0f} GB/s alg | ws-form med {t_ws[0]:.1f} min {t_ws[1]:.1f} us bitwise_same={same} | FUSED collapse med {t_fc[0]:.1f} us ({gflop / t_fc[0] * 1e3:.1f} TF) vs gather+GEMM {t_fused[0] + t_mm[0]:.1f} us (GEMM {t_mm[0]:.1f} us, {gflop / t_mm[0] * 1e3:.1f} TF) | gather(unfused) {t_unf[0]:.1f} us | box_params {t_box[0]:.1f} us")
+              f"{bytes_g / t_fused[0] / 1e3:.0f} GB/s alg | TAP-CACHE med {t_cache[0]:.1f} min {t_cache[1]:.1f} us = {bytes_g / t_cache[0] / 1e3:.0f} GB/s alg bitwise_same={same_c} | ws-form med {t_ws[0]:.1f} min {t_ws[1]:.1f} us bitwise_same={same} | FUSED collapse med {t_fc[0]:.1f} us ({gflop / t_fc[0] * 1e3:.1f} TF) vs gather+GEMM {t_fused[0] + t_mm[0]:.1f} us (GEMM {t_mm[0]:.1f} us, {gflop / t_mm[0] * 1e3:.1f} TF) | gather(unfused) {t_unf[0]:.1f} us | box_params {t_box[0]:.1f} us")
 
 
 if __name__ == "__main__":

@@ -604,6 +604,236 @@ __global__ __launch_bounds__(256, 4) void gather_kernel(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Projection + box pooling through an LDS tap cache (C = 256, layer-major output).
+// The direct kernel above is bound by the vector-L1 / texture-address path: every 1 KiB tap load costs a CU ~20 TA
+// cycles and a box issues 5-9 of them, although neighbouring boxes share most taps (distinct taps per box: 3.0 / 1.4 /
+// 0.65 at stride 8 / 16 / 32 on the bench workload).  Here ONE WAVE owns 8 consecutive boxes of a view:
+//   1. lane (box, corner) projects one cube corner; an 8-lane xor-shuffle min/max gives the box; lane 0 of each box
+//      stages the BoxRec in LDS;
+//   2. the 8 x 16 tap keys are inserted into a 64-entry LDS hash set (ds_cmpst), giving each DISTINCT tap a slot id;
+//   3. per 64-channel quarter: every distinct tap is loaded from memory once (16 lanes x float4 = 256 B, four taps per
+//      load instruction) into its LDS slot, then 16-lane groups -- four boxes per wave instruction -- read their 16
+//      taps with ds_read_b128 (bank = channel quad, conflict-free across the instruction's lane groups), run the
+//      reference's FMA chains and store 256 B per box.
+// Everything is private to the wave (its own ~10 KiB of LDS, workgroup = 64 threads), so no workgroup barriers.
+// A tile with more distinct taps than slots falls back to the direct per-box path.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCacheBoxes = 8;
+constexpr int kCacheSlots = 32;
+constexpr int kCacheHash = 64;
+constexpr unsigned kEmptyKey = 0xffffffffu;
+constexpr int kCacheQuads = 16;                      // float4 lanes per box: 16 -> 64 channels per pass, 4 boxes per instruction
+                                                     // (8 -> 32 channels, 8 boxes: smaller LDS, 5 waves/SIMD, measured no faster)
+constexpr int kCacheGroups = kWave / kCacheQuads;    // boxes pooled per wave instruction
+constexpr int kCachePasses = 256 / (4 * kCacheQuads);
+
+struct CachedLds {
+    BoxRec recs[kCacheBoxes];
+    unsigned tab[kCacheHash];                   // tap key (byte offset inside the view's padded image) or kEmptyKey
+    unsigned slot_key[kCacheSlots];             // dense slot id -> tap key
+    unsigned char ids[kCacheHash];              // hash entry -> dense slot id
+    unsigned char box_slots[kCacheBoxes][16];   // [box][tap = row index * 4 + col index] -> slot id
+    float4 slot_data[kCacheSlots][kCacheQuads]; // the current channel slice (kCacheQuads x 4 channels) of every distinct tap
+};
+
+__global__ __launch_bounds__(kWave) void gather_cached_kernel(const float *__restrict__ integral, BoxGeom g, GatherDims d,
+                                                             float *__restrict__ vox)
+{
+    __shared__ CachedLds L;
+    const int lane = threadIdx.x;
+    // A tile is 8 consecutive CELLS of one (view, layer): neighbouring cells of a layer are the boxes that share taps.
+    // Tiles are numbered (view, cell block, layer) so that tiles running side by side touch the same image columns.
+    const long long boxes_per_view = (long long)d.cell_count * d.nl;
+    const long long blocks_per_view = (d.cell_count + kCacheBoxes - 1) / kCacheBoxes;
+    const long long tiles_per_view = blocks_per_view * d.nl;
+    const long long tile = xcd_contiguous(blockIdx.x, d.per_xcd);
+    if (tile >= tiles_per_view * (d.n_boxes / boxes_per_view)) return;
+    const int view = (int)(tile / tiles_per_view);
+    const long long tv = tile % tiles_per_view;
+    const int layer = (int)(tv % d.nl);
+    const int cell0 = (int)(tv / d.nl) * kCacheBoxes; // first cell (local to the processed range) of the tile
+    const int nb = min(kCacheBoxes, d.cell_count - cell0);
+    const size_t img_stride = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C * sizeof(float);
+    const char *img = reinterpret_cast<const char *>(integral) + (size_t)view * img_stride;
+    // layer-major output: box (cell, layer) owns 1 KiB at ((view * cells + cell) * nl + layer) * 1024
+    const size_t box_pitch = (size_t)d.nl * 1024;
+    char *out_tile = reinterpret_cast<char *>(vox) + (((size_t)view * d.cell_count + cell0) * d.nl + layer) * 1024;
+
+    // ---- 1. box parameters: lane = (box, corner)
+    const int b = lane >> 3, corner = lane & 7;
+    const bool valid = b < nb;
+    float l, t, r, bt, area = 0.0f;
+    bool vis = false;
+    {
+        const int cell = d.cell_begin + cell0 + (valid ? b : 0);
+        const float *P = g.calibs + (size_t)view * 12;
+        const float gx = g.grid[cell * 3 + 0] + 0.0f; // + the int64 zeros of z_corners (vfa_op.py:52, :64)
+        const float gy = g.grid[cell * 3 + 1] + 0.0f;
+        const float gz = g.grid[cell * 3 + 2] + g.z_layers[layer];
+        float nu, nv;
+        project_corner(g, P, gx, gy, gz, corner, nu, nv);
+        l = r = nu; t = bt = nv;
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { // exact, order-insensitive (NaN propagates either way)
+            l = min_t(l, __shfl_xor(l, m));
+            r = max_t(r, __shfl_xor(r, m));
+            t = min_t(t, __shfl_xor(t, m));
+            bt = max_t(bt, __shfl_xor(bt, m));
+        }
+        area = box_area(l, t, r, bt, d.Hf, d.Wf);
+        vis = valid && box_visible(area, d.Hf, d.Wf);
+    }
+    unsigned key_x, key_y;
+    BoxRec rec;
+    fill_record(rec, view, l, t, r, bt, area, vis, d, key_x, key_y);
+    if (!valid) { rec.h.flags = 0; rec.h.masked = 0.0f; }
+    if (__ballot(vis) == 0ull) { // nothing visible in the tile: eight masked rows, one 1 KiB store each
+        for (int j = 0; j < nb; ++j) {
+            const float z = __shfl(rec.h.masked, 8 * j);
+            *reinterpret_cast<float4 *>(out_tile + (size_t)j * box_pitch + lane * 16) = make_float4(z, z, z, z);
+        }
+        return;
+    }
+    if (corner == 0) L.recs[b] = rec;
+    L.tab[lane] = kEmptyKey;
+    __syncthreads();
+
+    // ---- 2. distinct taps of the tile: lane (box, corner) owns taps 2*corner and 2*corner + 1 of its box
+    int myh[2] = {0, 0};
+    bool overflow = false;
+    if (vis) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // tap = 2 * corner + i: row index corner >> 1, column index 2 * (corner & 1) + i (selects, not indexing:
+            // a runtime index into the record would put it in scratch)
+            const int ri = corner >> 1, ci = 2 * (corner & 1) + i;
+            const unsigned rsel = ri == 0 ? rec.h.row[0] : (ri == 1 ? rec.h.row[1] : (ri == 2 ? rec.h.row[2] : rec.h.row[3]));
+            const unsigned csel = ci == 0 ? rec.h.col[0] : (ci == 1 ? rec.h.col[1] : (ci == 2 ? rec.h.col[2] : rec.h.col[3]));
+            const unsigned key = rsel + csel;
+            unsigned h = ((key >> 10) * 2654435761u) >> 26;
+            int probes = 0;
+            for (; probes < kCacheHash; ++probes) { // bounded: a full table means "too many distinct taps"
+                const unsigned old = atomicCAS(&L.tab[h], kEmptyKey, key);
+                if (old == kEmptyKey || old == key) break;
+                h = (h + 1) & (kCacheHash - 1);
+            }
+            if (probes == kCacheHash) overflow = true;
+            myh[i] = (int)h;
+        }
+    }
+    __syncthreads();
+    const unsigned mine = L.tab[lane];
+    const bool occ = mine != kEmptyKey;
+    const unsigned long long occ_mask = __ballot(occ);
+    const int n_slots = __popcll(occ_mask);
+    const int my_id = __popcll(occ_mask & ((1ull << lane) - 1ull));
+    const bool cached = n_slots <= kCacheSlots && __ballot(overflow) == 0ull;
+    if (occ && cached) {
+        L.ids[lane] = (unsigned char)my_id;
+        L.slot_key[my_id] = mine;
+    }
+    __syncthreads();
+    if (vis && cached) {
+        L.box_slots[b][2 * corner + 0] = L.ids[myh[0]];
+        L.box_slots[b][2 * corner + 1] = L.ids[myh[1]];
+    }
+    __syncthreads();
+
+    if (cached) {
+        // ---- 3. per 64-channel quarter: fill the slots, pool four boxes per wave instruction.
+        // The tap addresses of a lane's two boxes are quarter-invariant and stay in registers; the loads of quarter
+        // q+1 are issued (into registers) before quarter q is pooled, so their latency hides behind the arithmetic.
+        // LDS operations of one wave execute in order, so phases need no waits -- only compiler fences.
+        const int grp = lane / kCacheQuads, cq = lane % kCacheQuads;
+        constexpr int kIters = (kCacheBoxes + kCacheGroups - 1) / kCacheGroups;
+        constexpr int kLoads = kCacheSlots / kCacheGroups; // slots per lane group
+        constexpr int kSliceBytes = kCacheQuads * 16;
+        unsigned taps[kIters][16]; // slot index of each of the 16 taps (row index * 4 + column index)
+        bool bvis[kIters], bval[kIters];
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int bb = it * kCacheGroups + grp;
+            bval[it] = bb < nb;
+            const BoxRec &rc = L.recs[bval[it] ? bb : 0];
+            bvis[it] = bval[it] && (rc.h.flags & 1);
+            const uint4 sl4 = *reinterpret_cast<const uint4 *>(L.box_slots[bval[it] ? bb : 0]);
+            const unsigned sw[4] = {sl4.x, sl4.y, sl4.z, sl4.w}; // sw[row index] = the 4 column slots of that row
+#pragma unroll
+            for (int tp = 0; tp < 16; ++tp)
+                taps[it][tp] = bvis[it] ? ((sw[tp >> 2] >> (8 * (tp & 3))) & 0xffu) : 0u;
+        }
+        unsigned src[kLoads]; // byte offset of this lane's piece of slot grp + kCacheGroups k, slice 0
+        float4 pre[kLoads];
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int i = grp + kCacheGroups * k;
+            src[k] = L.slot_key[i < n_slots ? i : 0] + cq * 16;
+            pre[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n_slots) pre[k] = *reinterpret_cast<const float4 *>(img + src[k]);
+        }
+        for (int q = 0; q < kCachePasses; ++q) {
+#pragma unroll
+            for (int k = 0; k < kLoads; ++k)
+                if (grp + kCacheGroups * k < n_slots) L.slot_data[grp + kCacheGroups * k][cq] = pre[k];
+            if (q + 1 < kCachePasses) {
+#pragma unroll
+                for (int k = 0; k < kLoads; ++k)
+                    if (grp + kCacheGroups * k < n_slots)
+                        pre[k] = *reinterpret_cast<const float4 *>(img + (src[k] + (q + 1) * kSliceBytes));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < kIters; ++it) {
+                if (!bval[it]) continue;
+                const int bb = it * kCacheGroups + grp;
+                const BoxRec &rc = L.recs[bb];
+                float4 res;
+                if (bvis[it]) {
+                    const BoxWeights w = rc.w;
+                    auto T = [&](int tp) { return L.slot_data[taps[it][tp]][cq]; };
+                    const float4 lt = bilinear_w<4>(T(0), T(1), T(4), T(5), w.lt);
+                    const float4 rb = bilinear_w<4>(T(10), T(11), T(14), T(15), w.rb);
+                    const float4 rt = bilinear_w<4>(T(2), T(3), T(6), T(7), w.rt);
+                    const float4 lb = bilinear_w<4>(T(8), T(9), T(12), T(13), w.lb);
+                    res = vbox_mean<4>(lt, rb, rt, lb, w.area, w.rcp);
+                } else {
+                    const float z = rc.h.masked;
+                    res = make_float4(z, z, z, z);
+                }
+                *reinterpret_cast<float4 *>(out_tile + (size_t)bb * box_pitch + q * kSliceBytes + cq * 16) = res;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        return;
+    }
+
+    // ---- fallback: more distinct taps than slots -> direct per-box path (lanes = 256 channels)
+    const unsigned lane_off = (unsigned)lane * 16u;
+    for (int j = 0; j < nb; ++j) {
+        const BoxRec &rc = L.recs[j];
+        const int flags = uniform_i(rc.h.flags);
+        float4 res;
+        if (flags & 1) {
+            unsigned col[4], row[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { col[k] = rc.h.col[k]; row[k] = rc.h.row[k]; }
+            const BoxWeights w = rc.w;
+            float4 P[4][4];
+            load_patch<4, 2, 2>(P, img, lane_off, row, col); // all 16 taps (rare path: no dedupe)
+            res = pool_patch<4, 2, 2>(P, w);
+        } else {
+            const float z = rc.h.masked;
+            res = make_float4(z, z, z, z);
+        }
+        *reinterpret_cast<float4 *>(out_tile + (size_t)j * box_pitch + lane_off) = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Two-kernel form of the projection + box pooling: box records through HBM, scalar-loaded by the pooling waves.
 // ------------------------------------------------------------------------------------------------
 // records kernel: one thread per box, 256 boxes per workgroup; writes the same BoxRec the tiled kernel stages in LDS
@@ -1275,6 +1505,9 @@ __global__ __launch_bounds__(256) void relu_mask_backward_kernel(const float *__
 
 inline int launch_status() { return (int)hipGetLastError(); }
 
+// which pooling kernel vfa_project_gather_f32 uses for C = 256 (see vfa_set_option)
+int g_use_cached = 1;
+
 inline unsigned elementwise_blocks(size_t n_items)
 {
     const size_t want = (n_items + 255) / 256;
@@ -1287,6 +1520,8 @@ int launch_gather(const float *integral, const float *box, const float *area, co
                   float *vox, int n_views, int C, int Hf, int Wf, int nl, int n_cells, int cell_begin, int cell_count,
                   int vox_layout, hipStream_t s)
 {
+    const int kernel_choice = vox_layout & (VFA_VOX_KERNEL_DIRECT | VFA_VOX_KERNEL_TAP_CACHE);
+    vox_layout &= ~(VFA_VOX_KERNEL_DIRECT | VFA_VOX_KERNEL_TAP_CACHE);
     if (n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0 || nl <= 0 || n_cells < 0 || cell_begin < 0 || cell_count < 0 ||
         cell_begin + cell_count > n_cells || (vox_layout != VFA_VOX_REFERENCE && vox_layout != VFA_VOX_LAYER_MAJOR))
         return VFA_ERR_BAD_ARGUMENT;
@@ -1295,6 +1530,17 @@ int launch_gather(const float *integral, const float *box, const float *area, co
     d.cell_count = cell_count; d.vox_layout = vox_layout;
     d.n_boxes = (long long)n_views * cell_count * nl;
     if (d.n_boxes == 0) return 0;
+    // default choice: the tap cache pays when neighbouring cells share taps and few boxes are masked; measured faster on
+    // single-layer grids, about equal on the multi-layer dataset configs -> cached for nl == 1 unless told otherwise
+    const bool want_cached = kernel_choice == VFA_VOX_KERNEL_TAP_CACHE ? true
+                             : kernel_choice == VFA_VOX_KERNEL_DIRECT  ? false
+                                                                       : (g_use_cached && nl == 1);
+    if (FUSED && C == 256 && vox_layout == VFA_VOX_LAYER_MAJOR && want_cached) {
+        const long long tiles = (long long)n_views * nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes);
+        d.per_xcd = (tiles + 7) / 8;
+        hipLaunchKernelGGL(gather_cached_kernel, dim3((unsigned)(d.per_xcd * 8)), dim3(kWave), 0, s, integral, g, d, vox);
+        return launch_status();
+    }
     const long long blocks = (d.n_boxes + kTileBoxes - 1) / kTileBoxes;
     d.per_xcd = (blocks + 7) / 8;
     const dim3 grid((unsigned)(d.per_xcd * 8));
@@ -1343,6 +1589,13 @@ int launch_gather_ws(const float *integral, const float *box, const float *area,
 extern "C" {
 
 int vfa_abi_version(void) { return VFA_ABI_VERSION; }
+
+int vfa_set_option(int option, int value)
+{
+    if (option == VFA_OPT_TAP_CACHE) { g_use_cached = value != 0; return 0; }
+    return VFA_ERR_BAD_ARGUMENT;
+}
+
 
 int vfa_integral_image_f32(const float *feature, float *integral, int n_views, int C, int Hf, int Wf, void *stream)
 {

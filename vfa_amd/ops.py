@@ -55,6 +55,11 @@ def _launch(name, *args, tag=None):
     kt.records.append((name, e0, e1, tag))
 
 
+def set_tap_cache(enabled):
+    """Choose the pooling kernel of ``project_gather`` for C = 256: LDS tap cache (default) or the direct kernel."""
+    _lib.call("vfa_set_option", 1, 1 if enabled else 0)
+
+
 def integral_image(features):
     """(n,C,Hf,Wf) -> (n,Hf+2,Wf+2,C) zero-bordered channels-last integral images (reference vfa_op.py:172-173)."""
     _lib.require_device(features)
@@ -96,8 +101,12 @@ def gather(integral, box, area, visible, cell_begin=0, cell_count=None, layout=_
 
 
 def project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, crange=(-1, 0.95),
-                   cell_begin=0, cell_count=None, layout=_lib.VOX_LAYER_MAJOR, out=None):
-    """Fused projection + box pooling -> vox (n, cell_count, nl*C) (reference vfa_op.py:64-120)."""
+                   cell_begin=0, cell_count=None, layout=_lib.VOX_LAYER_MAJOR, out=None, kernel=None):
+    """Fused projection + box pooling -> vox (n, cell_count, nl*C) (reference vfa_op.py:64-120).
+
+    ``kernel``: None = library default, "direct" or "tap_cache" (identical results; see include/vfa_hip.h)."""
+    if kernel is not None:
+        layout = layout | {"direct": _lib.VOX_KERNEL_DIRECT, "tap_cache": _lib.VOX_KERNEL_TAP_CACHE}[kernel]
     _lib.require_device(integral, calibs, grid_flat, z_layers, corner_off)
     n, Hp, Wp, C = integral.shape
     n_cells, nl = grid_flat.shape[0], z_layers.numel()
