@@ -175,16 +175,19 @@ def main():
     # HBM traffic of that kernel from the PMC counters: collected by separate `rocprofv3 --pmc FETCH_SIZE` /
     # `--pmc WRITE_SIZE` passes over this same command (tools/pmc_to_traffic.py, summary committed under profiles/)
     traffic = None
+    chosen = sorted(set(ops._gather_choice.values())) or ["default"]
+    kname = {"tap_cache": "gather_cached_kernel", "direct": "gather_kernel<4, true>"}
     tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if a.workload == "multiviewc_200x200x1" and os.path.exists(tpath):
+    if a.workload == "multiviewc_200x200x1" and os.path.exists(tpath) and len(chosen) == 1 and chosen[0] in kname:
         for name, rec in json.load(open(tpath))["kernels"].items():
-            if "gather_kernel<4, true>" in name:
+            if kname[chosen[0]] in name:
                 traffic = rec["hbm_bytes_per_dispatch"]
     roofline = None
     if g["launches"]:
         avg_ms = g["ms"] / g["launches"]
         achieved = alg_bytes / g["launches"] / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "gather_kernel<4,true> (vfa_project_gather_f32)", "achieved": achieved,
+        roofline = {"bound": "hbm", "kernel": "vfa_project_gather_f32: " + "/".join(kname.get(c, c) for c in chosen) +
+                    " (picked per shape on first use)", "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes / g["launches"],
                     "launches": g["launches"]}

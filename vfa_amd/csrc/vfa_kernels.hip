@@ -712,6 +712,7 @@ __global__ __launch_bounds__(kWave) void gather_cached_kernel(const float *__res
             const unsigned key = rsel + csel;
             unsigned h = ((key >> 10) * 2654435761u) >> 26;
             int probes = 0;
+#pragma unroll 1
             for (; probes < kCacheHash; ++probes) { // bounded: a full table means "too many distinct taps"
                 const unsigned old = atomicCAS(&L.tab[h], kEmptyKey, key);
                 if (old == kEmptyKey || old == key) break;

@@ -2,6 +2,8 @@
 
 Tensors are device tensors; every call is asynchronous on the current torch HIP stream.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -100,12 +102,54 @@ def gather(integral, box, area, visible, cell_begin=0, cell_count=None, layout=_
     return vox
 
 
+GATHER_KERNEL = os.environ.get("VFA_AMD_GATHER", "auto")  # auto | default | direct | tap_cache
+_gather_choice = {}
+
+
+def _pick_gather_kernel(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, crange, cell_begin,
+                        cell_count):
+    """Time the two pooling kernels on this problem (HIP events, one synchronise) and return the faster one's name."""
+    n_cells = grid_flat.shape[0]
+    count = n_cells - cell_begin if cell_count is None else cell_count
+    sample = min(count, max(4096, (64 << 20) // max(1, integral.shape[0] * z_layers.numel() * 1024)))  # <= 64 MiB of vox
+    scratch = torch.empty((integral.shape[0], sample, z_layers.numel() * integral.shape[3]), dtype=torch.float32,
+                          device=integral.device)
+    best, best_ms = "direct", None
+    for name in ("direct", "tap_cache"):
+        args = (integral, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, crange, cell_begin, sample)
+        project_gather(*args, out=scratch, kernel=name)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            project_gather(*args, out=scratch, kernel=name)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if best_ms is None or ms < best_ms:
+            best, best_ms = name, ms
+    return best
+
+
 def project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, crange=(-1, 0.95),
                    cell_begin=0, cell_count=None, layout=_lib.VOX_LAYER_MAJOR, out=None, kernel=None):
     """Fused projection + box pooling -> vox (n, cell_count, nl*C) (reference vfa_op.py:64-120).
 
-    ``kernel``: None = library default, "direct" or "tap_cache" (identical results; see include/vfa_hip.h)."""
-    if kernel is not None:
+    ``kernel``: "direct", "tap_cache" (identical results; see include/vfa_hip.h), "default" (the library's static
+    rule) or None = ``GATHER_KERNEL`` (env VFA_AMD_GATHER, default "auto": both kernels are timed once per problem shape
+    on first use -- which one wins depends on how many taps neighbouring boxes share and how many are masked)."""
+    n, Hp, Wp, C = integral.shape
+    if kernel is None:
+        kernel = GATHER_KERNEL
+    if kernel == "auto":
+        kernel = "default"
+        if C == 256 and (layout & 0xff) == _lib.VOX_LAYER_MAJOR and not torch.cuda.is_current_stream_capturing():
+            cells = grid_flat.shape[0] - cell_begin if cell_count is None else cell_count
+            key = (integral.device.index, n, Hp, Wp, z_layers.numel(), cells, int(conv_kind), tuple(image_wh), tuple(crange))
+            kernel = _gather_choice.get(key)
+            if kernel is None:
+                kernel = _gather_choice[key] = _pick_gather_kernel(integral, calibs, grid_flat, z_layers, corner_off,
+                                                                   conv_kind, image_wh, crange, cell_begin, cell_count)
+    if kernel != "default":
         layout = layout | {"direct": _lib.VOX_KERNEL_DIRECT, "tap_cache": _lib.VOX_KERNEL_TAP_CACHE}[kernel]
     _lib.require_device(integral, calibs, grid_flat, z_layers, corner_off)
     n, Hp, Wp, C = integral.shape
