@@ -111,7 +111,8 @@ def _pick_gather_kernel(integral, calibs, grid_flat, z_layers, corner_off, conv_
     """Time the two pooling kernels on this problem (HIP events, one synchronise) and return the faster one's name."""
     n_cells = grid_flat.shape[0]
     count = n_cells - cell_begin if cell_count is None else cell_count
-    sample = min(count, max(4096, (64 << 20) // max(1, integral.shape[0] * z_layers.numel() * 1024)))  # <= 64 MiB of vox
+    # the whole problem when its vox fits 1 GiB (every launch of a shape then has one size), else a leading sample of cells
+    sample = min(count, max(4096, (1 << 30) // max(1, integral.shape[0] * z_layers.numel() * integral.shape[3] * 4)))
     scratch = torch.empty((integral.shape[0], sample, z_layers.numel() * integral.shape[3]), dtype=torch.float32,
                           device=integral.device)
     best, best_ms = "direct", None
