@@ -98,6 +98,59 @@ def test_aggregate_gradients_match_per_camera_loop():
         torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4 * b.abs().max().item())
 
 
+@pytest.mark.parametrize("workload,n_cam,cells", [("multiviewc_156x156x5", 2, (0, None)),
+                                                   ("multiviewc_200x200x1", 3, (0, None)),
+                                                   ("wildtrack_120x360x8", 2, (1003, 20011)),
+                                                   ("multiviewx_160x250x8", 2, (77, 13))])
+def test_lds_scatter_matches_atomic_scatter_and_is_the_adjoint(workload, n_cam, cells):
+    """C = 256 takes the LDS-privatised backward (`gather_backward_cached_kernel`).  Box pooling is linear in the
+    integral image, so <pool(I), G> == <I, pool^T(G)> (a size-independent property), and the kernel agrees with the
+    run-combined atomic scatter."""
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import WORKLOADS, make_workload
+    import vfa_amd
+    if workload not in WORKLOADS:
+        pytest.skip(f"{workload} not defined")
+    dev = torch.device("cuda:0")
+    wl = make_workload(workload, channels=256, seed=5, n_cam=n_cam)
+    mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+    zl, co = mod._kernel_geometry(dev)
+    calibs = wl["calibs"].reshape(n_cam, 12).to(dev)
+    grid = wl["grid"].reshape(-1, 3).to(dev)
+    kind, size = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
+    begin, count = cells
+    count = grid.shape[0] - begin if count is None else count
+    feat = torch.cat([wl["features"][c][1] for c in range(n_cam)]).to(dev)
+    integral = ops.integral_image(feat)
+    vox = ops.project_gather(integral, calibs, grid, zl, co, kind, size, cell_begin=begin, cell_count=count)
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    gvox = torch.randn(vox.shape, generator=gen).to(dev)
+    _, _, visible = ops.box_params(calibs, grid, zl, co, kind, size, feat.shape[-2:])
+    live = visible[:, :, begin:begin + count].permute(0, 2, 1).bool()  # (n, cells, nl)
+    live = live[..., None].expand(-1, -1, -1, 256).reshape(vox.shape)
+    assert live.any()
+    gvox = torch.where(live, gvox, torch.full_like(gvox, 1e30))  # masked voxels pass no gradient, whatever arrives
+    grads = {}
+    try:
+        for name, on in (("lds", True), ("atomics", False)):
+            ops.set_tap_cache(on)
+            grads[name] = ops.project_gather_backward(gvox, tuple(integral.shape), calibs, grid, zl, co, kind, size,
+                                                      cell_begin=begin, cell_count=count)
+            twice = ops.project_gather_backward(gvox, tuple(integral.shape), calibs, grid, zl, co, kind, size,
+                                                cell_begin=begin, cell_count=count, out=grads[name].clone(),
+                                                accumulate=True)
+            torch.testing.assert_close(twice, 2 * grads[name], rtol=1e-4, atol=1e-5 * grads[name].abs().max().item())
+    finally:
+        ops.set_tap_cache(True)
+    scale = grads["atomics"].abs().max().item()
+    assert scale > 0 and torch.isfinite(grads["lds"]).all()
+    torch.testing.assert_close(grads["lds"], grads["atomics"], rtol=1e-4, atol=2e-5 * scale)
+    lhs = (vox.double() * torch.where(live, gvox, torch.zeros_like(gvox)).double()).sum().item()
+    rhs = (integral.double() * grads["lds"].double()).sum().item()
+    norm = (vox.double().abs() * torch.where(live, gvox, torch.zeros_like(gvox)).double().abs()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * norm, (lhs, rhs, norm)
+
+
 def test_integral_backward_is_reverse_double_cumsum():
     from vfa_amd import ops
     dev = torch.device("cuda:0")

@@ -363,7 +363,9 @@ def test_vfanet_forward_interface():
     assert tuple(out["dim_offset"].shape) == (1, L, W, 3)
     assert tuple(out["rotation"].shape) == (1, L, W, 36)
     assert ortho.abs().max() > 0
-    torch.testing.assert_close(ortho, acc, rtol=RTOL, atol=ATOL_REL * acc.abs().max().item())
+    # both sides are sums of nine library GEMM results of different shapes (batched vs per camera), each rounded in
+    # its own order: twice the single-GEMM absolute tolerance
+    torch.testing.assert_close(ortho, acc, rtol=RTOL, atol=2 * ATOL_REL * acc.abs().max().item())
 
 
 @pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 2, (70, 93)), ("multiviewc_156x156x5", 2, (40, 50)),

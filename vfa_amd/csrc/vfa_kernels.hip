@@ -834,6 +834,173 @@ __global__ __launch_bounds__(kWave) void gather_cached_kernel(const float *__res
     }
 }
 
+// Backward twin of gather_cached_kernel: the same tiles, records and hash set.  d integral[tap] of a tile is
+//   sum_box coef[tap][box] * grad_vox[box],   coef = the signed bilinear weights / area of the box's taps that hit `tap`,
+// an (n_taps x 8) matrix built once per tile in LDS.  A lane owns channels lane + 64 q: it keeps the 8 x 4 gradients of
+// the tile in registers, forms each distinct tap's row with 8 fmas per channel and issues ONE 256-byte atomic row per
+// distinct tap and 64-channel slice -- 3-8x fewer global atomics than the per-box scatter (which runs at the chip's
+// ~1.3 TB/s atomic rate), no LDS traffic in the channel loop beyond two broadcast reads per tap.
+struct BackwardLds {
+    BoxRec recs[kCacheBoxes];                 // only read by the fallback
+    unsigned tab[kCacheHash];
+    unsigned slot_key[kCacheHash];            // every hash entry can be a tap: the fallback is for > 64 distinct taps
+    unsigned char ids[kCacheHash];
+    float coef[kCacheHash][kCacheBoxes];
+};
+
+__global__ __launch_bounds__(kWave) void gather_backward_cached_kernel(const float *__restrict__ grad_vox, BoxGeom g,
+                                                                      GatherDims d, float *__restrict__ grad_integral)
+{
+    __shared__ BackwardLds L;
+    const int lane = threadIdx.x;
+    // A tile is 8 consecutive CELLS of one (view, layer): neighbouring cells of a layer are the boxes that share taps.
+    // Tiles are numbered (view, cell block, layer) so that tiles running side by side touch the same image columns.
+    const long long boxes_per_view = (long long)d.cell_count * d.nl;
+    const long long blocks_per_view = (d.cell_count + kCacheBoxes - 1) / kCacheBoxes;
+    const long long tiles_per_view = blocks_per_view * d.nl;
+    const long long tile = xcd_contiguous(blockIdx.x, d.per_xcd);
+    if (tile >= tiles_per_view * (d.n_boxes / boxes_per_view)) return;
+    const int view = (int)(tile / tiles_per_view);
+    const long long tv = tile % tiles_per_view;
+    const int layer = (int)(tv % d.nl);
+    const int cell0 = (int)(tv / d.nl) * kCacheBoxes; // first cell (local to the processed range) of the tile
+    const int nb = min(kCacheBoxes, d.cell_count - cell0);
+    const size_t img_stride = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C * sizeof(float);
+    char *gimg = reinterpret_cast<char *>(grad_integral) + (size_t)view * img_stride;
+    // layer-major output: box (cell, layer) owns 1 KiB at ((view * cells + cell) * nl + layer) * 1024
+    const size_t box_pitch = (size_t)d.nl * 1024;
+    const char *gv_tile = reinterpret_cast<const char *>(grad_vox) + (((size_t)view * d.cell_count + cell0) * d.nl + layer) * 1024;
+
+    // ---- 1. box parameters: lane = (box, corner)
+    const int b = lane >> 3, corner = lane & 7;
+    const bool valid = b < nb;
+    float l, t, r, bt, area = 0.0f;
+    bool vis = false;
+    {
+        const int cell = d.cell_begin + cell0 + (valid ? b : 0);
+        const float *P = g.calibs + (size_t)view * 12;
+        const float gx = g.grid[cell * 3 + 0] + 0.0f; // + the int64 zeros of z_corners (vfa_op.py:52, :64)
+        const float gy = g.grid[cell * 3 + 1] + 0.0f;
+        const float gz = g.grid[cell * 3 + 2] + g.z_layers[layer];
+        float nu, nv;
+        project_corner(g, P, gx, gy, gz, corner, nu, nv);
+        l = r = nu; t = bt = nv;
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { // exact, order-insensitive (NaN propagates either way)
+            l = min_t(l, __shfl_xor(l, m));
+            r = max_t(r, __shfl_xor(r, m));
+            t = min_t(t, __shfl_xor(t, m));
+            bt = max_t(bt, __shfl_xor(bt, m));
+        }
+        area = box_area(l, t, r, bt, d.Hf, d.Wf);
+        vis = valid && box_visible(area, d.Hf, d.Wf);
+    }
+    unsigned key_x, key_y;
+    BoxRec rec;
+    fill_record(rec, view, l, t, r, bt, area, vis, d, key_x, key_y);
+    if (!valid) { rec.h.flags = 0; rec.h.masked = 0.0f; }
+    if (__ballot(vis) == 0ull) return; // masked voxels pass no gradient
+    if (corner == 0) L.recs[b] = rec;
+    L.tab[lane] = kEmptyKey;
+    __syncthreads();
+
+    // ---- 2. distinct taps of the tile: lane (box, corner) owns taps 2*corner and 2*corner + 1 of its box
+    int myh[2] = {0, 0};
+    bool overflow = false;
+    if (vis) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            // tap = 2 * corner + i: row index corner >> 1, column index 2 * (corner & 1) + i (selects, not indexing:
+            // a runtime index into the record would put it in scratch)
+            const int ri = corner >> 1, ci = 2 * (corner & 1) + i;
+            const unsigned rsel = ri == 0 ? rec.h.row[0] : (ri == 1 ? rec.h.row[1] : (ri == 2 ? rec.h.row[2] : rec.h.row[3]));
+            const unsigned csel = ci == 0 ? rec.h.col[0] : (ci == 1 ? rec.h.col[1] : (ci == 2 ? rec.h.col[2] : rec.h.col[3]));
+            const unsigned key = rsel + csel;
+            unsigned h = ((key >> 10) * 2654435761u) >> 26;
+            int probes = 0;
+#pragma unroll 1
+            for (; probes < kCacheHash; ++probes) { // bounded: a full table means "too many distinct taps"
+                const unsigned old = atomicCAS(&L.tab[h], kEmptyKey, key);
+                if (old == kEmptyKey || old == key) break;
+                h = (h + 1) & (kCacheHash - 1);
+            }
+            if (probes == kCacheHash) overflow = true;
+            myh[i] = (int)h;
+        }
+    }
+    __syncthreads();
+    const unsigned mine = L.tab[lane];
+    const bool occ = mine != kEmptyKey;
+    const unsigned long long occ_mask = __ballot(occ);
+    const int n_slots = __popcll(occ_mask);
+    const int my_id = __popcll(occ_mask & ((1ull << lane) - 1ull));
+    const bool cached = __ballot(overflow) == 0ull;
+    if (occ && cached) {
+        L.ids[lane] = (unsigned char)my_id;
+        L.slot_key[my_id] = mine;
+    }
+    __syncthreads();
+    // ---- 3. coefficient matrix: lane (box, corner) adds its two taps (ds_add_f32, twice per tile)
+#pragma unroll
+    for (int k = 0; k < kCacheBoxes; ++k) L.coef[lane][k] = 0.0f;
+    __syncthreads();
+    if (vis && cached) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ri = corner >> 1, ci = 2 * (corner & 1) + i, k = (ri & 1) * 2 + (ci & 1);
+            const bool top = ri < 2, left = ci < 2;
+            auto pick = [&](const float(&a)[4]) { return k == 0 ? a[0] : (k == 1 ? a[1] : (k == 2 ? a[2] : a[3])); };
+            const float wt = top ? (left ? pick(rec.w.lt) : pick(rec.w.rt)) : (left ? pick(rec.w.lb) : pick(rec.w.rb));
+            atomicAdd(&L.coef[L.ids[myh[i]]][b], (top == left ? wt : -wt) / rec.w.area);
+        }
+    }
+    __syncthreads();
+
+    if (cached) {
+        // ---- 4. lane = channel (+ 64 q): gradients of the tile in registers, one atomic row per distinct tap and slice
+        const unsigned long long vis_mask = __ballot(vis); // lane 8 b .. 8 b + 7 = box b
+        float gv[kCacheBoxes][kCachePasses];
+#pragma unroll
+        for (int bb = 0; bb < kCacheBoxes; ++bb) {
+            const bool on = (vis_mask >> (8 * bb)) & 1ull; // masked voxels pass no gradient (and may hold anything)
+#pragma unroll
+            for (int q = 0; q < kCachePasses; ++q)
+                gv[bb][q] = on ? *reinterpret_cast<const float *>(gv_tile + (size_t)bb * box_pitch + q * 256 + lane * 4) : 0.0f;
+        }
+        for (int i = 0; i < n_slots; ++i) {
+            const float4 c0 = *reinterpret_cast<const float4 *>(&L.coef[i][0]);
+            const float4 c1 = *reinterpret_cast<const float4 *>(&L.coef[i][4]);
+            float *dst = reinterpret_cast<float *>(gimg + L.slot_key[i]) + lane;
+#pragma unroll
+            for (int q = 0; q < kCachePasses; ++q) {
+                float a = c0.x * gv[0][q];
+                a = fmaf(c0.y, gv[1][q], a); a = fmaf(c0.z, gv[2][q], a); a = fmaf(c0.w, gv[3][q], a);
+                a = fmaf(c1.x, gv[4][q], a); a = fmaf(c1.y, gv[5][q], a); a = fmaf(c1.z, gv[6][q], a);
+                a = fmaf(c1.w, gv[7][q], a);
+                unsafeAtomicAdd(dst + q * kWave, a);
+            }
+        }
+        return;
+    }
+    // ---- fallback (more distinct taps than slots): per-box global atomics, lanes = 64 channels x 4 sweeps
+    for (int j = 0; j < nb; ++j) {
+        const BoxRec &rc = L.recs[j];
+        if (!(uniform_i(rc.h.flags) & 1)) continue;
+        const BoxWeights w = rc.w;
+        const float *gvox = reinterpret_cast<const float *>(gv_tile + (size_t)j * box_pitch);
+        for (int c = lane; c < d.C; c += kWave) {
+            const float gv = gvox[c] / w.area;
+            auto add = [&](int ry, int cx, float wt) {
+                unsafeAtomicAdd(reinterpret_cast<float *>(gimg + (rc.h.row[ry] + rc.h.col[cx])) + c, gv * wt);
+            };
+            add(0, 0, w.lt[0]); add(0, 1, w.lt[1]); add(1, 0, w.lt[2]); add(1, 1, w.lt[3]);
+            add(2, 2, w.rb[0]); add(2, 3, w.rb[1]); add(3, 2, w.rb[2]); add(3, 3, w.rb[3]);
+            add(0, 2, -w.rt[0]); add(0, 3, -w.rt[1]); add(1, 2, -w.rt[2]); add(1, 3, -w.rt[3]);
+            add(2, 0, -w.lb[0]); add(2, 1, -w.lb[1]); add(3, 0, -w.lb[2]); add(3, 1, -w.lb[3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Two-kernel form of the projection + box pooling: box records through HBM, scalar-loaded by the pooling waves.
 // ------------------------------------------------------------------------------------------------
@@ -1726,6 +1893,13 @@ int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, 
     d.cell_count = cell_count; d.vox_layout = VFA_VOX_LAYER_MAJOR;
     d.n_boxes = (long long)n_views * cell_count * nl;
     if (d.n_boxes == 0) return 0;
+    if (C == 256 && g_use_cached) {
+        const long long tiles = (long long)n_views * nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes);
+        d.per_xcd = (tiles + 7) / 8;
+        hipLaunchKernelGGL(gather_backward_cached_kernel, dim3((unsigned)(d.per_xcd * 8)), dim3(kWave), 0, s, grad_vox, g, d,
+                           grad_integral);
+        return launch_status();
+    }
     const long long blocks = (d.n_boxes + kTileBoxes - 1) / kTileBoxes;
     d.per_xcd = (blocks + 7) / 8;
     hipLaunchKernelGGL(gather_backward_kernel, dim3((unsigned)(d.per_xcd * 8)), dim3(256), 0, s, grad_vox, g, d,
