@@ -149,6 +149,18 @@ int vfa_scale_view_sum_f32(const float *lin8, const float *lin16, const float *l
                            const float *bias16, const float *bias32, float *ortho, int n_views, size_t M, int N,
                            int accumulate, void *stream);
 
+/* `collapse` + ReLU + view sum in one MFMA kernel, for K = N = 256 (single-layer grids, C = 256):
+ *   out[m, :] = (accumulate ? out[m, :] : 0) + sum_v relu(vox[v, m, :] . weight^T + bias)
+ *                                              replaces vfa_op.py:121-124 (Linear, ReLU) and vfanet.py:82 (view sum)
+ *   vox (n_views, M, K) layer-major; weight (N, K) = collapse.weight (layer-major columns; identical to the reference's
+ *   for one layer); bias (N) or NULL; out (M, N).
+ * fp32 in, fp32 out, fp32 accumulation; each fp32 product is formed from `terms` bf16 MFMA products of an exact
+ * hi/lo split of both operands (3 = default when 0 is passed, 4 adds lo*lo): error ~5e-6 of max|out| (the fp32 library
+ * GEMM: 1e-6), inside the 1e-4 / 1e-5 max tolerance of the path; not bitwise -- no GEMM order is.  Inf inputs give
+ * NaN (Inf - Inf in the split).  Returns VFA_ERR_UNSUPPORTED for other K, N: use a GEMM + the epilogues above. */
+int vfa_collapse_relu_sum_f32(const float *vox, const float *weight, const float *bias, float *out, int n_views, size_t M,
+                              int K, int N, int accumulate, int terms, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

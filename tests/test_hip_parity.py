@@ -583,3 +583,42 @@ def test_tap_cache_kernel_all_masked_and_tiny_inputs():
             a = ops.project_gather(integral, calib, grid, zl, co, 0, (64, 48), kernel="direct")
             b = ops.project_gather(integral, calib, grid, zl, co, 0, (64, 48), kernel="tap_cache")
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.parametrize("n_views,M,terms", [(1, 32, 3), (3, 1000, 3), (7, 4097, 4), (2, 31, 0), (5, 8192 + 17, 3)])
+def test_collapse_relu_sum_kernel_matches_float64(n_views, M, terms):
+    """`vfa_collapse_relu_sum_f32` (bf16-split MFMA + ReLU + view sum, K = N = 256) against the float64 product, at the
+    path's post-GEMM tolerance; also `accumulate`, a NULL bias, masked (all-zero) rows and a ragged last tile."""
+    from vfa_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(M + n_views)
+    vox = torch.rand(n_views, M, 256, generator=gen) * 3.0
+    vox[torch.rand(n_views, M, generator=gen) < 0.3] = 0.0
+    w = (torch.rand(256, 256, generator=gen) - 0.5) * 0.125
+    b = (torch.rand(256, generator=gen) - 0.5) * 0.125
+    want = torch.relu(vox.double() @ w.double().T + b.double()).sum(0)
+    got = ops.collapse_relu_sum(vox.to(dev), w.to(dev), b.to(dev), terms=terms)
+    scale = want.abs().max().item()
+    torch.testing.assert_close(got.cpu().double(), want, rtol=RTOL, atol=ATOL_REL * scale)
+    err = (got.cpu().double() - want).abs().max().item() / scale
+    assert err < 0.6e-5, err  # margin inside the tolerance (the fp32 library GEMM: ~1e-6)
+    # accumulate on top of an existing map, no bias
+    base = torch.randn(M, 256, generator=gen)
+    got2 = ops.collapse_relu_sum(vox.to(dev), w.to(dev), None, out=base.to(dev).clone(), accumulate=True, terms=terms)
+    want2 = base.double() + torch.relu(vox.double() @ w.double().T).sum(0)
+    torch.testing.assert_close(got2.cpu().double(), want2, rtol=RTOL, atol=ATOL_REL * want2.abs().max().item())
+
+
+def test_collapse_relu_sum_rejects_other_shapes_and_handles_empty():
+    from vfa_amd import _lib, ops
+    dev = _dev()
+    with pytest.raises(_lib.VFAHipError):
+        ops.collapse_relu_sum(torch.zeros(1, 8, 128, device=dev), torch.zeros(256, 128, device=dev), None)
+    out = ops.collapse_relu_sum(torch.zeros(0, 8, 256, device=dev), torch.zeros(256, 256, device=dev), None)
+    assert out.shape == (8, 256) and (out == 0).all()
+    out = ops.collapse_relu_sum(torch.zeros(2, 0, 256, device=dev), torch.zeros(256, 256, device=dev), None)
+    assert out.shape == (0, 256)
+    nan = torch.zeros(1, 40, 256, device=dev)
+    nan[0, 7, 3] = float("nan")
+    out = ops.collapse_relu_sum(nan, torch.ones(256, 256, device=dev), None)
+    assert torch.isnan(out[7]).all() and torch.isfinite(out[:7]).all() and torch.isfinite(out[8:]).all()

@@ -112,8 +112,15 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     """
     length, width = grid.shape[-3], grid.shape[-2]
     n = calibs.shape[0]
-    if n > 0:
-        work = ((vfa8, lat8), (vfa16, lat16), (vfa32, lat32))
+    work = ((vfa8, lat8), (vfa16, lat16), (vfa32, lat32))
+    if n > 0 and all(m.mfma_collapse_ok(lat) for m, lat in work):
+        # inference on single-layer grids: per scale, pooling then ONE MFMA kernel that forms collapse + bias + ReLU and
+        # sums the views into the map (sum over views per scale, then over scales: the reference's sums re-associated,
+        # inside the post-GEMM tolerance)
+        ortho = torch.empty((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
+        for i, (m, lat) in enumerate(work):
+            m.project_sum(lat, calibs, grid, crange, out=ortho, accumulate=i > 0)
+    elif n > 0:
         if N_STREAMS == 1 or not grid.is_cuda:
             lins = [m.project_views(lat, calibs, grid, crange) for m, lat in work]
         else:

@@ -268,3 +268,20 @@ def scale_view_sum(lin8, lin16, lin32, b8, b16, b32, out=None, accumulate=False)
     _launch("vfa_scale_view_sum_f32", _lib.ptr(lin8), _lib.ptr(lin16), _lib.ptr(lin32), _lib.ptr(b8), _lib.ptr(b16),
               _lib.ptr(b32), _lib.ptr(out), n, M, N, 1 if accumulate else 0, _lib.current_stream_handle())
     return out
+
+
+def collapse_relu_sum(vox, weight, bias, out=None, accumulate=False, terms=0):
+    """out (M,N) (+)= sum_v relu(vox[v] @ weight.T + bias) in one bf16-split MFMA kernel (K = N = 256 only; reference
+    vfa_op.py:121-124 + vfanet.py:82).  Raises ``VFAHipError`` (VFA_ERR_UNSUPPORTED) for other shapes."""
+    _lib.require_device(vox, weight, bias, out)
+    vox, weight = _f32c(vox), _f32c(weight)
+    bias = None if bias is None else _f32c(bias)
+    n, M, K = vox.shape
+    N = weight.shape[0]
+    assert weight.shape == (N, K), (tuple(weight.shape), K)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=vox.device)
+        accumulate = False
+    _launch("vfa_collapse_relu_sum_f32", _lib.ptr(vox), _lib.ptr(weight), _lib.ptr(bias),
+            _lib.ptr(out), n, M, K, N, 1 if accumulate else 0, int(terms), _lib.current_stream_handle())
+    return out

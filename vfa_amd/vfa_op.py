@@ -35,6 +35,11 @@ VOX_BYTES_LIMIT = int(os.environ.get("VFA_AMD_VOX_BYTES", str(8 << 30)))
 # the memory-lean path for very large grids.  On MI355X it runs at the speed of pooling kernel + library GEMM (fp32 MFMA
 # is clock/power-bound either way), so it is opt-in: VFA_AMD_FUSED=1.
 USE_FUSED = os.environ.get("VFA_AMD_FUSED", "0") == "1"
+# `collapse` on single-layer grids (K = N = 256) when no gradient is needed: "mfma_bf16" (default) = the hand-written
+# bf16-split MFMA kernel fused with bias, ReLU and the view sum (include/vfa_hip.h: vfa_collapse_relu_sum_f32);
+# "library" = fp32 library GEMM + epilogue kernels (the training path, and every other shape, always use this).
+COLLAPSE_KERNEL = os.environ.get("VFA_AMD_COLLAPSE", "mfma_bf16")
+COLLAPSE_TERMS = int(os.environ.get("VFA_AMD_COLLAPSE_TERMS", "3"))
 
 
 def _conv_kind(args):
@@ -177,6 +182,51 @@ class VFA(nn.Module):
             outs.append(torch.matmul(vox.view(n * count, nl * C), w_lm_t).view(n, count, -1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
+    def mfma_collapse_ok(self, features=None):
+        """True when the inference-only bf16-split MFMA kernel (`vfa_collapse_relu_sum_f32`) covers this module."""
+        if COLLAPSE_KERNEL == "library" or self.num_grid_layer * self.channel != 256 or self.collapse.out_features != 256:
+            return False
+        if not torch.is_grad_enabled():
+            return True
+        params = (self.collapse.weight, self.collapse.bias) + (() if features is None else (features,))
+        return not any(p is not None and p.requires_grad for p in params)
+
+    def project_sum(self, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False):
+        """Inference path of one scale, all cameras: ``out (L*W, C_out) (+)= sum_v relu(collapse(vox_v))``.
+
+        Integral images -> projection + pooling (HIP) -> `collapse` + bias + ReLU + view sum in ONE MFMA kernel
+        (``ops.collapse_relu_sum``): neither ``lin`` nor a separate epilogue pass exists.  Needs ``mfma_collapse_ok``.
+        """
+        _lib.require_device(features, calibs, grid)
+        conv_kind = _conv_kind(self.args)
+        img_h, img_w = (float(v) for v in self.args.image_size)
+        n, C, Hf, Wf = features.shape
+        if C != self.channel:
+            raise ValueError(f"feature has {C} channels, VFA was built for {self.channel}")
+        grid_flat = grid.reshape(-1, 3).to(dtype=torch.float32).contiguous()
+        calibs = calibs.reshape(n, 12).to(dtype=torch.float32).contiguous()
+        z_layers, corner_off = self._kernel_geometry(features.device)
+        n_cells, nl = grid_flat.shape[0], self.num_grid_layer
+        if out is None:
+            out = torch.empty((n_cells, self.collapse.out_features), dtype=torch.float32, device=features.device)
+            accumulate = False
+        if n_cells == 0:
+            return out
+        if n == 0:
+            return out if accumulate else out.zero_()
+        with torch.no_grad():
+            integral = ops.integral_image(features)
+            weight = self.layer_major_weight()
+            per_cell = n * nl * C * 4
+            chunk = max(1, min(n_cells, VOX_BYTES_LIMIT // max(per_cell, 1)))
+            for begin in range(0, n_cells, chunk):
+                count = min(chunk, n_cells - begin)
+                vox = ops.project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h),
+                                         (float(crange[0]), float(crange[1])), cell_begin=begin, cell_count=count)
+                ops.collapse_relu_sum(vox, weight, self.collapse.bias, out=out[begin:begin + count],
+                                      accumulate=accumulate, terms=COLLAPSE_TERMS)
+        return out
+
     # ------------------------------------------------------------------ reference interface
     def forward(self, feature, calib, grid, crange=(-1, 0.95), visualize=False):
         """feature (1,C,Hf,Wf), calib (3,4), grid (1,L,W,3) -> (1,C,L,W), ReLU'd (reference vfa_op.py:61-125)."""
@@ -185,8 +235,11 @@ class VFA(nn.Module):
         length, width = grid.shape[-3], grid.shape[-2]
         if visualize:
             self.visualize_cube(feature, calib, grid, crange)
-        lin = self.project_views(feature, calib.reshape(1, 3, 4), grid, crange)
-        ortho = _BiasReluSum.apply(lin, self.collapse.bias)
+        if self.mfma_collapse_ok(feature):
+            ortho = self.project_sum(feature, calib.reshape(1, 3, 4), grid, crange)
+        else:
+            lin = self.project_views(feature, calib.reshape(1, 3, 4), grid, crange)
+            ortho = _BiasReluSum.apply(lin, self.collapse.bias)
         return ortho.view(1, length, width, self.collapse.out_features).permute(0, 3, 1, 2)
 
     def extra_repr(self):
