@@ -52,11 +52,12 @@ __device__ __forceinline__ void split_bf16(float x, __bf16 &hi, __bf16 &lo)
 
 struct Frag { bf16x8 hi, lo; };
 
-template <int TERMS, bool DEPHASE>
+template <int TERMS>
 __global__ __launch_bounds__(kThreads) void collapse_relu_sum_kernel(const float *__restrict__ vox, const float *__restrict__ weight,
                                                                    const float *__restrict__ bias, float *__restrict__ out,
                                                                    int n_views, long long M, int accumulate)
 {
+
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *raw = smem;                       // [kRing][32 rows][1 KiB]
     unsigned char *planes = smem + kRing * kRaw;     // [buffer][hi / lo][32 rows][512 B]
@@ -98,18 +99,35 @@ __global__ __launch_bounds__(kThreads) void collapse_relu_sum_kernel(const float
         }
     };
     // split this thread's share of a landed raw slot into the bf16 planes of `buf`
+    constexpr int kPieces = kRows * kK / 4 / kThreads; // float4 per thread and item (4)
+    static_assert(kPieces == 4, "the raw reads below are written for 4 pieces");
     auto stage = [&](int slot, int buf) {
+        // The raw reads are inline asm: for a plain LDS load hipcc first drains every LDS-DMA in flight (vmcnt(0), it
+        // cannot tell the slots apart), which would cut the prefetch depth to nothing.  wait_oldest() + the barrier
+        // of the previous item already guarantee that this slot has landed.
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+        const unsigned src = lds0 + slot * kRaw + tid * 16;
+        const unsigned dst = lds0 + kRing * kRaw + buf * 2 * kPlane;
 #pragma unroll
-        for (int i = 0; i < kRows * kK / 4 / kThreads; ++i) {
-            const int idx = tid + kThreads * i, row = idx >> 6, c4 = idx & 63;
-            const float4 x4 = *reinterpret_cast<const float4 *>(raw + slot * kRaw + idx * 16);
-            const float x[4] = {x4.x, x4.y, x4.z, x4.w};
-            union { __bf16 b[4]; uint2 u; } hi, lo;
+        for (int half = 0; half < 2; ++half) {
+            float4 x4[2];
+            if (half == 0)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:8192\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(x4[0]), "=&v"(x4[1]) : "v"(src) : "memory");
+            else
+                asm volatile("ds_read_b128 %0, %2 offset:16384\n\tds_read_b128 %1, %2 offset:24576\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(x4[0]), "=&v"(x4[1]) : "v"(src) : "memory");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split_bf16(x[j], hi.b[j], lo.b[j]);
-            const int off = row * kRowBytes + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
-            *reinterpret_cast<uint2 *>(planes + (buf * 2 + 0) * kPlane + off) = hi.u;
-            *reinterpret_cast<uint2 *>(planes + (buf * 2 + 1) * kPlane + off) = lo.u;
+            for (int k = 0; k < 2; ++k) {
+                const int idx = tid + kThreads * (2 * half + k), row = idx >> 6, c4 = idx & 63;
+                const float x[4] = {x4[k].x, x4[k].y, x4[k].z, x4[k].w};
+                union { __bf16 b[4]; unsigned long long u; } hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split_bf16(x[j], hi.b[j], lo.b[j]);
+                const unsigned off = dst + row * kRowBytes + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
+                // hi plane at off, lo plane at off + kPlane (= 32 x 64 x 8 bytes)
+                asm volatile("ds_write2st64_b64 %0, %1, %2 offset1:32" : : "v"(off), "v"(hi.u), "v"(lo.u) : "memory");
+            }
         }
     };
     auto next_item = [&](long long &t, int &v) {
@@ -122,10 +140,10 @@ __global__ __launch_bounds__(kThreads) void collapse_relu_sum_kernel(const float
     };
 
     // Items are (tile, view) pairs in the order this workgroup meets them; item i lives in raw slot i % 3 and, split,
-    // in plane buffer i & 1.  Waves w and w + 4 share a SIMD: the "late" group (0-3) splits its share of the next
-    // item after its MFMAs, the "early" group (4-7) before them, so that one wave's VALU / LDS phase runs under the
-    // other's MFMAs.
-    const bool early = DEPHASE && wave >= 4;
+    // in plane buffer i & 1.  All waves run the same phase at the same time: the two waves of a SIMD hide each other's
+    // fragment-read latency in the MFMA phase.  Measured alternatives, none faster: shifting waves 4-7 half an item
+    // (their split under the others' MFMAs), reading the next chunk's fragments ahead, a quarter of the split behind
+    // every second chunk (102-118 us each against 109-115 us on the bench shape).
     long long tf = tile; // next item to fetch
     int vf = 0, slot_f = 0;
     int in_flight = 0;   // items whose LDS-DMA this wave has issued and not yet waited for
@@ -167,7 +185,6 @@ __global__ __launch_bounds__(kThreads) void collapse_relu_sum_kernel(const float
                 ++in_flight;
             }
             next_item(tf, vf);
-            if (early && has_next) stage(slot1, buf ^ 1);
 
             f32x16 acc;
 #pragma unroll
@@ -185,6 +202,7 @@ __global__ __launch_bounds__(kThreads) void collapse_relu_sum_kernel(const float
                 if (__ballot((any & 0x7fff7fffu) != 0u) == 0ull) continue; // +-0 only
                 const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off0);
                 const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off1);
+                // the four hi products first: they cover the latency of the lo reads
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].lo, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].lo, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].hi, acc, 0, 0, 0);
@@ -198,17 +216,20 @@ __global__ __launch_bounds__(kThreads) void collapse_relu_sum_kernel(const float
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[i] + bcol); // vfa_op.py:124, vfanet.py:82
-            if (!early && has_next) stage(slot1, buf ^ 1);
+            if (has_next) stage(slot1, buf ^ 1);
             wait_oldest(); // item + 2 has landed (this wave's rows); the barrier makes all rows visible
             if (v + 1 == n_views) {
                 // C/D map of the 32x32 MFMA: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h, column r
                 float *orow = out + (size_t)tile * kRows * kN + wave * 32 + r;
+                const long long rows_left = M - tile * kRows;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (tile * kRows + row < M) {
-                        float *p = orow + (size_t)row * kN;
-                        *p = accumulate ? *p + sum[i] : sum[i];
+                    if (row < rows_left) {
+                        // this workgroup owns the rows: a fire-and-forget atomic is load + add + store without the
+                        // round trip (a load's wait would also drain the LDS-DMA in flight)
+                        if (accumulate) unsafeAtomicAdd(orow + (size_t)row * kN, sum[i]);
+                        else orow[(size_t)row * kN] = sum[i];
                     }
                 }
             }
@@ -236,11 +257,10 @@ extern "C" int vfa_collapse_relu_sum_f32(const float *vox, const float *weight, 
     constexpr size_t lds_bytes = kLdsBytes;
     static bool attr_set = false; // idempotent: a race only repeats the call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)collapse_relu_sum_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)collapse_relu_sum_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes);
+        hipError_t e = hipSuccess;
+        const void *fns[2] = {(const void *)collapse_relu_sum_kernel<3>, (const void *)collapse_relu_sum_kernel<4>};
+        for (int i = 0; i < 2 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -254,10 +274,10 @@ extern "C" int vfa_collapse_relu_sum_f32(const float *vox, const float *weight, 
     const long long n_tiles = ((long long)M + kRows - 1) / kRows;
     const unsigned blocks = (unsigned)(n_tiles < n_cu ? n_tiles : n_cu);
     if (terms == 4)
-        hipLaunchKernelGGL((collapse_relu_sum_kernel<4, false>), dim3(blocks), dim3(kThreads), lds_bytes, s, vox, weight, bias, out, n_views,
+        hipLaunchKernelGGL((collapse_relu_sum_kernel<4>), dim3(blocks), dim3(kThreads), lds_bytes, s, vox, weight, bias, out, n_views,
                            (long long)M, accumulate);
     else
-        hipLaunchKernelGGL((collapse_relu_sum_kernel<3, false>), dim3(blocks), dim3(kThreads), lds_bytes, s, vox, weight, bias, out, n_views,
+        hipLaunchKernelGGL((collapse_relu_sum_kernel<3>), dim3(blocks), dim3(kThreads), lds_bytes, s, vox, weight, bias, out, n_views,
                            (long long)M, accumulate);
     return (int)hipGetLastError();
 }
