@@ -622,3 +622,49 @@ def test_collapse_relu_sum_rejects_other_shapes_and_handles_empty():
     nan[0, 7, 3] = float("nan")
     out = ops.collapse_relu_sum(nan, torch.ones(256, 256, device=dev), None)
     assert torch.isnan(out[7]).all() and torch.isfinite(out[:7]).all() and torch.isfinite(out[8:]).all()
+
+
+@pytest.mark.parametrize("name", ["multiviewc_200x200x1", "wildtrack_480x1440x1"])
+def test_mfma_collapse_path_matches_library_path_and_float64(name, monkeypatch):
+    """Inference on single-layer grids runs pooling + `vfa_collapse_relu_sum_f32`; the same frame through the fp32
+    library GEMM + epilogue kernels and through a float64 product of the (bitwise-pinned) voxel features must agree
+    within the post-GEMM tolerance, at BASELINE sizes."""
+    import vfa_amd
+    from vfa_amd import _lib, ops, vfa_op
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    n_cam = 3 if name.startswith("wildtrack") else None
+    wl = make_workload(name, channels=256, seed=2, device=dev, **({"n_cam": n_cam} if n_cam else {}))
+    n = wl["n_cam"]
+    torch.manual_seed(1)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+            for _ in range(3)]
+    lats = [torch.cat([wl["features"][c][s] for c in range(n)]) for s in range(3)]
+    assert all(m.mfma_collapse_ok() for m in mods) is False  # parameters require grad outside no_grad
+    with torch.no_grad():
+        assert all(m.mfma_collapse_ok(l) for m, l in zip(mods, lats))
+        with ops.KernelTimer() as kt:
+            fast = vfa_amd.aggregate_views(*mods, *lats, wl["calibs"], wl["grid"])
+        torch.cuda.synchronize()
+        assert "vfa_collapse_relu_sum_f32" in kt.summary() and "vfa_scale_view_sum_f32" not in kt.summary()
+        monkeypatch.setattr(vfa_op, "COLLAPSE_KERNEL", "library")
+        with ops.KernelTimer() as kt:
+            slow = vfa_amd.aggregate_views(*mods, *lats, wl["calibs"], wl["grid"])
+        torch.cuda.synchronize()
+        assert "vfa_scale_view_sum_f32" in kt.summary() and "vfa_collapse_relu_sum_f32" not in kt.summary()
+        # float64 from the voxel features (first 20 000 cells: memory)
+        cells = min(20000, wl["grid"].shape[1] * wl["grid"].shape[2])
+        want = torch.zeros(cells, 256, dtype=torch.float64, device=dev)
+        grid_flat = wl["grid"].reshape(-1, 3).contiguous()
+        for m, lat in zip(mods, lats):
+            zl, co = m._kernel_geometry(dev)
+            vox = ops.project_gather(ops.integral_image(lat), wl["calibs"].reshape(n, 12).contiguous(), grid_flat, zl, co,
+                                     _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1], cell_count=cells)
+            want += torch.relu(vox.double() @ m.collapse.weight.double().T + m.collapse.bias.double()).sum(0)
+    scale = want.abs().max().item()
+    L, W = wl["grid"].shape[1:3]
+    f = fast[0].permute(1, 2, 0).reshape(L * W, 256)
+    s = slow[0].permute(1, 2, 0).reshape(L * W, 256)
+    torch.testing.assert_close(f, s, rtol=RTOL, atol=2 * ATOL_REL * scale)
+    torch.testing.assert_close(f[:cells].double(), want, rtol=RTOL, atol=ATOL_REL * scale)
+    torch.testing.assert_close(s[:cells].double(), want, rtol=RTOL, atol=ATOL_REL * scale)
