@@ -206,6 +206,12 @@ def main():
                          "fp32_equivalent_tflops": gemm_flops / 3 / (ck["ms"] / ck["launches"] * 1e-3) / 1e12,
                          "bf16_mfma_tflops": gemm_flops / (ck["ms"] / ck["launches"] * 1e-3) / 1e12,
                          "max_rel_error_vs_fp64": "~3e-6 of max|out| (tests/test_hip_parity.py), tolerance 1e-5"}
+    elif ks.get("vfa_collapse_gemm_f32", {}).get("launches"):
+        cg = ks["vfa_collapse_gemm_f32"]
+        collapse_info = {"flops_per_step": gemm_flops, "backend": "vfa_collapse_gemm_f32 (K-looped 3xbf16-split MFMA tile GEMM, "
+                         "fp32 accumulate) + epilogue kernels", "avg_us": 1e3 * cg["ms"] / cg["launches"],
+                         "fp32_equivalent_tflops": gemm_flops / 3 / (cg["ms"] / cg["launches"] * 1e-3) / 1e12,
+                         "max_rel_error_vs_fp64": "~5e-6 of max|out| (tests/test_hip_parity.py), tolerance 1e-5"}
     else:
         collapse_info = {"flops_per_step": gemm_flops, "backend": "torch.matmul (rocBLAS/hipBLASLt fp32)"
                          + (", TunableOp-selected" if a.tune_gemm else ""), "peak_tflops": FP32_MFMA_PEAK_TFLOPS}

@@ -161,6 +161,16 @@ int vfa_scale_view_sum_f32(const float *lin8, const float *lin16, const float *l
 int vfa_collapse_relu_sum_f32(const float *vox, const float *weight, const float *bias, float *out, int n_views, size_t M,
                               int K, int N, int accumulate, int terms, void *stream);
 
+/* The `collapse` product alone for any layer count:  lin[m, :] = vox[m, :] . weight^T,  m < M = n_views * cells,
+ * K = nl * C a multiple of 128, N = 256 (other shapes: VFA_ERR_UNSUPPORTED, use a library GEMM).  No bias, no ReLU: the
+ * two epilogue entry points above add them while summing views.         replaces vfa_op.py:121-123 (nn.Linear)
+ * Same arithmetic as vfa_collapse_relu_sum_f32 (bf16-split MFMA, fp32 accumulation, `terms` 0/3/4), as a K-looped
+ * 128-row tile GEMM.  `workspace`: vfa_collapse_gemm_workspace_bytes(K, N) bytes of caller-owned scratch (the weight,
+ * split into bf16 planes in MFMA fragment order, rewritten by every call). */
+size_t vfa_collapse_gemm_workspace_bytes(int K, int N);
+int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, void *workspace, size_t workspace_bytes, size_t M,
+                          int K, int N, int terms, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

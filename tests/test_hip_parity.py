@@ -40,7 +40,10 @@ def assert_bitwise(name, got, ref, zero_sign_free=False):
 
 def assert_close(name, got, ref):
     ref = np.asarray(ref)
-    np.testing.assert_allclose(np.asarray(got), ref, rtol=RTOL, atol=ATOL_REL * np.abs(ref).max(), err_msg=name)
+    got = np.asarray(got)
+    tol = RTOL * np.abs(ref) + ATOL_REL * np.abs(ref).max()
+    print(f"[margin] {name}: worst |err| / tolerance = {float((np.abs(got - ref) / tol).max()):.3f}")  # shown with -s / on failure
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL_REL * np.abs(ref).max(), err_msg=name)
 
 
 def _meta(d):
@@ -668,3 +671,36 @@ def test_mfma_collapse_path_matches_library_path_and_float64(name, monkeypatch):
     torch.testing.assert_close(f, s, rtol=RTOL, atol=2 * ATOL_REL * scale)
     torch.testing.assert_close(f[:cells].double(), want, rtol=RTOL, atol=ATOL_REL * scale)
     torch.testing.assert_close(s[:cells].double(), want, rtol=RTOL, atol=ATOL_REL * scale)
+
+
+@pytest.mark.parametrize("M,K,terms", [(128, 128, 3), (1000, 1280, 3), (4097, 2048, 4), (31, 256, 0), (8192 + 17, 768, 3)])
+def test_collapse_gemm_kernel_matches_float64(M, K, terms):
+    """`vfa_collapse_gemm_f32` (K-looped bf16-split MFMA tile GEMM, N = 256) against the float64 product at the path's
+    post-GEMM tolerance: ragged last tile, masked (all-zero) rows, several chunk counts."""
+    from vfa_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(M + K)
+    vox = torch.rand(M, K, generator=gen) * 3.0
+    vox[torch.rand(M, generator=gen) < 0.3] = 0.0
+    vox[:, : K // 4][torch.rand(M, generator=gen) < 0.2] = 0.0  # partially masked rows (some layers invisible)
+    w = (torch.rand(256, K, generator=gen) - 0.5) * (2.0 / K ** 0.5)
+    want = vox.double() @ w.double().T
+    got = ops.collapse_gemm(vox.to(dev), w.to(dev), terms=terms)
+    scale = want.abs().max().item()
+    torch.testing.assert_close(got.cpu().double(), want, rtol=RTOL, atol=ATOL_REL * scale)
+    err = (got.cpu().double() - want).abs().max().item() / scale
+    assert err < 0.6e-5, err
+    # a second call with another weight on the same stream reuses the workspace
+    w2 = torch.flip(w, dims=(0,))
+    got2 = ops.collapse_gemm(vox.to(dev), w2.to(dev), terms=terms)
+    torch.testing.assert_close(got2.cpu().double(), vox.double() @ w2.double().T, rtol=RTOL, atol=ATOL_REL * scale)
+
+
+def test_collapse_gemm_rejects_other_shapes():
+    from vfa_amd import _lib, ops
+    dev = _dev()
+    with pytest.raises(_lib.VFAHipError):
+        ops.collapse_gemm(torch.zeros(8, 192, device=dev), torch.zeros(256, 192, device=dev))
+    with pytest.raises(_lib.VFAHipError):
+        ops.collapse_gemm(torch.zeros(8, 256, device=dev), torch.zeros(128, 256, device=dev))
+    assert ops.collapse_gemm(torch.zeros(0, 256, device=dev), torch.zeros(256, 256, device=dev)).shape == (0, 256)

@@ -38,6 +38,8 @@ SIGNATURES = {
     "vfa_relu_mask_backward_f32": [_vp, _vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _vp],
     "vfa_bias_relu_accumulate_f32": [_vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _vp],
     "vfa_scale_view_sum_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _vp],
+    "vfa_collapse_gemm_workspace_bytes": [_c_int, _c_int],
+    "vfa_collapse_gemm_f32": [_vp, _vp, _vp, _vp, _c_size_t, _c_size_t, _c_int, _c_int, _c_int, _vp],
     "vfa_collapse_relu_sum_f32": [_vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
 }
 

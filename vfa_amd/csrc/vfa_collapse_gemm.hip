@@ -1,0 +1,221 @@
+// vfa_collapse_gemm.hip -- the `collapse` product (reference vfa/model/vfa_op.py:121-123) for multi-layer grids:
+//
+//   lin[m, :] = vox[m, :] . W^T          m < M = n_views * cells,  K = nl * 256 inputs,  N = 256 outputs
+//
+// (no bias, no ReLU: the epilogue kernels of vfa_kernels.hip add them while summing views, exactly as behind the library
+// GEMM this replaces).  Same arithmetic as vfa_collapse.hip: every fp32 product is three bf16 MFMA products of an exact
+// hi/lo split of both operands, accumulated in fp32 (error ~3e-6 of max|out|, tolerance of the path 1e-5).
+//
+// K does not fit the register-resident W of the single-layer kernel, so this one is a K-looped tile GEMM:
+//   * a prep kernel splits W once per call into bf16 hi / lo planes stored in MFMA B-fragment order in a caller-owned
+//     workspace (K * 256 * 4 bytes): a wave fetches the fragments of a k-step with one coalesced 1 KiB load per plane;
+//   * one persistent 512-thread workgroup per CU owns tiles of 128 rows; wave w owns output columns 32 w .. 32 w + 31
+//     and keeps 4 x (32 x 32) fp32 accumulators (64 VGPRs);
+//   * K advances in chunks of 128: the chunk of the NEXT work item is loaded from HBM into registers (8 float4 per
+//     thread) while the MFMAs of the current one run, then split into two XOR-swizzled bf16 LDS planes (double-buffered,
+//     128 KiB); the W fragments of a chunk arrive in two halves, the second in flight under the MFMAs of the first;
+//   * 96 MFMAs per wave between barriers (4x the single-layer kernel's): the serial per-item phases cost ~15 %.
+//   * (row block, k-step) pairs whose hi fragment is all zero -- masked voxels -- skip their MFMAs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vfa_hip.h"
+
+namespace {
+
+constexpr int kN = 256;          // output channels (the only width this kernel is built for)
+constexpr int kTileRows = 128;   // rows per tile = 4 MFMA row blocks
+constexpr int kRowBlocks = kTileRows / 32;
+constexpr int kChunk = 128;      // k per chunk
+constexpr int kStepsPerChunk = kChunk / 16;
+constexpr int kThreads = 512;
+constexpr int kRowBytes = kChunk * 2;            // one bf16 plane row of a chunk (256 B); 16-byte pieces XOR (row & 15)
+constexpr int kPlane = kTileRows * kRowBytes;    // 32 KiB
+constexpr int kLdsBytes = 2 * 2 * kPlane;        // [buffer][hi / lo] = 128 KiB
+constexpr int kLoads = kTileRows * kChunk / 4 / kThreads; // float4 per thread and chunk (8)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void split_bf16(float x, __bf16 &hi, __bf16 &lo)
+{
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+
+// Workspace layout: fragment (chunk c, wave w, step s, plane p) = 64 lanes x 16 B at
+//   ((((c * 8 + w) * kStepsPerChunk + s) * 2 + p) * 64 + lane) * 16
+// lane (r, h) holds W[n = 32 w + r][k = 128 c + 16 s + 8 h + j], j = 0..7  (MFMA B operand of v_mfma_f32_32x32x16_bf16)
+__global__ __launch_bounds__(256) void split_weight_kernel(const float *__restrict__ weight, uint4 *__restrict__ ws, int K)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; // one (c, w, s, lane) per thread, both planes
+    const size_t total = (size_t)(K / kChunk) * 8 * kStepsPerChunk * 64;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const int s = (int)((i >> 6) % kStepsPerChunk);
+    const int w = (int)((i >> 6) / kStepsPerChunk % 8);
+    const int c = (int)((i >> 6) / kStepsPerChunk / 8);
+    const int r = lane & 31, h = lane >> 5;
+    const float *src = weight + (size_t)(32 * w + r) * K + (size_t)kChunk * c + 16 * s + 8 * h;
+    union { __bf16 b[8]; uint4 u; } hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_bf16(src[j], hi.b[j], lo.b[j]);
+    const size_t base = ((((size_t)c * 8 + w) * kStepsPerChunk + s) * 2) * 64 + lane;
+    ws[base] = hi.u;
+    ws[base + 64] = lo.u;
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__restrict__ vox, const uint4 *__restrict__ ws,
+                                                               float *__restrict__ lin, long long M, int K)
+{
+    extern __shared__ __align__(16) unsigned char planes[]; // [buffer][hi / lo][128 rows][256 B]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const long long n_tiles = (M + kTileRows - 1) / kTileRows;
+    const int n_chunks = K / kChunk;
+    long long tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+
+    // this thread's share of a chunk: float4 number tid + 512 i of the 128 x 32 float4 (row = idx / 32)
+    float4 pre[kLoads];
+    auto fetch = [&](long long t, int c) {
+        const long long row0 = t * kTileRows;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = tid + kThreads * i, row = idx >> 5, c4 = idx & 31;
+            const long long m = row0 + row;
+            pre[i] = m < M ? *reinterpret_cast<const float4 *>(vox + (size_t)m * K + (size_t)c * kChunk + 4 * c4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int idx = tid + kThreads * i, row = idx >> 5, c4 = idx & 31;
+            const float x[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+            union { __bf16 b[4]; uint2 u; } hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_bf16(x[j], hi.b[j], lo.b[j]);
+            const int off = row * kRowBytes + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
+            *reinterpret_cast<uint2 *>(planes + (buf * 2 + 0) * kPlane + off) = hi.u;
+            *reinterpret_cast<uint2 *>(planes + (buf * 2 + 1) * kPlane + off) = lo.u;
+        }
+    };
+    // W fragments of half a chunk (4 k-steps x 2 planes = 32 VGPRs); two halves are alive at a time
+    struct WHalf { bf16x8 hi[kStepsPerChunk / 2], lo[kStepsPerChunk / 2]; };
+    auto load_w = [&](WHalf &wq, int c, int half) {
+        const uint4 *p = ws + ((((size_t)c * 8 + wave) * kStepsPerChunk + half * (kStepsPerChunk / 2)) * 2) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < kStepsPerChunk / 2; ++s) {
+            const uint4 a = p[(size_t)s * 128], b = p[(size_t)s * 128 + 64];
+            wq.hi[s] = *reinterpret_cast<const bf16x8 *>(&a);
+            wq.lo[s] = *reinterpret_cast<const bf16x8 *>(&b);
+        }
+    };
+
+    const int key = r & 15;
+    const int frag_base = r * kRowBytes + ((h ^ (key & 1)) << 4);
+    f32x16 acc[kRowBlocks];
+    auto mfma_half = [&](const WHalf &wq, int buf, int half) {
+        const unsigned char *pa = planes + buf * 2 * kPlane + frag_base;
+#pragma unroll
+        for (int s = 0; s < kStepsPerChunk / 2; ++s) {
+            const int off = ((half * (kStepsPerChunk / 2) + s) ^ (key >> 1)) << 5;
+#pragma unroll
+            for (int rb = 0; rb < kRowBlocks; ++rb) {
+                const unsigned char *pr = pa + rb * 32 * kRowBytes + off;
+                const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(pr);
+                const uint4 u = *reinterpret_cast<const uint4 *>(&a_hi);
+                if (__ballot((((u.x | u.y) | (u.z | u.w)) & 0x7fff7fffu) != 0u) == 0ull) continue; // masked rows: +-0 only
+                const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(pr + kPlane);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, wq.lo[s], acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, wq.hi[s], acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, wq.hi[s], acc[rb], 0, 0, 0);
+                if (TERMS >= 4) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, wq.lo[s], acc[rb], 0, 0, 0);
+            }
+        }
+    };
+
+    // work items = (tile, chunk) in the order this workgroup meets them
+    fetch(tile, 0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int rb = 0; rb < kRowBlocks; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][i] = 0.0f;
+        for (int c = 0; c < n_chunks; ++c) {
+            const bool last_chunk = c + 1 == n_chunks;
+            const long long nt = last_chunk ? tile + gridDim.x : tile;
+            const bool has_next = nt < n_tiles;
+            if (has_next) fetch(nt, last_chunk ? 0 : c + 1); // lands under the MFMAs below
+            WHalf w0, w1;
+            load_w(w0, c, 0);
+            load_w(w1, c, 1); // in flight under the first half's MFMAs
+            mfma_half(w0, buf, 0);
+            mfma_half(w1, buf, 1);
+            if (has_next) stage(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // C/D map of the 32x32 MFMA: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h, column r
+#pragma unroll
+        for (int rb = 0; rb < kRowBlocks; ++rb) {
+            const long long row0 = tile * kTileRows + rb * 32;
+            float *orow = lin + (size_t)row0 * kN + wave * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (row0 + row < M) orow[(size_t)row * kN] = acc[rb][i];
+            }
+        }
+    }
+}
+
+} // namespace
+
+extern "C" size_t vfa_collapse_gemm_workspace_bytes(int K, int N)
+{
+    if (K <= 0 || N <= 0) return 0;
+    return (size_t)K * (size_t)N * 4;
+}
+
+extern "C" int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, void *workspace, size_t workspace_bytes,
+                                     size_t M, int K, int N, int terms, void *stream)
+{
+    if (K <= 0 || N <= 0 || (terms != 0 && terms != 3 && terms != 4)) return VFA_ERR_BAD_ARGUMENT;
+    if (N != kN || K % kChunk != 0) return VFA_ERR_UNSUPPORTED;
+    if (M == 0) return 0;
+    if (!workspace || workspace_bytes < vfa_collapse_gemm_workspace_bytes(K, N)) return VFA_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false; // idempotent: a race only repeats the call
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)collapse_gemm_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)collapse_gemm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int n_cu = 256;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            cus > 0)
+            n_cu = cus;
+    }
+    const size_t frags = (size_t)(K / kChunk) * 8 * kStepsPerChunk * 64;
+    hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, s, weight, (uint4 *)workspace, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const long long n_tiles = ((long long)M + kTileRows - 1) / kTileRows;
+    const unsigned blocks = (unsigned)(n_tiles < n_cu ? n_tiles : n_cu);
+    if (terms == 4)
+        hipLaunchKernelGGL((collapse_gemm_kernel<4>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, lin,
+                           (long long)M, K);
+    else
+        hipLaunchKernelGGL((collapse_gemm_kernel<3>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, lin,
+                           (long long)M, K);
+    return (int)hipGetLastError();
+}

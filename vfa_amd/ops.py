@@ -285,3 +285,26 @@ def collapse_relu_sum(vox, weight, bias, out=None, accumulate=False, terms=0):
     _launch("vfa_collapse_relu_sum_f32", _lib.ptr(vox), _lib.ptr(weight), _lib.ptr(bias),
             _lib.ptr(out), n, M, K, N, 1 if accumulate else 0, int(terms), _lib.current_stream_handle())
     return out
+
+
+_gemm_ws = {}
+
+
+def collapse_gemm(vox2d, weight, out=None, terms=0):
+    """lin (M,N) = vox2d (M,K) @ weight (N,K).T as a bf16-split MFMA tile GEMM (N = 256, K a multiple of 128; reference
+    vfa_op.py:121-123 without bias).  Raises ``VFAHipError`` (VFA_ERR_UNSUPPORTED) for other shapes."""
+    _lib.require_device(vox2d, weight, out)
+    vox2d, weight = _f32c(vox2d), _f32c(weight)
+    M, K = vox2d.shape
+    N = weight.shape[0]
+    assert weight.shape == (N, K), (tuple(weight.shape), K)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=vox2d.device)
+    need = _lib.lib().vfa_collapse_gemm_workspace_bytes(K, N)
+    key = (vox2d.device.index, torch.cuda.current_stream(vox2d.device).cuda_stream)
+    ws = _gemm_ws.get(key)
+    if ws is None or ws.numel() < need:  # one scratch buffer per (device, stream): calls on a stream are ordered
+        ws = _gemm_ws[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=vox2d.device)
+    _launch("vfa_collapse_gemm_f32", _lib.ptr(vox2d), _lib.ptr(weight), _lib.ptr(out), _lib.ptr(ws), ws.numel(), M, K, N,
+            int(terms), _lib.current_stream_handle(), tag=(M, K, N))
+    return out

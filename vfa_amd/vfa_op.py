@@ -37,7 +37,8 @@ VOX_BYTES_LIMIT = int(os.environ.get("VFA_AMD_VOX_BYTES", str(8 << 30)))
 USE_FUSED = os.environ.get("VFA_AMD_FUSED", "0") == "1"
 # `collapse` on single-layer grids (K = N = 256) when no gradient is needed: "mfma_bf16" (default) = the hand-written
 # bf16-split MFMA kernel fused with bias, ReLU and the view sum (include/vfa_hip.h: vfa_collapse_relu_sum_f32);
-# "library" = fp32 library GEMM + epilogue kernels (the training path, and every other shape, always use this).
+# on multi-layer grids and in training (K = nl*C a multiple of 128, N = 256) the product alone runs as the K-looped MFMA
+# tile GEMM `vfa_collapse_gemm_f32` in front of the epilogue kernels; "library" = fp32 library GEMM everywhere.
 COLLAPSE_KERNEL = os.environ.get("VFA_AMD_COLLAPSE", "mfma_bf16")
 COLLAPSE_TERMS = int(os.environ.get("VFA_AMD_COLLAPSE_TERMS", "3"))
 
@@ -85,6 +86,29 @@ class _BoxPool(torch.autograd.Function):
         grad_integral = ops.project_gather_backward(grad_vox, shape, calibs, grid_flat, z_layers, corner_off, conv_kind,
                                                     (img_w, img_h), (cmin, cmax), cell_begin, cell_count)
         return grad_integral, None, None, None, None, None, None, None
+
+
+class _CollapseGemm(torch.autograd.Function):
+    """lin (M,N) = vox (M,K) @ weight (N,K)^T.  Forward: the hand-written bf16-split MFMA tile GEMM
+    (``vfa_collapse_gemm_f32``); backward: the two fp32 library products."""
+
+    @staticmethod
+    def forward(ctx, vox2d, weight):
+        ctx.save_for_backward(vox2d, weight)
+        return ops.collapse_gemm(vox2d, weight, terms=COLLAPSE_TERMS)
+
+    @staticmethod
+    def backward(ctx, grad):
+        vox2d, weight = ctx.saved_tensors
+        grad = grad.contiguous()
+        g_vox = torch.matmul(grad, weight) if ctx.needs_input_grad[0] else None
+        g_w = torch.matmul(grad.t(), vox2d) if ctx.needs_input_grad[1] else None
+        return g_vox, g_w
+
+
+def mfma_gemm_ok(K, N):
+    """The K-looped MFMA GEMM covers this `collapse` shape (any layer count at C = 256)."""
+    return COLLAPSE_KERNEL != "library" and N == 256 and K % 128 == 0
 
 
 class _BiasReluSum(torch.autograd.Function):
@@ -172,14 +196,19 @@ class VFA(nn.Module):
             w_t = self.layer_major_weight().t().contiguous()
             return ops.project_collapse(integral, calibs, grid_flat, z_layers, corner_off, w_t, conv_kind,
                                         (img_w, img_h), (geom[3], geom[4]))
-        w_lm_t = self.layer_major_weight().t()
+        w_lm = self.layer_major_weight()
+        use_mfma = mfma_gemm_ok(nl * C, self.collapse.out_features)
         per_cell = n * nl * C * 4
         chunk = max(1, min(n_cells, VOX_BYTES_LIMIT // max(per_cell, 1)))
         outs = []
         for begin in range(0, n_cells, chunk):
             count = min(chunk, n_cells - begin)
             vox = _BoxPool.apply(integral, calibs, grid_flat, z_layers, corner_off, geom, begin, count)
-            outs.append(torch.matmul(vox.view(n * count, nl * C), w_lm_t).view(n, count, -1))
+            if use_mfma:
+                lin = _CollapseGemm.apply(vox.view(n * count, nl * C), w_lm.contiguous())
+            else:
+                lin = torch.matmul(vox.view(n * count, nl * C), w_lm.t())
+            outs.append(lin.view(n, count, -1))
         return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
     def mfma_collapse_ok(self, features=None):
