@@ -14,8 +14,13 @@
 //   * K advances in chunks of 128: the chunk of the NEXT work item is loaded from HBM into registers (8 float4 per
 //     thread) while the MFMAs of the current one run, then split into two XOR-swizzled bf16 LDS planes (double-buffered,
 //     128 KiB); the W fragments of a chunk arrive in two halves, the second in flight under the MFMAs of the first;
-//   * 96 MFMAs per wave between barriers (4x the single-layer kernel's): the serial per-item phases cost ~15 %.
-//   * (row block, k-step) pairs whose hi fragment is all zero -- masked voxels -- skip their MFMAs.
+//   * 96 MFMAs per wave between barriers (4x the single-layer kernel's);
+//   * row blocks of 32 rows whose chunk is all zero -- masked voxels -- skip their MFMAs (flags set by the split pass).
+// Measured (MI355X): 260-310 TFLOP/s fp32-equivalent (K = 1280 / 2048) against 110-135 for the fp32 library GEMM, error
+// 5e-6 of max|out|.  In-kernel stamps: the MFMA phase of an item is 6 200-8 200 cycles (the two waves of a SIMD need
+// 6 144), the HBM side delivers a CU's 64 KiB in ~7 500 (2.1-2.5 TB/s chip-wide while the MFMAs run, 4.8 TB/s alone),
+// the output stores ~3 400 per item.  Variants measured within +-5 %: 4 dedicated loader waves beside 8 MFMA waves
+// (768 threads), two items in flight per loader, LDS fragment reads pipelined one half-step ahead.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -31,7 +36,7 @@ constexpr int kStepsPerChunk = kChunk / 16;
 constexpr int kThreads = 512;
 constexpr int kRowBytes = kChunk * 2;            // one bf16 plane row of a chunk (256 B); 16-byte pieces XOR (row & 15)
 constexpr int kPlane = kTileRows * kRowBytes;    // 32 KiB
-constexpr int kLdsBytes = 2 * 2 * kPlane;        // [buffer][hi / lo] = 128 KiB
+constexpr int kLdsBytes = 2 * 2 * kPlane + 64;   // [buffer][hi / lo] = 128 KiB, + live flags [3 items][4 row blocks]
 constexpr int kLoads = kTileRows * kChunk / 4 / kThreads; // float4 per thread and chunk (8)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -70,36 +75,50 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
                                                                float *__restrict__ lin, long long M, int K)
 {
     extern __shared__ __align__(16) unsigned char planes[]; // [buffer][hi / lo][128 rows][256 B]
+    int *live = reinterpret_cast<int *>(planes + 2 * 2 * kPlane); // [item % 3][row block]: the chunk has a non-zero element there
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
     const long long n_tiles = (M + kTileRows - 1) / kTileRows;
     const int n_chunks = K / kChunk;
     long long tile = blockIdx.x;
     if (tile >= n_tiles) return;
 
-    // this thread's share of a chunk: float4 number tid + 512 i of the 128 x 32 float4 (row = idx / 32)
+    // this thread's share of a chunk: float4 number tid + 512 i of the 128 x 32 float4 (row = idx / 32).
+    // Every load of the main loop is UNCONDITIONAL (addresses are clamped instead): with straight-line loads the in-order
+    // vmcnt counter lets the compiler wait for exactly the W fragments it needs and leave the younger HBM loads in
+    // flight; with predicated loads it fell back to vmcnt(0) between them and before the first MFMA (1.5x slower).
     float4 pre[kLoads];
     auto fetch = [&](long long t, int c) {
         const long long row0 = t * kTileRows;
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int idx = tid + kThreads * i, row = idx >> 5, c4 = idx & 31;
-            const long long m = row0 + row;
-            pre[i] = m < M ? *reinterpret_cast<const float4 *>(vox + (size_t)m * K + (size_t)c * kChunk + 4 * c4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            long long m = row0 + row;
+            m = m < M ? m : M - 1; // rows past the end read a valid row; their outputs are never stored
+            pre[i] = *reinterpret_cast<const float4 *>(vox + (size_t)m * K + (size_t)c * kChunk + 4 * c4);
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, int slot) {
+        unsigned nz = 0; // bit rb: this thread saw a non-zero (or NaN) element in row block rb
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int idx = tid + kThreads * i, row = idx >> 5, c4 = idx & 31;
             const float x[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
             union { __bf16 b[4]; uint2 u; } hi, lo;
+            bool any = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) split_bf16(x[j], hi.b[j], lo.b[j]);
+            for (int j = 0; j < 4; ++j) {
+                split_bf16(x[j], hi.b[j], lo.b[j]);
+                any |= !(x[j] == 0.0f);
+            }
+            nz |= any ? 1u << (row >> 5) : 0u;
             const int off = row * kRowBytes + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
             *reinterpret_cast<uint2 *>(planes + (buf * 2 + 0) * kPlane + off) = hi.u;
             *reinterpret_cast<uint2 *>(planes + (buf * 2 + 1) * kPlane + off) = lo.u;
         }
+        // a thread's rows are (tid + 512 i) / 32 = tid / 32 + 16 i: one row of each 16-row half of every row block
+#pragma unroll
+        for (int rb = 0; rb < kRowBlocks; ++rb)
+            if (__ballot((nz >> rb) & 1u) != 0ull && lane == 0) live[slot * kRowBlocks + rb] = 1; // every writer stores 1
     };
     // W fragments of half a chunk (4 k-steps x 2 planes = 32 VGPRs); two halves are alive at a time
     struct WHalf { bf16x8 hi[kStepsPerChunk / 2], lo[kStepsPerChunk / 2]; };
@@ -116,17 +135,16 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
     const int key = r & 15;
     const int frag_base = r * kRowBytes + ((h ^ (key & 1)) << 4);
     f32x16 acc[kRowBlocks];
-    auto mfma_half = [&](const WHalf &wq, int buf, int half) {
+    auto mfma_half = [&](const WHalf &wq, int buf, int half, int slot) {
         const unsigned char *pa = planes + buf * 2 * kPlane + frag_base;
 #pragma unroll
-        for (int s = 0; s < kStepsPerChunk / 2; ++s) {
-            const int off = ((half * (kStepsPerChunk / 2) + s) ^ (key >> 1)) << 5;
+        for (int rb = 0; rb < kRowBlocks; ++rb) {
+            if (!__builtin_amdgcn_readfirstlane(live[slot * kRowBlocks + rb])) continue; // 32 masked voxels: all +-0
 #pragma unroll
-            for (int rb = 0; rb < kRowBlocks; ++rb) {
+            for (int s = 0; s < kStepsPerChunk / 2; ++s) {
+                const int off = ((half * (kStepsPerChunk / 2) + s) ^ (key >> 1)) << 5;
                 const unsigned char *pr = pa + rb * 32 * kRowBytes + off;
                 const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(pr);
-                const uint4 u = *reinterpret_cast<const uint4 *>(&a_hi);
-                if (__ballot((((u.x | u.y) | (u.z | u.w)) & 0x7fff7fffu) != 0u) == 0ull) continue; // masked rows: +-0 only
                 const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(pr + kPlane);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, wq.lo[s], acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, wq.hi[s], acc[rb], 0, 0, 0);
@@ -136,11 +154,16 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
         }
     };
 
-    // work items = (tile, chunk) in the order this workgroup meets them
-    fetch(tile, 0);
-    stage(0);
+    // work items = (tile, chunk) in the order this workgroup meets them; item i: plane buffer i & 1, flags slot i % 3
+    if (tid < 3 * kRowBlocks) live[tid] = 0;
     __syncthreads();
-    int buf = 0;
+    fetch(tile, 0);
+    stage(0, 0);
+    WHalf w0, w1;
+    load_w(w0, 0, 0);
+    load_w(w1, 0, 1);
+    __syncthreads();
+    int buf = 0, slot = 0;
     for (; tile < n_tiles; tile += gridDim.x) {
 #pragma unroll
         for (int rb = 0; rb < kRowBlocks; ++rb)
@@ -150,15 +173,18 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
             const bool last_chunk = c + 1 == n_chunks;
             const long long nt = last_chunk ? tile + gridDim.x : tile;
             const bool has_next = nt < n_tiles;
-            if (has_next) fetch(nt, last_chunk ? 0 : c + 1); // lands under the MFMAs below
-            WHalf w0, w1;
-            load_w(w0, c, 0);
-            load_w(w1, c, 1); // in flight under the first half's MFMAs
-            mfma_half(w0, buf, 0);
-            mfma_half(w1, buf, 1);
-            if (has_next) stage(buf ^ 1);
+            const int cn = last_chunk ? 0 : c + 1; // the next item's chunk (its W fragments do not depend on the tile)
+            const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+            if (tid < kRowBlocks) live[slot2 * kRowBlocks + tid] = 0; // read last in the previous item, set in the next
+            fetch(has_next ? nt : tile, cn); // lands under the MFMAs below (after the last item: a harmless re-read)
+            mfma_half(w0, buf, 0, slot);
+            load_w(w0, cn, 0); // in flight under the second half's MFMAs
+            mfma_half(w1, buf, 1, slot);
+            load_w(w1, cn, 1); // in flight under the split below and the next first half
+            stage(buf ^ 1, slot1);
             __syncthreads();
             buf ^= 1;
+            slot = slot1;
         }
         // C/D map of the 32x32 MFMA: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h, column r
 #pragma unroll
