@@ -151,11 +151,15 @@ def main():
 
     step()  # one-off set-up outside warm-up and timing: GEMM kernel selection (TunableOp) and pooling-kernel choice
     drain()
-    for _ in range(a.warmup):
-        step()
-    drain()
-    fence()
-    with ops.KernelTimer() as kt:
+    # Warm-up steps: HIP events around EVERY entry point (the `kernels` table).  Timed steps: only around the roofline
+    # kernel -- each timed launch puts two event records in the queue (~3 us apiece), and timing all nine launches
+    # of a frame slowed the 0.9 ms frame by 6 %.
+    with ops.KernelTimer() as kt_warm:
+        for _ in range(a.warmup):
+            step()
+        drain()
+        fence()
+    with ops.KernelTimer(only=("vfa_project_gather_f32",)) as kt:
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
@@ -193,11 +197,13 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes / g["launches"],
                     "launches": g["launches"]}
-    kernels = {k: {"launches": v["launches"], "avg_us": 1e3 * v["ms"] / max(v["launches"], 1)} for k, v in ks.items()}
+    ks_all = kt_warm.summary() if a.warmup > 0 else ks
+    kernels = {k: {"launches": v["launches"], "avg_us": 1e3 * v["ms"] / max(v["launches"], 1)} for k, v in ks_all.items()}
+    kernels_note = f"HIP events around every entry point during the {a.warmup} warm-up steps; the timed steps time only the roofline kernel"
     gemm_flops = 3 * 2.0 * n * L * W * (C * nl) * C
-    hip_ms = sum(v["ms"] for v in ks.values()) / a.steps
+    hip_ms = sum(v["ms"] for v in ks_all.values()) / max(a.warmup, 1)
 
-    ck = ks.get("vfa_collapse_relu_sum_f32")
+    ck = ks_all.get("vfa_collapse_relu_sum_f32")
     if ck and ck["launches"]:
         # hand-written kernel: every fp32 product = 3 bf16 MFMA products of an exact hi/lo split, fp32 accumulation,
         # fused with bias + ReLU + view sum (inference, K = N = 256).  TFLOP/s below counts the fp32-equivalent flops.
@@ -206,8 +212,8 @@ def main():
                          "fp32_equivalent_tflops": gemm_flops / 3 / (ck["ms"] / ck["launches"] * 1e-3) / 1e12,
                          "bf16_mfma_tflops": gemm_flops / (ck["ms"] / ck["launches"] * 1e-3) / 1e12,
                          "max_rel_error_vs_fp64": "~3e-6 of max|out| (tests/test_hip_parity.py), tolerance 1e-5"}
-    elif ks.get("vfa_collapse_gemm_f32", {}).get("launches"):
-        cg = ks["vfa_collapse_gemm_f32"]
+    elif ks_all.get("vfa_collapse_gemm_f32", {}).get("launches"):
+        cg = ks_all["vfa_collapse_gemm_f32"]
         collapse_info = {"flops_per_step": gemm_flops, "backend": "vfa_collapse_gemm_f32 (K-looped 3xbf16-split MFMA tile GEMM, "
                          "fp32 accumulate) + epilogue kernels", "avg_us": 1e3 * cg["ms"] / cg["launches"],
                          "fp32_equivalent_tflops": gemm_flops / 3 / (cg["ms"] / cg["launches"] * 1e-3) / 1e12,
@@ -232,6 +238,7 @@ def main():
             "bev_cells_per_s": nl * L * W * a.steps / dt,
             "roofline": roofline,
             "kernels": kernels,
+            "kernels_note": kernels_note,
             "hip_kernel_ms_per_step": hip_ms,
             "collapse_gemm": collapse_info,
         }

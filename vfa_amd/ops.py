@@ -22,8 +22,11 @@ class KernelTimer:
     """
     active = None
 
-    def __init__(self):
+    def __init__(self, only=None):
+        """``only``: an iterable of entry-point names; other launches are not timed (each timed launch costs two event
+        records in the queue, ~3 us apiece on MI355X: 18 per frame slow a 0.9 ms frame by 6 %)."""
         self.records = []
+        self.only = None if only is None else frozenset(only)
 
     def __enter__(self):
         KernelTimer.active = self
@@ -47,7 +50,7 @@ class KernelTimer:
 
 def _launch(name, *args, tag=None):
     kt = KernelTimer.active
-    if kt is None:
+    if kt is None or (kt.only is not None and name not in kt.only):
         _lib.call(name, *args)
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
