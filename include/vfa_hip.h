@@ -63,6 +63,11 @@ int vfa_abi_version(void);
 /* Process-wide tuning switches (do not change results).  VFA_OPT_TAP_CACHE: 1 (default) = vfa_project_gather_f32 may
  * pool through the LDS tap cache by default (see VFA_VOX_KERNEL_*); 0 = the default is always the direct kernel. */
 #define VFA_OPT_TAP_CACHE 1
+/* VFA_OPT_RESERVED_CUS: the persistent MFMA kernels (vfa_collapse_relu_sum_f32, vfa_collapse_gemm_f32, one workgroup per
+ * CU with all of its LDS) launch on at most n_cu - value CUs (default 0) whenever that does not add a round of tiles
+ * to a launch.  Multi-GPU: leaves room for the RCCL kernels of the all-reduce that overlaps the next frame, which could
+ * otherwise only start at a kernel boundary. */
+#define VFA_OPT_RESERVED_CUS 2
 int vfa_set_option(int option, int value);
 
 /* Integral image of every feature map: cumsum over W then over H, double accumulator rounded to

@@ -704,3 +704,26 @@ def test_collapse_gemm_rejects_other_shapes():
     with pytest.raises(_lib.VFAHipError):
         ops.collapse_gemm(torch.zeros(8, 256, device=dev), torch.zeros(128, 256, device=dev))
     assert ops.collapse_gemm(torch.zeros(0, 256, device=dev), torch.zeros(256, 256, device=dev)).shape == (0, 256)
+
+
+def test_reserved_cus_option_leaves_results_unchanged():
+    """`VFA_OPT_RESERVED_CUS` (multi-GPU: room for concurrent RCCL kernels) only changes how many workgroups the
+    persistent MFMA kernels launch."""
+    from vfa_amd import _lib, ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(3)
+    vox = (torch.rand(3, 9000, 256, generator=gen) * (torch.rand(3, 9000, 1, generator=gen) > 0.3)).to(dev)
+    w = ((torch.rand(256, 256, generator=gen) - 0.5) * 0.125).to(dev)
+    b = ((torch.rand(256, generator=gen) - 0.5) * 0.125).to(dev)
+    wide = torch.rand(5000, 768, generator=gen).to(dev)
+    w3 = ((torch.rand(256, 768, generator=gen) - 0.5) * 0.07).to(dev)
+    base = ops.collapse_relu_sum(vox, w, b), ops.collapse_gemm(wide, w3)
+    try:
+        for n in (16, 200, 255, 1000):
+            ops.set_reserved_cus(n)
+            assert torch.equal(ops.collapse_relu_sum(vox, w, b), base[0])
+            assert torch.equal(ops.collapse_gemm(wide, w3), base[1])
+        with pytest.raises(_lib.VFAHipError):
+            ops.set_reserved_cus(-1)
+    finally:
+        ops.set_reserved_cus(0)

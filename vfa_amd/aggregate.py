@@ -22,6 +22,19 @@ from . import ops
 # pooling kernel of another.  Measured gain on MI355X: 4 % (the GEMM fills the chip), so the default stays 1 stream,
 # which also keeps per-kernel timings clean; VFA_AMD_STREAMS=3 enables the overlap.
 N_STREAMS = max(1, min(3, int(os.environ.get("VFA_AMD_STREAMS", "1"))))
+# Multi-GPU: the collapse kernels are persistent (one workgroup per CU holding all of its LDS), so an RCCL kernel queued
+# on another stream could only start at a kernel boundary.  With world_size > 1 they leave this many CUs free, which is
+# where the all-reduce of the previous frame runs while this frame is projected.  The library applies the reservation
+# only to launches whose number of tile rounds it does not increase, so it costs nothing.
+RESERVED_CUS = max(0, int(os.environ.get("VFA_AMD_RESERVED_CUS", "16")))
+_reserved_state = {"value": None}
+
+
+def _reserve_cus_for_collectives(active):
+    want = RESERVED_CUS if active else 0
+    if _reserved_state["value"] != want:
+        ops.set_reserved_cus(want)
+        _reserved_state["value"] = want
 _side_streams = {}
 
 
@@ -112,6 +125,9 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     """
     length, width = grid.shape[-3], grid.shape[-2]
     n = calibs.shape[0]
+    if grid.is_cuda:
+        _reserve_cus_for_collectives(bool(distributed) and dist.is_available() and dist.is_initialized()
+                                     and dist.get_world_size(reduce_group) > 1)
     work = ((vfa8, lat8), (vfa16, lat16), (vfa32, lat32))
     if n > 0 and all(m.mfma_collapse_ok(lat) for m, lat in work):
         # inference on single-layer grids: per scale, pooling then ONE MFMA kernel that forms collapse + bias + ReLU and

@@ -26,6 +26,8 @@
 
 #include "vfa_hip.h"
 
+extern __attribute__((visibility("hidden"))) int g_vfa_reserved_cus; // vfa_set_option(VFA_OPT_RESERVED_CUS)
+
 namespace {
 
 constexpr int kN = 256;          // output channels (the only width this kernel is built for)
@@ -236,7 +238,15 @@ extern "C" int vfa_collapse_gemm_f32(const float *vox, const float *weight, floa
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const long long n_tiles = ((long long)M + kTileRows - 1) / kTileRows;
-    const unsigned blocks = (unsigned)(n_tiles < n_cu ? n_tiles : n_cu);
+    // Persistent workgroups, one per CU: every workgroup walks `rounds` tiles; launch only as many as that takes (an even
+    // load, and the CUs a ragged last round would idle stay free).  VFA_OPT_RESERVED_CUS lowers the count further when
+    // that does not add a round.
+    long long rounds = (n_tiles + n_cu - 1) / n_cu;
+    if (g_vfa_reserved_cus > 0 && n_cu - g_vfa_reserved_cus >= 8 && (n_tiles + (n_cu - g_vfa_reserved_cus) - 1) / (n_cu - g_vfa_reserved_cus) == rounds)
+        n_cu -= g_vfa_reserved_cus;
+    long long wgs = (n_tiles + rounds - 1) / rounds;
+    if (wgs > n_cu) wgs = n_cu;
+    const unsigned blocks = (unsigned)wgs;
     if (terms == 4)
         hipLaunchKernelGGL((collapse_gemm_kernel<4>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, lin,
                            (long long)M, K);

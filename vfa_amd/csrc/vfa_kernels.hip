@@ -1675,6 +1675,9 @@ inline int launch_status() { return (int)hipGetLastError(); }
 
 // which pooling kernel vfa_project_gather_f32 uses for C = 256 (see vfa_set_option)
 int g_use_cached = 1;
+} // namespace
+__attribute__((visibility("hidden"))) int g_vfa_reserved_cus = 0; // VFA_OPT_RESERVED_CUS, read by the persistent MFMA kernels' launchers
+namespace {
 
 inline unsigned elementwise_blocks(size_t n_items)
 {
@@ -1761,6 +1764,11 @@ int vfa_abi_version(void) { return VFA_ABI_VERSION; }
 int vfa_set_option(int option, int value)
 {
     if (option == VFA_OPT_TAP_CACHE) { g_use_cached = value != 0; return 0; }
+    if (option == VFA_OPT_RESERVED_CUS) {
+        if (value < 0) return VFA_ERR_BAD_ARGUMENT;
+        g_vfa_reserved_cus = value;
+        return 0;
+    }
     return VFA_ERR_BAD_ARGUMENT;
 }
 

@@ -65,6 +65,11 @@ def set_tap_cache(enabled):
     _lib.call("vfa_set_option", 1, 1 if enabled else 0)
 
 
+def set_reserved_cus(n):
+    """The persistent MFMA kernels launch on n_cu - n CUs (0 = all): room for concurrent RCCL kernels in multi-GPU runs."""
+    _lib.call("vfa_set_option", 2, int(n))
+
+
 def integral_image(features):
     """(n,C,Hf,Wf) -> (n,Hf+2,Wf+2,C) zero-bordered channels-last integral images (reference vfa_op.py:172-173)."""
     _lib.require_device(features)
