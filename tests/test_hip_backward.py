@@ -11,11 +11,11 @@ import torch_reference as ref
 pytestmark = pytest.mark.gpu
 
 
-def _case(data, seed):
+def _case(data, seed, C=8):
     from vfa_amd.synthetic import ring_cameras
     from vfa_amd.utils import make_grid
     gen = torch.Generator().manual_seed(seed)
-    C, Hf, Wf = 8, 14, 22
+    Hf, Wf = 14, 22
     image_size = (14 * 8, 22 * 8)
     if data == "MultiviewC":
         grid = make_grid((700, 900), cube_LW=(50, 50), dataset=data)
@@ -33,14 +33,17 @@ def _case(data, seed):
     return dict(data=data, feature=feature, calib=calib, grid=grid, cube=cube, gh=gh, image_size=image_size, gen=gen)
 
 
-@pytest.mark.parametrize("data,seed", [("MultiviewC", 0), ("MultiviewC", 1), ("Wildtrack", 2), ("MultiviewX", 3)])
-def test_module_gradients_vs_float64_autograd(data, seed):
+@pytest.mark.parametrize("data,seed,C", [("MultiviewC", 0, 8), ("MultiviewC", 1, 8), ("Wildtrack", 2, 8), ("MultiviewX", 3, 8),
+                                         ("MultiviewC", 4, 256), ("Wildtrack", 5, 256)])
+def test_module_gradients_vs_float64_autograd(data, seed, C):
+    """C = 8: library GEMM + run-combined atomic scatter; C = 256: the MFMA tile GEMM in the forward (`_CollapseGemm`,
+    library products in its backward) and the LDS-privatised scatter."""
     import vfa_amd
     dev = torch.device("cuda:0")
-    c = _case(data, seed)
+    c = _case(data, seed, C)
     args = SimpleNamespace(data=data, image_size=c["image_size"])
     torch.manual_seed(seed)
-    mod = vfa_amd.VFA(8, grid_height=c["gh"], cube_size=c["cube"], args=args).to(dev)
+    mod = vfa_amd.VFA(C, grid_height=c["gh"], cube_size=c["cube"], args=args).to(dev)
     feat = c["feature"].to(dev).requires_grad_(True)
     out = mod(feat, c["calib"].to(dev), c["grid"].to(dev)[None])
     probe = torch.randn(out.shape, generator=c["gen"])
