@@ -6,9 +6,9 @@
         bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the hot path over one synthetic frame batch already resident in HBM: for each of the
-three feature scales the integral images of all local cameras, the fused projection + box-pooling kernel, the
-fp32 collapse GEMM, then the fused bias/ReLU/scale-sum/view-sum epilogue; with N > 1 ranks an RCCL all-reduce of
-the partial BEV map.  Unit of work ("voxel aggregated") = one (camera, scale, z-layer, BEV cell) box producing
+three feature scales the integral images of all local cameras, the fused projection + box-pooling kernel and the
+collapse (Linear + bias + ReLU + view sum: one hand-written MFMA kernel on single-layer grids, MFMA tile GEMM + epilogue
+kernel on multi-layer ones); with N > 1 ranks an RCCL all-reduce of the partial BEV map.  Unit of work ("voxel aggregated") = one (camera, scale, z-layer, BEV cell) box producing
 C = 256 channels.  Scaling is weak: every rank holds `n_cam` cameras of an N-times larger
 rig observing the same grid, and the grids are summed over ranks (camera-sharded data parallelism).
 
@@ -42,7 +42,8 @@ def parse():
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                    help="weak: n_cam cameras per rank; strong: the frame's cameras are split over ranks")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
-    p.add_argument("--tune-gemm", type=int, default=1, help="1: TunableOp selects the collapse GEMM kernel in warm-up")
+    p.add_argument("--tune-gemm", type=int, default=0,
+                   help="1: TunableOp selects the library GEMM in warm-up (only used with VFA_AMD_COLLAPSE=library)")
     return p.parse_args()
 
 
