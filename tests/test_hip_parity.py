@@ -28,12 +28,14 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def assert_bitwise(name, got, ref, zero_sign_free=False):
+def assert_bitwise(name, got, ref, zero_sign_free=False, nan_equal=False):
     got, ref = np.asarray(got, dtype=np.float32), np.asarray(ref, dtype=np.float32)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     eq = _bits(got) == _bits(ref)
     if zero_sign_free:
         eq |= (got == 0) & (ref == 0)
+    if nan_equal:  # NaN payload / sign is not part of the contract
+        eq |= np.isnan(got) & np.isnan(ref)
     assert eq.all(), f"{name}: {np.count_nonzero(~eq)} of {eq.size} elements differ bitwise " \
                      f"(max abs diff {np.nanmax(np.abs(got - ref))})"
 
@@ -727,3 +729,62 @@ def test_reserved_cus_option_leaves_results_unchanged():
             ops.set_reserved_cus(-1)
     finally:
         ops.set_reserved_cus(0)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_scenes_bitwise_vs_oracle(oracle, seed):
+    """Seeded random scenes: camera pose (some inside / below / looking away from the grid: points behind the camera,
+    NaN-free but wildly clamped boxes), focal length, feature size, channel count (C = 256 exercises both pooling
+    kernels), layers, dataset conversion and clamp range.  Integral image and voxel features must be bitwise the oracle's."""
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import look_at_camera
+    from vfa_amd.utils import make_grid
+    dev = _dev()
+    rng = np.random.default_rng(1000 + seed)
+    data = ("MultiviewC", "MultiviewX", "Wildtrack")[seed % 3]
+    C = int(rng.choice([1, 4, 7, 32, 256, 256]))
+    Hf, Wf = int(rng.integers(5, 48)), int(rng.integers(5, 80))
+    image_size = (int(rng.integers(200, 1100)), int(rng.integers(300, 2000)))  # (H, W) of the "original" image
+    nl = int(rng.integers(1, 5))
+    cells_l, cells_w = int(rng.integers(3, 30)), int(rng.integers(3, 40))
+    unit = {"MultiviewC": 1.0, "MultiviewX": 1 / 40.0, "Wildtrack": 2.5}[data]       # grid unit -> world unit
+    origin = {"Wildtrack": np.array([-300.0, -900.0, 0.0])}.get(data, np.zeros(3))
+    cube = (int(rng.integers(2, 40)), int(rng.integers(2, 40)), int(rng.integers(2, 40)))
+    world = (cells_l * cube[0], cells_w * cube[1])
+    grid = make_grid(world_size=world if data != "Wildtrack" else world[::-1], cube_LW=cube[:2], dataset=data)
+    ext = np.array([grid[..., 0].max().item(), grid[..., 1].max().item(), cube[2] * nl]) * unit
+    centre = origin + 0.5 * ext
+    kind = seed % 4
+    if kind == 0:    # outside, looking at the grid
+        pos = centre + np.array([1.5, 0.3, 0.0]) * ext.max() + np.array([0, 0, 0.8 * ext.max()])
+        target = centre
+    elif kind == 1:  # inside the grid volume, looking sideways: half of the boxes are behind the camera
+        pos = centre + np.array([0.05, -0.1, 0.2]) * ext
+        target = centre + np.array([1.0, 0.2, 0.0]) * ext
+    elif kind == 2:  # far away, long lens: boxes smaller than a feature pixel
+        pos = centre + np.array([-6.0, 5.0, 3.0]) * ext.max()
+        target = centre
+    else:            # below the ground plane, looking up through it
+        pos = centre + np.array([0.3, 0.3, -0.6]) * ext.max()
+        target = centre + np.array([0.0, 0.0, 0.5]) * ext.max()
+    focal = float(rng.uniform(0.3, 3.0)) * image_size[1]
+    calib = torch.tensor(look_at_camera(tuple(pos), tuple(target), focal, (image_size[1], image_size[0])), dtype=torch.float32)
+    crange = ((-1, 0.95), (-1, 0.95), (-0.8, 0.6), (-1.0, 1.0))[seed % 4]
+    feat = torch.from_numpy(rng.standard_normal((1, C, Hf, Wf)).astype(np.float32))
+    if seed % 2:
+        feat = feat.abs()
+    zl = oracle.z_layers_of(cube[2] * nl, cube)
+    co = oracle.corner_offsets(cube)
+    I = oracle.integral_image(feat[0].numpy())
+    box, area, vis = oracle.box_params(calib.numpy(), grid.numpy(), zl, co, data, image_size, Hf, Wf, crange=crange)
+    want = _to_layer_major(oracle.gather(I, box, area, vis), C, len(zl))
+    print(f"[scene {seed}] {data} C={C} {Hf}x{Wf} nl={nl} cells={grid.shape[0] * grid.shape[1]} camera kind {kind}: "
+          f"{vis.mean():.0%} of the boxes visible, {np.isnan(want).mean():.1%} NaN")
+    integral = ops.integral_image(feat.to(dev))
+    assert_bitwise("integral", integral.cpu().numpy()[0][1:-1, 1:-1].transpose(2, 0, 1), I)
+    for kernel in (("direct", "tap_cache") if C == 256 else ("direct",)):
+        got = ops.project_gather(integral, calib.reshape(1, 12).to(dev), grid.reshape(-1, 3).to(dev),
+                                 torch.from_numpy(zl).to(dev), torch.from_numpy(co).to(dev), _lib.CONV_KIND[data],
+                                 image_size[::-1], crange, kernel=kernel)
+        assert_bitwise(f"vox ({kernel}, {vis.mean():.0%} visible)", got.cpu().numpy()[0], want, zero_sign_free=True,
+                       nan_equal=True)
