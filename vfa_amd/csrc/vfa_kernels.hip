@@ -325,11 +325,37 @@ __device__ __forceinline__ float4 vbox_mean<4>(float4 lt, float4 rb, float4 rt, 
                        box_mean(lt.z, rb.z, rt.z, lb.z, area, rcp), box_mean(lt.w, rb.w, rt.w, lb.w, area, rcp));
 }
 
+// Unsigned 32-bit division by a launch constant as multiply-high + shifts (Granlund-Montgomery round-up form, exact
+// for every 32-bit dividend): the tile decomposition of the tap-cache kernels is wave-uniform SALU work at the head of
+// every tile's dependent chain, and hipcc's 64-bit '/' and '%' cost ~100 scalar instructions apiece there.
+struct FastDiv {
+    unsigned mul, sh1, sh2, d;
+};
+inline FastDiv make_fastdiv(unsigned d)
+{
+    FastDiv f;
+    f.d = d;
+    unsigned L = 0;
+    while (L < 32 && (1ull << L) < d) ++L; // ceil(log2 d)
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << L) - d)) / d + 1);
+    f.sh1 = L < 1 ? L : 1;
+    f.sh2 = L > 0 ? L - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv &f)
+{
+    const unsigned t = __umulhi(n, f.mul);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 struct GatherDims {
     int C, Hf, Wf, nl, n_cells, cell_begin, cell_count, vox_layout;
     long long n_boxes;    // n_views * cell_count * nl
     long long per_xcd;    // blocks per XCD
     int ws_chunk;         // two-kernel form: boxes per pooling wave (power of two <= 64)
+    // tap-cache kernels: tile = (view, cell block, layer), layer fastest
+    unsigned n_tiles;     // n_views * tiles_per_view
+    FastDiv tiles_per_view, layers;
 };
 
 // Per-box record staged in LDS by phase 1 of the gather kernel (32 words = 8 x ds_read_b128, broadcast to the wave).
@@ -643,15 +669,13 @@ __global__ __launch_bounds__(kWave) void gather_cached_kernel(const float *__res
     const int lane = threadIdx.x;
     // A tile is 8 consecutive CELLS of one (view, layer): neighbouring cells of a layer are the boxes that share taps.
     // Tiles are numbered (view, cell block, layer) so that tiles running side by side touch the same image columns.
-    const long long boxes_per_view = (long long)d.cell_count * d.nl;
-    const long long blocks_per_view = (d.cell_count + kCacheBoxes - 1) / kCacheBoxes;
-    const long long tiles_per_view = blocks_per_view * d.nl;
-    const long long tile = xcd_contiguous(blockIdx.x, d.per_xcd);
-    if (tile >= tiles_per_view * (d.n_boxes / boxes_per_view)) return;
-    const int view = (int)(tile / tiles_per_view);
-    const long long tv = tile % tiles_per_view;
-    const int layer = (int)(tv % d.nl);
-    const int cell0 = (int)(tv / d.nl) * kCacheBoxes; // first cell (local to the processed range) of the tile
+    const unsigned tile = (blockIdx.x & 7u) * (unsigned)d.per_xcd + (blockIdx.x >> 3); // xcd_contiguous, 32-bit
+    if (tile >= d.n_tiles) return;
+    const int view = (int)fast_div(tile, d.tiles_per_view);
+    const unsigned tv = tile - (unsigned)view * d.tiles_per_view.d;
+    const unsigned cb = fast_div(tv, d.layers);
+    const int layer = (int)(tv - cb * d.layers.d);
+    const int cell0 = (int)cb * kCacheBoxes; // first cell (local to the processed range) of the tile
     const int nb = min(kCacheBoxes, d.cell_count - cell0);
     const size_t img_stride = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C * sizeof(float);
     const char *img = reinterpret_cast<const char *>(integral) + (size_t)view * img_stride;
@@ -855,15 +879,13 @@ __global__ __launch_bounds__(kWave) void gather_backward_cached_kernel(const flo
     const int lane = threadIdx.x;
     // A tile is 8 consecutive CELLS of one (view, layer): neighbouring cells of a layer are the boxes that share taps.
     // Tiles are numbered (view, cell block, layer) so that tiles running side by side touch the same image columns.
-    const long long boxes_per_view = (long long)d.cell_count * d.nl;
-    const long long blocks_per_view = (d.cell_count + kCacheBoxes - 1) / kCacheBoxes;
-    const long long tiles_per_view = blocks_per_view * d.nl;
-    const long long tile = xcd_contiguous(blockIdx.x, d.per_xcd);
-    if (tile >= tiles_per_view * (d.n_boxes / boxes_per_view)) return;
-    const int view = (int)(tile / tiles_per_view);
-    const long long tv = tile % tiles_per_view;
-    const int layer = (int)(tv % d.nl);
-    const int cell0 = (int)(tv / d.nl) * kCacheBoxes; // first cell (local to the processed range) of the tile
+    const unsigned tile = (blockIdx.x & 7u) * (unsigned)d.per_xcd + (blockIdx.x >> 3); // xcd_contiguous, 32-bit
+    if (tile >= d.n_tiles) return;
+    const int view = (int)fast_div(tile, d.tiles_per_view);
+    const unsigned tv = tile - (unsigned)view * d.tiles_per_view.d;
+    const unsigned cb = fast_div(tv, d.layers);
+    const int layer = (int)(tv - cb * d.layers.d);
+    const int cell0 = (int)cb * kCacheBoxes; // first cell (local to the processed range) of the tile
     const int nb = min(kCacheBoxes, d.cell_count - cell0);
     const size_t img_stride = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C * sizeof(float);
     char *gimg = reinterpret_cast<char *>(grad_integral) + (size_t)view * img_stride;
@@ -1708,7 +1730,11 @@ int launch_gather(const float *integral, const float *box, const float *area, co
                                                                        : (g_use_cached && nl == 1);
     if (FUSED && C == 256 && vox_layout == VFA_VOX_LAYER_MAJOR && want_cached) {
         const long long tiles = (long long)n_views * nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes);
+        if (tiles >= (1ll << 31) - 8) return VFA_ERR_BAD_ARGUMENT; // chunk the cells (the host side does, by vox bytes)
         d.per_xcd = (tiles + 7) / 8;
+        d.n_tiles = (unsigned)tiles;
+        d.tiles_per_view = make_fastdiv((unsigned)(nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes)));
+        d.layers = make_fastdiv((unsigned)nl);
         hipLaunchKernelGGL(gather_cached_kernel, dim3((unsigned)(d.per_xcd * 8)), dim3(kWave), 0, s, integral, g, d, vox);
         return launch_status();
     }
@@ -1903,7 +1929,11 @@ int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, 
     if (d.n_boxes == 0) return 0;
     if (C == 256 && g_use_cached) {
         const long long tiles = (long long)n_views * nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes);
+        if (tiles >= (1ll << 31) - 8) return VFA_ERR_BAD_ARGUMENT;
         d.per_xcd = (tiles + 7) / 8;
+        d.n_tiles = (unsigned)tiles;
+        d.tiles_per_view = make_fastdiv((unsigned)(nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes)));
+        d.layers = make_fastdiv((unsigned)nl);
         hipLaunchKernelGGL(gather_backward_cached_kernel, dim3((unsigned)(d.per_xcd * 8)), dim3(kWave), 0, s, grad_vox, g, d,
                            grad_integral);
         return launch_status();
