@@ -230,6 +230,9 @@ def main():
             "unit": "voxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 in / out and fp32 accumulation everywhere; pre-GEMM stages bit-exact with the reference's CPU path; the "
+                          "collapse product forms each fp32 product from three bf16 MFMA products of an exact hi/lo split "
+                          "(error ~3e-6 of max|out|, tolerance 1e-5; VFA_AMD_COLLAPSE=library selects the fp32 library GEMM)",
             "config": {"workload": a.workload, "cameras_per_rank": n, "cameras_total": n * world if a.scaling == "weak"
                        else n_frame, "channels": C, "feature_maps": [list(s) for s in wl["feat_sizes"]],
                        "grid": [L, W, nl], "units_per_step": units_total,
