@@ -325,6 +325,17 @@ __device__ __forceinline__ float4 vbox_mean<4>(float4 lt, float4 rb, float4 rt, 
                        box_mean(lt.z, rb.z, rt.z, lb.z, area, rcp), box_mean(lt.w, rb.w, rt.w, lb.w, area, rcp));
 }
 
+// Voxel features are written once and read once by the next kernel: non-temporal stores keep their 287 MB per scale from
+// displacing the integral image in L2 / Infinity Cache and let the write-back overlap this (not bandwidth-bound) kernel
+// instead of the consumer's reads (pooling kernel 162 -> 144 us at stride 8; frame 0.86 -> 0.84 ms).
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nt(void *p, float4 v)
+{
+    nt_f32x4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<nt_f32x4 *>(p));
+}
+__device__ __forceinline__ void store_nt(void *p, float v) { __builtin_nontemporal_store(v, reinterpret_cast<float *>(p)); }
+
 // Unsigned 32-bit division by a launch constant as multiply-high + shifts (Granlund-Montgomery round-up form, exact
 // for every 32-bit dividend): the tile decomposition of the tap-cache kernels is wave-uniform SALU work at the head of
 // every tile's dependent chain, and hipcc's 64-bit '/' and '%' cost ~100 scalar instructions apiece there.
@@ -574,8 +585,8 @@ __global__ __launch_bounds__(256, 4) void gather_kernel(const float *__restrict_
 #pragma unroll 1
             for (int c = lane * VEC; c < d.C; c += kWave * VEC) {
                 if (layer_major) {
-                    if constexpr (VEC == 4) *reinterpret_cast<float4 *>(out + c * 4) = make_float4(z, z, z, z);
-                    else *reinterpret_cast<float *>(out + c * 4) = z;
+                    if constexpr (VEC == 4) store_nt(out + c * 4, make_float4(z, z, z, z));
+                    else store_nt(out + c * 4, z);
                 } else {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) reinterpret_cast<float *>(out)[(size_t)(c + k) * d.nl] = z;
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(256, 4) void gather_kernel(const float *__restrict_
             const BoxWeights w = recs[j + k].w;                                                                 \
             const V res = pool_patch<VEC, DY, DX>(P, w);                                                        \
             if (layer_major) {                                                                                  \
-                *reinterpret_cast<V *>(out0 + (size_t)k * c_bytes + lane_off) = res;                            \
+                store_nt(out0 + (size_t)k * c_bytes + lane_off, res);                                           \
             } else {                                                                                            \
                 float *o = vox + (size_t)uniform_i(w.out_row) * d.C * d.nl + uniform_i(w.layer);                \
                 const float *rs = reinterpret_cast<const float *>(&res);                                        \
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(kWave) void gather_cached_kernel(const float *__res
     if (__ballot(vis) == 0ull) { // nothing visible in the tile: eight masked rows, one 1 KiB store each
         for (int j = 0; j < nb; ++j) {
             const float z = __shfl(rec.h.masked, 8 * j);
-            *reinterpret_cast<float4 *>(out_tile + (size_t)j * box_pitch + lane * 16) = make_float4(z, z, z, z);
+            store_nt(out_tile + (size_t)j * box_pitch + lane * 16, make_float4(z, z, z, z));
         }
         return;
     }
@@ -827,7 +838,7 @@ __global__ __launch_bounds__(kWave) void gather_cached_kernel(const float *__res
                     const float z = rc.h.masked;
                     res = make_float4(z, z, z, z);
                 }
-                *reinterpret_cast<float4 *>(out_tile + (size_t)bb * box_pitch + q * kSliceBytes + cq * 16) = res;
+                store_nt(out_tile + (size_t)bb * box_pitch + q * kSliceBytes + cq * 16, res);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -854,7 +865,7 @@ __global__ __launch_bounds__(kWave) void gather_cached_kernel(const float *__res
             const float z = rc.h.masked;
             res = make_float4(z, z, z, z);
         }
-        *reinterpret_cast<float4 *>(out_tile + (size_t)j * box_pitch + lane_off) = res;
+        store_nt(out_tile + (size_t)j * box_pitch + lane_off, res);
     }
 }
 
