@@ -23,7 +23,8 @@ VFA_CASES = [
     "mc_nl1.npz", "wt_cam0_s8.npz", "wt_cam1_s32.npz", "wt_side_dense_s16.npz", "mx_cam0_s16.npz",
     "mx_cam1_s8.npz",
 ]
-VFANET_CASES = ["vfanet_mc.npz", "vfanet_wt.npz"]
+# *_nl1: single-layer grids at C = 256 (K = N = 256), the shape the flagship MFMA collapse kernels are built for
+VFANET_CASES = ["vfanet_mc.npz", "vfanet_wt.npz", "vfanet_mc_nl1.npz", "vfanet_wt_nl1.npz"]
 
 
 @pytest.fixture(scope="session")

@@ -215,5 +215,19 @@ def main():
                 ring_cameras(2, wt_c, 0.45 * 1440 * 2.5, 400.0, 1100.0, (1920, 1080)), (72, 128), 32)
 
 
+def main_nl1():
+    """Round-2 additions: single-layer grids at C = 256 (K = N = 256), the shape of BASELINE configs[1] / configs[2] --
+    the reference's own ``VFANet.forward`` output for the flagship MFMA collapse kernels."""
+    vfanet_case("vfanet_mc_nl1.npz", "MultiviewC", (720, 1280), (3750, 3750), (18.75, 18.75, 160), 160, (150, 125),
+                ring_cameras(3, (1875.0, 1875.0, 0.0), 2700.0, 600.0, 900.0, (1280, 720)), (96, 160), 41)
+    wt_c = (480 * 2.5 / 2 - 300.0, 1440 * 2.5 / 2 - 900.0, 0.0)
+    vfanet_case("vfanet_wt_nl1.npz", "Wildtrack", (1080, 1920), (480, 1440), (1, 1, 4), 4, (40, 90),
+                ring_cameras(2, wt_c, 0.45 * 1440 * 2.5, 400.0, 1100.0, (1920, 1080)), (72, 128), 42)
+
+
 if __name__ == "__main__":
-    main()
+    if "--nl1" in sys.argv:
+        main_nl1()
+    else:
+        main()
+        main_nl1()

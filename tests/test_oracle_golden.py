@@ -75,3 +75,23 @@ def test_oracle_make_grid(oracle):
                              dataset=name)
         assert g.shape == d[key].shape, key
         assert np.array_equal(g, d[key]), key
+
+
+def test_product_make_grid_matches_reference_fixture():
+    """The PRODUCT's ``vfa_amd.make_grid`` (host code, runs on CPU) against the reference's own outputs
+    (``vfa/utils.py:16-37``): bit-equal for the three dataset kinds, offsets and ragged sizes included."""
+    import torch
+    import vfa_amd
+    d = np.load(golden_path("make_grid.npz"))
+    n = 0
+    for key in d.files:
+        if key.endswith("_args"):
+            continue
+        a = d[key + "_args"]
+        name = key.split("_")[0]
+        g = vfa_amd.make_grid(world_size=(a[0], a[1]), cube_LW=[a[2], a[3]], grid_offset=(a[4], a[5], a[6]),
+                              dataset=name)
+        assert g.dtype == torch.float32 and tuple(g.shape) == d[key].shape, key
+        assert np.array_equal(g.numpy().view(np.uint32), d[key].view(np.uint32)), key
+        n += 1
+    assert n == 5
