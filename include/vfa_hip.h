@@ -9,7 +9,7 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm allocations in practice);
- *     the library allocates nothing, keeps no global state and is re-entrant;
+ *     the library allocates nothing, keeps no global state (every tuning choice is a per-call flag) and is re-entrant;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is stream-ordered
  *     and asynchronous, nothing synchronises the device;
  *   - return value: 0 on success, otherwise a hipError_t (launch failure) or VFA_ERR_* (bad argument);
@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VFA_ABI_VERSION 1
+#define VFA_ABI_VERSION 2
 
 /* world-unit conversion of the grid, reference vfa_op.py:23-44 (chosen by args.data) */
 #define VFA_CONV_MULTIVIEWC 0 /* x / 1.0                                   */
@@ -60,15 +60,17 @@ extern "C" {
 /* ABI version of the loaded library (VFA_ABI_VERSION at build time). */
 int vfa_abi_version(void);
 
-/* Process-wide tuning switches (do not change results).  VFA_OPT_TAP_CACHE: 1 (default) = vfa_project_gather_f32 may
- * pool through the LDS tap cache by default (see VFA_VOX_KERNEL_*); 0 = the default is always the direct kernel. */
-#define VFA_OPT_TAP_CACHE 1
-/* VFA_OPT_RESERVED_CUS: the persistent MFMA kernels (vfa_collapse_relu_sum_f32, vfa_collapse_gemm_f32, one workgroup per
- * CU with all of its LDS) launch on at most n_cu - value CUs (default 0) whenever that does not add a round of tiles
- * to a launch.  Multi-GPU: leaves room for the RCCL kernels of the all-reduce that overlaps the next frame, which could
- * otherwise only start at a kernel boundary. */
-#define VFA_OPT_RESERVED_CUS 2
-int vfa_set_option(int option, int value);
+/* Per-call `flags` of the MFMA collapse entry points (there is no process-wide state):
+ *   bits 0-3   number of bf16 product terms per fp32 product: 0 = default (3), 3, 4 (adds lo*lo)
+ *   bits 8-15  VFA_FLAG_RESERVED_CUS(n): the persistent kernels (one workgroup per CU with all of its LDS) launch on at
+ *              most n_cu - n CUs whenever that does not add a round of tiles.  Multi-GPU: leaves room for the RCCL
+ *              kernels of the all-reduce that overlaps the next frame, which could otherwise only start at a kernel
+ *              boundary.  Results are unchanged. */
+#define VFA_FLAG_TERMS_MASK 0xf
+#define VFA_FLAG_RESERVED_CUS(n) (((n) & 0xff) << 8)
+/* `flags` of vfa_project_gather_backward_f32: bit 0 = accumulate into grad_integral (otherwise it is zeroed first);
+ * VFA_VOX_KERNEL_DIRECT selects the per-box atomic kernel instead of the LDS-privatised one (C = 256). */
+#define VFA_BWD_ACCUMULATE 1
 
 /* Integral image of every feature map: cumsum over W then over H, double accumulator rounded to
  * fp32 at every element (what ATen's CPU cumsum does), written channels-last inside a zero border.
@@ -123,12 +125,12 @@ int vfa_project_gather_ws_f32(const float *integral, const float *calibs, const 
 
 /* Backward of vfa_project_gather_f32 with respect to the integral images (training: the reference back-propagates
  * through the path with autograd, trainer.py:41; calib and grid carry no gradient).  grad_vox is layer-major
- * (n_views, cell_count, nl*C); grad_integral (n_views, Hf+2, Wf+2, C) is zeroed first unless `accumulate`.
+ * (n_views, cell_count, nl*C); grad_integral (n_views, Hf+2, Wf+2, C) is zeroed first unless VFA_BWD_ACCUMULATE is set in `flags`.
  * Scatter-add with float atomics: results are not bit-reproducible run to run. */
 int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, const float *grid, const float *z_layers,
                                     const float *corner_off, float *grad_integral, int n_views, int C, int Hf, int Wf,
                                     int nl, int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w,
-                                    float img_h, float cmin, float cmax, int accumulate, void *stream);
+                                    float img_h, float cmin, float cmax, int flags, void *stream);
 
 /* Backward of vfa_integral_image_f32: reverse cumsum over H (in place on grad_integral, which is destroyed) then over
  * W, written as NCHW grad_feature (n_views, C, Hf, Wf). */
@@ -160,21 +162,21 @@ int vfa_scale_view_sum_f32(const float *lin8, const float *lin16, const float *l
  *   vox (n_views, M, K) layer-major; weight (N, K) = collapse.weight (layer-major columns; identical to the reference's
  *   for one layer); bias (N) or NULL; out (M, N).
  * fp32 in, fp32 out, fp32 accumulation; each fp32 product is formed from `terms` bf16 MFMA products of an exact
- * hi/lo split of both operands (3 = default when 0 is passed, 4 adds lo*lo): error ~5e-6 of max|out| (the fp32 library
+ * hi/lo split of both operands (`flags` bits 0-3: 3 = default when 0 is passed, 4 adds lo*lo): error ~5e-6 of max|out| (the fp32 library
  * GEMM: 1e-6), inside the 1e-4 / 1e-5 max tolerance of the path; not bitwise -- no GEMM order is.  Inf inputs give
  * NaN (Inf - Inf in the split).  Returns VFA_ERR_UNSUPPORTED for other K, N: use a GEMM + the epilogues above. */
 int vfa_collapse_relu_sum_f32(const float *vox, const float *weight, const float *bias, float *out, int n_views, size_t M,
-                              int K, int N, int accumulate, int terms, void *stream);
+                              int K, int N, int accumulate, int flags, void *stream);
 
 /* The `collapse` product alone for any layer count:  lin[m, :] = vox[m, :] . weight^T,  m < M = n_views * cells,
  * K = nl * C a multiple of 128, N = 256 (other shapes: VFA_ERR_UNSUPPORTED, use a library GEMM).  No bias, no ReLU: the
  * two epilogue entry points above add them while summing views.         replaces vfa_op.py:121-123 (nn.Linear)
- * Same arithmetic as vfa_collapse_relu_sum_f32 (bf16-split MFMA, fp32 accumulation, `terms` 0/3/4), as a K-looped
+ * Same arithmetic as vfa_collapse_relu_sum_f32 (bf16-split MFMA, fp32 accumulation, same `flags`), as a K-looped
  * 128-row tile GEMM.  `workspace`: vfa_collapse_gemm_workspace_bytes(K, N) bytes of caller-owned scratch (the weight,
  * split into bf16 planes in MFMA fragment order, rewritten by every call). */
 size_t vfa_collapse_gemm_workspace_bytes(int K, int N);
 int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, void *workspace, size_t workspace_bytes, size_t M,
-                          int K, int N, int terms, void *stream);
+                          int K, int N, int flags, void *stream);
 
 #ifdef __cplusplus
 }

@@ -134,17 +134,13 @@ def test_lds_scatter_matches_atomic_scatter_and_is_the_adjoint(workload, n_cam, 
     assert live.any()
     gvox = torch.where(live, gvox, torch.full_like(gvox, 1e30))  # masked voxels pass no gradient, whatever arrives
     grads = {}
-    try:
-        for name, on in (("lds", True), ("atomics", False)):
-            ops.set_tap_cache(on)
-            grads[name] = ops.project_gather_backward(gvox, tuple(integral.shape), calibs, grid, zl, co, kind, size,
-                                                      cell_begin=begin, cell_count=count)
-            twice = ops.project_gather_backward(gvox, tuple(integral.shape), calibs, grid, zl, co, kind, size,
-                                                cell_begin=begin, cell_count=count, out=grads[name].clone(),
-                                                accumulate=True)
-            torch.testing.assert_close(twice, 2 * grads[name], rtol=1e-4, atol=1e-5 * grads[name].abs().max().item())
-    finally:
-        ops.set_tap_cache(True)
+    for name, kern in (("lds", None), ("atomics", "direct")):  # a per-call flag of the entry point, no library state
+        grads[name] = ops.project_gather_backward(gvox, tuple(integral.shape), calibs, grid, zl, co, kind, size,
+                                                  cell_begin=begin, cell_count=count, kernel=kern)
+        twice = ops.project_gather_backward(gvox, tuple(integral.shape), calibs, grid, zl, co, kind, size,
+                                            cell_begin=begin, cell_count=count, out=grads[name].clone(),
+                                            accumulate=True, kernel=kern)
+        torch.testing.assert_close(twice, 2 * grads[name], rtol=1e-4, atol=1e-5 * grads[name].abs().max().item())
     scale = grads["atomics"].abs().max().item()
     assert scale > 0 and torch.isfinite(grads["lds"]).all()
     torch.testing.assert_close(grads["lds"], grads["atomics"], rtol=1e-4, atol=2e-5 * scale)

@@ -708,9 +708,9 @@ def test_collapse_gemm_rejects_other_shapes():
     assert ops.collapse_gemm(torch.zeros(0, 256, device=dev), torch.zeros(256, 256, device=dev)).shape == (0, 256)
 
 
-def test_reserved_cus_option_leaves_results_unchanged():
-    """`VFA_OPT_RESERVED_CUS` (multi-GPU: room for concurrent RCCL kernels) only changes how many workgroups the
-    persistent MFMA kernels launch."""
+def test_reserved_cus_flag_leaves_results_unchanged():
+    """`VFA_FLAG_RESERVED_CUS(n)` (multi-GPU: room for concurrent RCCL kernels) is a per-call flag that only changes how
+    many workgroups the persistent MFMA kernels launch."""
     from vfa_amd import _lib, ops
     dev = _dev()
     gen = torch.Generator().manual_seed(3)
@@ -720,15 +720,13 @@ def test_reserved_cus_option_leaves_results_unchanged():
     wide = torch.rand(5000, 768, generator=gen).to(dev)
     w3 = ((torch.rand(256, 768, generator=gen) - 0.5) * 0.07).to(dev)
     base = ops.collapse_relu_sum(vox, w, b), ops.collapse_gemm(wide, w3)
-    try:
-        for n in (16, 200, 255, 1000):
-            ops.set_reserved_cus(n)
-            assert torch.equal(ops.collapse_relu_sum(vox, w, b), base[0])
-            assert torch.equal(ops.collapse_gemm(wide, w3), base[1])
-        with pytest.raises(_lib.VFAHipError):
-            ops.set_reserved_cus(-1)
-    finally:
-        ops.set_reserved_cus(0)
+    for n in (16, 200, 255):
+        assert torch.equal(ops.collapse_relu_sum(vox, w, b, reserved_cus=n), base[0])
+        assert torch.equal(ops.collapse_gemm(wide, w3, reserved_cus=n), base[1])
+    assert torch.equal(ops.collapse_relu_sum(vox, w, b), base[0])  # and nothing sticks to the library
+    with pytest.raises(_lib.VFAHipError):  # unknown flag bits are refused
+        _lib.call("vfa_collapse_relu_sum_f32", _lib.ptr(vox), _lib.ptr(w), _lib.ptr(b), _lib.ptr(base[0].clone()), 3, 9000,
+                  256, 256, 0, 1 << 20, _lib.current_stream_handle())
 
 
 @pytest.mark.parametrize("seed", list(range(24)))

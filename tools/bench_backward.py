@@ -26,14 +26,13 @@ for s in range(3):
     gvox = torch.randn(n, grid.shape[0], zl.numel() * 256, device=dev)
     line = [f"stride {8 << s} ({Hf}x{Wf})"]
     for name, cache, dbg in modes:
-        ops.set_tap_cache(bool(cache))
         for _ in range(2):
-            ops.project_gather_backward(gvox, (n, Hf + 2, Wf + 2, 256), calibs, grid, zl, co, kind, size)
+            ops.project_gather_backward(gvox, (n, Hf + 2, Wf + 2, 256), calibs, grid, zl, co, kind, size, kernel=None if cache else 'direct')
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            ops.project_gather_backward(gvox, (n, Hf + 2, Wf + 2, 256), calibs, grid, zl, co, kind, size)
+            ops.project_gather_backward(gvox, (n, Hf + 2, Wf + 2, 256), calibs, grid, zl, co, kind, size, kernel=None if cache else 'direct')
         e1.record()
         torch.cuda.synchronize()
         line.append(f"{name} {e0.elapsed_time(e1) / 5 * 1e3:.0f} us")

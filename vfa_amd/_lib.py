@@ -8,18 +8,24 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvfa_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 CONV_KIND = {"MultiviewC": 0, "MultiviewX": 1, "Wildtrack": 2}
 VOX_REFERENCE, VOX_LAYER_MAJOR = 0, 1
 VOX_KERNEL_DIRECT, VOX_KERNEL_TAP_CACHE = 0x100, 0x200
+BWD_ACCUMULATE = 1
+
+
+def collapse_flags(terms=0, reserved_cus=0):
+    """`flags` of the MFMA collapse entry points: product terms (0 = default 3) | VFA_FLAG_RESERVED_CUS(n)."""
+    return (int(terms) & 0xf) | ((int(reserved_cus) & 0xff) << 8)
+
 
 _c_int, _c_float, _c_size_t, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 
 # name -> argtypes; must list every symbol include/vfa_hip.h declares (tests/test_abi.py checks it)
 SIGNATURES = {
     "vfa_abi_version": [],
-    "vfa_set_option": [_c_int, _c_int],
     "vfa_integral_image_f32": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_box_params_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _c_int,
                            _c_float, _c_float, _vp, _vp, _vp, _vp],

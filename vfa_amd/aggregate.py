@@ -26,15 +26,7 @@ N_STREAMS = max(1, min(3, int(os.environ.get("VFA_AMD_STREAMS", "1"))))
 # on another stream could only start at a kernel boundary.  With world_size > 1 they leave this many CUs free, which is
 # where the all-reduce of the previous frame runs while this frame is projected.  The library applies the reservation
 # only to launches whose number of tile rounds it does not increase, so it costs nothing.
-RESERVED_CUS = max(0, int(os.environ.get("VFA_AMD_RESERVED_CUS", "16")))
-_reserved_state = {"value": None}
-
-
-def _reserve_cus_for_collectives(active):
-    want = RESERVED_CUS if active else 0
-    if _reserved_state["value"] != want:
-        ops.set_reserved_cus(want)
-        _reserved_state["value"] = want
+RESERVED_CUS = max(0, min(255, int(os.environ.get("VFA_AMD_RESERVED_CUS", "16"))))
 _side_streams = {}
 
 
@@ -86,6 +78,37 @@ class _AllReduceSum(torch.autograd.Function):
         return grad, None
 
 
+PREHEAD_PREFIXES = ("base.", "lat8.", "lat16.", "lat32.", "bn8.", "bn16.", "bn32.", "vfa8.", "vfa16.", "vfa32.")
+
+
+def all_reduce_prehead_grads(module, group=None, prefixes=PREHEAD_PREFIXES):
+    """Camera-sharded TRAINING (``VFANet.forward(..., distributed=True)``): call after ``loss.backward()`` and before
+    ``optimizer.step()``.
+
+    Every rank back-propagates the same loss through the same fused map, so ``_AllReduceSum.backward`` hands each rank
+    the full dL/d(map) and the heads' gradients are already identical everywhere.  The parameters in FRONT of the
+    all-reduce (backbone ``base``, laterals ``lat*`` / ``bn*``, projectors ``vfa*``) were only exercised by the local
+    cameras, so their gradients are partial sums: this SUMs them over ranks (not a mean -- DistributedDataParallel's
+    averaging would scale them by 1/world against the heads; a rank with no camera contributes zeros).  Without it
+    the replicas diverge.  Returns the number of tensors reduced."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return 0
+    params = [p for n, p in module.named_parameters() if p.requires_grad and n.startswith(tuple(prefixes))]
+    for p in params:
+        if p.grad is None:  # e.g. the rank of an 8-GPU job that holds none of the 7 cameras
+            p.grad = torch.zeros_like(p)
+    if not params:
+        return 0
+    flat = torch.cat([p.grad.reshape(-1) for p in params])  # one bucket: a single collective over xGMI
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+    return len(params)
+
+
 def all_reduce_ortho(ortho_nhwc, group=None):
     """Sum the partial BEV maps of all ranks in place (RCCL over xGMI; backend string "nccl" on ROCm)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -125,9 +148,9 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     """
     length, width = grid.shape[-3], grid.shape[-2]
     n = calibs.shape[0]
-    if grid.is_cuda:
-        _reserve_cus_for_collectives(bool(distributed) and dist.is_available() and dist.is_initialized()
-                                     and dist.get_world_size(reduce_group) > 1)
+    # a per-call flag of the MFMA entry points (include/vfa_hip.h: VFA_FLAG_RESERVED_CUS), no library state
+    reserved = RESERVED_CUS if (bool(distributed) and dist.is_available() and dist.is_initialized()
+                                and dist.get_world_size(reduce_group) > 1) else 0
     work = ((vfa8, lat8), (vfa16, lat16), (vfa32, lat32))
     if n > 0 and all(m.mfma_collapse_ok(lat) for m, lat in work):
         # inference on single-layer grids: per scale, pooling then ONE MFMA kernel that forms collapse + bias + ReLU and
@@ -135,10 +158,10 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
         # inside the post-GEMM tolerance)
         ortho = torch.empty((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
         for i, (m, lat) in enumerate(work):
-            m.project_sum(lat, calibs, grid, crange, out=ortho, accumulate=i > 0)
+            m.project_sum(lat, calibs, grid, crange, out=ortho, accumulate=i > 0, reserved_cus=reserved)
     elif n > 0:
         if N_STREAMS == 1 or not grid.is_cuda:
-            lins = [m.project_views(lat, calibs, grid, crange) for m, lat in work]
+            lins = [m.project_views(lat, calibs, grid, crange, reserved_cus=reserved) for m, lat in work]
         else:
             main = torch.cuda.current_stream(grid.device)
             side = _streams(grid.device)
@@ -148,7 +171,7 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
                 if st is not main:
                     st.wait_stream(main)  # the inputs (and last step's consumers of recycled memory) are ready
                 with torch.cuda.stream(st):
-                    lins.append(m.project_views(lat, calibs, grid, crange))
+                    lins.append(m.project_views(lat, calibs, grid, crange, reserved_cus=reserved))
                 if st is not main:
                     lins[-1].record_stream(main)
             for st in side:

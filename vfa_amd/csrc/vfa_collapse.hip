@@ -24,7 +24,6 @@
 
 #include "vfa_hip.h"
 
-extern __attribute__((visibility("hidden"))) int g_vfa_reserved_cus; // vfa_set_option(VFA_OPT_RESERVED_CUS)
 
 namespace {
 
@@ -246,8 +245,10 @@ __global__ __launch_bounds__(kThreads) void collapse_relu_sum_kernel(const float
 } // namespace
 
 extern "C" int vfa_collapse_relu_sum_f32(const float *vox, const float *weight, const float *bias, float *out, int n_views,
-                                         size_t M, int K, int N, int accumulate, int terms, void *stream)
+                                         size_t M, int K, int N, int accumulate, int flags, void *stream)
 {
+    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
+    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xff00)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || K <= 0 || N <= 0 || (terms != 0 && terms != 3 && terms != 4)) return VFA_ERR_BAD_ARGUMENT;
     if (K != kK || N != kN) return VFA_ERR_UNSUPPORTED;
     if (M == 0) return 0;
@@ -275,11 +276,11 @@ extern "C" int vfa_collapse_relu_sum_f32(const float *vox, const float *weight, 
     }
     const long long n_tiles = ((long long)M + kRows - 1) / kRows;
     // Persistent workgroups, one per CU: every workgroup walks `rounds` tiles; launch only as many as that takes (an even
-    // load, and the CUs a ragged last round would idle stay free).  VFA_OPT_RESERVED_CUS lowers the count further when
+    // load, and the CUs a ragged last round would idle stay free).  VFA_FLAG_RESERVED_CUS(n) lowers the count further when
     // that does not add a round.
     long long rounds = (n_tiles + n_cu - 1) / n_cu;
-    if (g_vfa_reserved_cus > 0 && n_cu - g_vfa_reserved_cus >= 8 && (n_tiles + (n_cu - g_vfa_reserved_cus) - 1) / (n_cu - g_vfa_reserved_cus) == rounds)
-        n_cu -= g_vfa_reserved_cus;
+    if (reserved_cus > 0 && n_cu - reserved_cus >= 8 && (n_tiles + (n_cu - reserved_cus) - 1) / (n_cu - reserved_cus) == rounds)
+        n_cu -= reserved_cus;
     long long wgs = (n_tiles + rounds - 1) / rounds;
     if (wgs > n_cu) wgs = n_cu;
     const unsigned blocks = (unsigned)wgs;

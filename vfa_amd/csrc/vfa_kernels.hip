@@ -532,8 +532,10 @@ __device__ __forceinline__ void stage_box_records(BoxRec *recs, long long tile0,
         // Runs of boxes with one tap set: lanes are consecutive boxes, a wave's chunk in phase 2 is `chunk` of them.
         // cont = "this box continues the run of the previous lane"; run_len counts the set bits that follow.
         const int tag = (view << 5) | rc.h.flags;
-        const bool cont = vis && (lane & (chunk - 1)) != 0 && __shfl_up(tag, 1) == tag &&
-                          __shfl_up(key_x, 1) == key_x && __shfl_up(key_y, 1) == key_y;
+        // shuffles first, unconditionally: behind a short-circuit a neighbour that skipped the shuffle would read as 0
+        const int tag_prev = __shfl_up(tag, 1);
+        const unsigned kx_prev = __shfl_up(key_x, 1), ky_prev = __shfl_up(key_y, 1);
+        const bool cont = vis && (lane & (chunk - 1)) != 0 && tag_prev == tag && kx_prev == key_x && ky_prev == key_y;
         const unsigned long long mask = __ballot(cont);
         const unsigned long long after = lane == 63 ? 0ull : (mask >> (lane + 1));
         const int follow = after == ~0ull ? 64 : __builtin_ctzll(~after);
@@ -1278,8 +1280,9 @@ __global__ __launch_bounds__(64 * (4 + kProducers)) void fused_collapse_kernel(c
                 if (!valid) { rc.h.flags = 0; rc.h.masked = 0.0f; }
                 tag = valid ? rc.h.flags : (-1 - lane);
             }
-            const bool cont = vis && lane != 0 && lane < kRowsPerProducer && __shfl_up(tag, 1) == tag &&
-                              __shfl_up(key_x, 1) == key_x && __shfl_up(key_y, 1) == key_y;
+            const int tag_prev = __shfl_up(tag, 1); // unconditional: see stage_box_records
+            const unsigned kx_prev = __shfl_up(key_x, 1), ky_prev = __shfl_up(key_y, 1);
+            const bool cont = vis && lane != 0 && lane < kRowsPerProducer && tag_prev == tag && kx_prev == key_x && ky_prev == key_y;
             const unsigned long long mask = __ballot(cont);
             const unsigned long long after = lane == 63 ? 0ull : (mask >> (lane + 1));
             const int follow = after == ~0ull ? 64 : __builtin_ctzll(~after);
@@ -1706,11 +1709,6 @@ __global__ __launch_bounds__(256) void relu_mask_backward_kernel(const float *__
 
 inline int launch_status() { return (int)hipGetLastError(); }
 
-// which pooling kernel vfa_project_gather_f32 uses for C = 256 (see vfa_set_option)
-int g_use_cached = 1;
-} // namespace
-__attribute__((visibility("hidden"))) int g_vfa_reserved_cus = 0; // VFA_OPT_RESERVED_CUS, read by the persistent MFMA kernels' launchers
-namespace {
 
 inline unsigned elementwise_blocks(size_t n_items)
 {
@@ -1738,7 +1736,7 @@ int launch_gather(const float *integral, const float *box, const float *area, co
     // single-layer grids, about equal on the multi-layer dataset configs -> cached for nl == 1 unless told otherwise
     const bool want_cached = kernel_choice == VFA_VOX_KERNEL_TAP_CACHE ? true
                              : kernel_choice == VFA_VOX_KERNEL_DIRECT  ? false
-                                                                       : (g_use_cached && nl == 1);
+                                                                       : nl == 1;
     if (FUSED && C == 256 && vox_layout == VFA_VOX_LAYER_MAJOR && want_cached) {
         const long long tiles = (long long)n_views * nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes);
         if (tiles >= (1ll << 31) - 8) return VFA_ERR_BAD_ARGUMENT; // chunk the cells (the host side does, by vox bytes)
@@ -1797,17 +1795,6 @@ int launch_gather_ws(const float *integral, const float *box, const float *area,
 extern "C" {
 
 int vfa_abi_version(void) { return VFA_ABI_VERSION; }
-
-int vfa_set_option(int option, int value)
-{
-    if (option == VFA_OPT_TAP_CACHE) { g_use_cached = value != 0; return 0; }
-    if (option == VFA_OPT_RESERVED_CUS) {
-        if (value < 0) return VFA_ERR_BAD_ARGUMENT;
-        g_vfa_reserved_cus = value;
-        return 0;
-    }
-    return VFA_ERR_BAD_ARGUMENT;
-}
 
 
 int vfa_integral_image_f32(const float *feature, float *integral, int n_views, int C, int Hf, int Wf, void *stream)
@@ -1919,8 +1906,10 @@ int vfa_project_collapse_f32(const float *integral, const float *calibs, const f
 int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, const float *grid, const float *z_layers,
                                     const float *corner_off, float *grad_integral, int n_views, int C, int Hf, int Wf,
                                     int nl, int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w,
-                                    float img_h, float cmin, float cmax, int accumulate, void *stream)
+                                    float img_h, float cmin, float cmax, int flags, void *stream)
 {
+    const int accumulate = flags & VFA_BWD_ACCUMULATE;
+    if (flags & ~(VFA_BWD_ACCUMULATE | VFA_VOX_KERNEL_DIRECT | VFA_VOX_KERNEL_TAP_CACHE)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0 || nl <= 0 || n_cells < 0 || cell_begin < 0 || cell_count < 0 ||
         cell_begin + cell_count > n_cells || conv_kind < 0 || conv_kind > 2)
         return VFA_ERR_BAD_ARGUMENT;
@@ -1938,7 +1927,7 @@ int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, 
     d.cell_count = cell_count; d.vox_layout = VFA_VOX_LAYER_MAJOR;
     d.n_boxes = (long long)n_views * cell_count * nl;
     if (d.n_boxes == 0) return 0;
-    if (C == 256 && g_use_cached) {
+    if (C == 256 && !(flags & VFA_VOX_KERNEL_DIRECT)) {
         const long long tiles = (long long)n_views * nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes);
         if (tiles >= (1ll << 31) - 8) return VFA_ERR_BAD_ARGUMENT;
         d.per_xcd = (tiles + 7) / 8;

@@ -60,16 +60,6 @@ def _launch(name, *args, tag=None):
     kt.records.append((name, e0, e1, tag))
 
 
-def set_tap_cache(enabled):
-    """Choose the pooling kernel of ``project_gather`` for C = 256: LDS tap cache (default) or the direct kernel."""
-    _lib.call("vfa_set_option", 1, 1 if enabled else 0)
-
-
-def set_reserved_cus(n):
-    """The persistent MFMA kernels launch on n_cu - n CUs (0 = all): room for concurrent RCCL kernels in multi-GPU runs."""
-    _lib.call("vfa_set_option", 2, int(n))
-
-
 def integral_image(features):
     """(n,C,Hf,Wf) -> (n,Hf+2,Wf+2,C) zero-bordered channels-last integral images (reference vfa_op.py:172-173)."""
     _lib.require_device(features)
@@ -210,8 +200,9 @@ def project_gather_ws(integral, calibs, grid_flat, z_layers, corner_off, conv_ki
 
 
 def project_gather_backward(grad_vox, integral_shape, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh,
-                            crange=(-1, 0.95), cell_begin=0, cell_count=None, out=None, accumulate=False):
-    """d vox (n, cell_count, nl*C) layer-major -> d integral (n, Hf+2, Wf+2, C) by scatter-add (float atomics)."""
+                            crange=(-1, 0.95), cell_begin=0, cell_count=None, out=None, accumulate=False, kernel=None):
+    """d vox (n, cell_count, nl*C) layer-major -> d integral (n, Hf+2, Wf+2, C) by scatter-add (float atomics).
+    ``kernel="direct"`` selects the per-box atomic kernel instead of the LDS-privatised one (C = 256)."""
     _lib.require_device(grad_vox, calibs, grid_flat, z_layers, corner_off, out)
     n, Hp, Wp, C = integral_shape
     n_cells, nl = grid_flat.shape[0], z_layers.numel()
@@ -223,7 +214,8 @@ def project_gather_backward(grad_vox, integral_shape, calibs, grid_flat, z_layer
     _launch("vfa_project_gather_backward_f32", _lib.ptr(grad_vox), _lib.ptr(calibs), _lib.ptr(grid_flat),
             _lib.ptr(z_layers), _lib.ptr(corner_off), _lib.ptr(out), n, C, Hp - 2, Wp - 2, nl, n_cells, cell_begin,
             cell_count, int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]),
-            1 if accumulate else 0, _lib.current_stream_handle())
+            (_lib.BWD_ACCUMULATE if accumulate else 0) | (_lib.VOX_KERNEL_DIRECT if kernel == "direct" else 0),
+            _lib.current_stream_handle())
     return out
 
 
@@ -278,7 +270,7 @@ def scale_view_sum(lin8, lin16, lin32, b8, b16, b32, out=None, accumulate=False)
     return out
 
 
-def collapse_relu_sum(vox, weight, bias, out=None, accumulate=False, terms=0):
+def collapse_relu_sum(vox, weight, bias, out=None, accumulate=False, terms=0, reserved_cus=0):
     """out (M,N) (+)= sum_v relu(vox[v] @ weight.T + bias) in one bf16-split MFMA kernel (K = N = 256 only; reference
     vfa_op.py:121-124 + vfanet.py:82).  Raises ``VFAHipError`` (VFA_ERR_UNSUPPORTED) for other shapes."""
     _lib.require_device(vox, weight, bias, out)
@@ -291,14 +283,15 @@ def collapse_relu_sum(vox, weight, bias, out=None, accumulate=False, terms=0):
         out = torch.empty((M, N), dtype=torch.float32, device=vox.device)
         accumulate = False
     _launch("vfa_collapse_relu_sum_f32", _lib.ptr(vox), _lib.ptr(weight), _lib.ptr(bias),
-            _lib.ptr(out), n, M, K, N, 1 if accumulate else 0, int(terms), _lib.current_stream_handle())
+            _lib.ptr(out), n, M, K, N, 1 if accumulate else 0, _lib.collapse_flags(terms, reserved_cus),
+            _lib.current_stream_handle())
     return out
 
 
 _gemm_ws = {}
 
 
-def collapse_gemm(vox2d, weight, out=None, terms=0):
+def collapse_gemm(vox2d, weight, out=None, terms=0, reserved_cus=0):
     """lin (M,N) = vox2d (M,K) @ weight (N,K).T as a bf16-split MFMA tile GEMM (N = 256, K a multiple of 128; reference
     vfa_op.py:121-123 without bias).  Raises ``VFAHipError`` (VFA_ERR_UNSUPPORTED) for other shapes."""
     _lib.require_device(vox2d, weight, out)
@@ -314,5 +307,5 @@ def collapse_gemm(vox2d, weight, out=None, terms=0):
     if ws is None or ws.numel() < need:  # one scratch buffer per (device, stream): calls on a stream are ordered
         ws = _gemm_ws[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=vox2d.device)
     _launch("vfa_collapse_gemm_f32", _lib.ptr(vox2d), _lib.ptr(weight), _lib.ptr(out), _lib.ptr(ws), ws.numel(), M, K, N,
-            int(terms), _lib.current_stream_handle(), tag=(M, K, N))
+            _lib.collapse_flags(terms, reserved_cus), _lib.current_stream_handle(), tag=(M, K, N))
     return out

@@ -93,9 +93,9 @@ class _CollapseGemm(torch.autograd.Function):
     (``vfa_collapse_gemm_f32``); backward: the two fp32 library products."""
 
     @staticmethod
-    def forward(ctx, vox2d, weight):
+    def forward(ctx, vox2d, weight, reserved_cus=0):
         ctx.save_for_backward(vox2d, weight)
-        return ops.collapse_gemm(vox2d, weight, terms=COLLAPSE_TERMS)
+        return ops.collapse_gemm(vox2d, weight, terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
 
     @staticmethod
     def backward(ctx, grad):
@@ -103,7 +103,7 @@ class _CollapseGemm(torch.autograd.Function):
         grad = grad.contiguous()
         g_vox = torch.matmul(grad, weight) if ctx.needs_input_grad[0] else None
         g_w = torch.matmul(grad.t(), vox2d) if ctx.needs_input_grad[1] else None
-        return g_vox, g_w
+        return g_vox, g_w, None
 
 
 def mfma_gemm_ok(K, N):
@@ -168,7 +168,7 @@ class VFA(nn.Module):
         return w.view(out_c, self.channel, self.num_grid_layer).permute(0, 2, 1).reshape(out_c, -1)
 
     # ------------------------------------------------------------------ batched projector
-    def project_views(self, features, calibs, grid, crange=(-1, 0.95)):
+    def project_views(self, features, calibs, grid, crange=(-1, 0.95), reserved_cus=0):
         """All cameras of one scale at once.
 
         features (n,C,Hf,Wf), calibs (n,3,4), grid (1,L,W,3) or (L,W,3)  ->  lin (n, L*W, C_out) =
@@ -205,7 +205,7 @@ class VFA(nn.Module):
             count = min(chunk, n_cells - begin)
             vox = _BoxPool.apply(integral, calibs, grid_flat, z_layers, corner_off, geom, begin, count)
             if use_mfma:
-                lin = _CollapseGemm.apply(vox.view(n * count, nl * C), w_lm.contiguous())
+                lin = _CollapseGemm.apply(vox.view(n * count, nl * C), w_lm.contiguous(), reserved_cus)
             else:
                 lin = torch.matmul(vox.view(n * count, nl * C), w_lm.t())
             outs.append(lin.view(n, count, -1))
@@ -220,7 +220,7 @@ class VFA(nn.Module):
         params = (self.collapse.weight, self.collapse.bias) + (() if features is None else (features,))
         return not any(p is not None and p.requires_grad for p in params)
 
-    def project_sum(self, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False):
+    def project_sum(self, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0):
         """Inference path of one scale, all cameras: ``out (L*W, C_out) (+)= sum_v relu(collapse(vox_v))``.
 
         Integral images -> projection + pooling (HIP) -> `collapse` + bias + ReLU + view sum in ONE MFMA kernel
@@ -253,7 +253,7 @@ class VFA(nn.Module):
                 vox = ops.project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h),
                                          (float(crange[0]), float(crange[1])), cell_begin=begin, cell_count=count)
                 ops.collapse_relu_sum(vox, weight, self.collapse.bias, out=out[begin:begin + count],
-                                      accumulate=accumulate, terms=COLLAPSE_TERMS)
+                                      accumulate=accumulate, terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
         return out
 
     # ------------------------------------------------------------------ reference interface

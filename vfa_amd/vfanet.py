@@ -9,12 +9,53 @@ per-camera computation of the reference.
 Multi-GPU (``distributed=True``): each rank runs backbone + laterals + projection for ITS cameras
 (``camera_shard``) and the partial BEV maps are summed with one RCCL all-reduce; heads run replicated.
 """
+import glob
+import os
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .aggregate import aggregate_views, camera_shard
 from .vfa_op import VFA
+
+# ``pretrained=True`` (the default of the reference's train.py:90): the reference downloads the torchvision ImageNet
+# checkpoint (resnet.py:155-159, 170-172).  There is no network on the MI355X boxes, so the file is looked up locally.
+PRETRAINED_ENV = "VFA_AMD_PRETRAINED"
+
+
+def _find_pretrained(base):
+    cand = [os.environ.get(PRETRAINED_ENV)] if os.environ.get(PRETRAINED_ENV) else []
+    hub = os.path.join(os.environ.get("TORCH_HOME", os.path.join(os.path.expanduser("~"), ".cache", "torch")), "hub",
+                       "checkpoints")
+    cand += sorted(glob.glob(os.path.join(hub, f"{base}-*.pth")))
+    for path in cand:
+        if path and os.path.isdir(path):
+            hits = sorted(glob.glob(os.path.join(path, f"{base}*.pth")))
+            path = hits[0] if hits else None
+        if path and os.path.isfile(path):
+            return path
+    return None
+
+
+def load_pretrained_trunk(trunk, base):
+    """Reference ``_load_pretrained`` (resnet.py:170-175): copy every checkpoint entry whose key exists in the trunk
+    (conv weights and the affine parameters the GroupNorm layers share with torchvision's BatchNorm by NAME; running
+    statistics have no counterpart).  Returns the number of tensors loaded; warns and keeps the random initialisation
+    when no local checkpoint is found."""
+    path = _find_pretrained(base)
+    if path is None:
+        warnings.warn(f"VFANet(pretrained=True): no local {base} ImageNet checkpoint (set {PRETRAINED_ENV} to the .pth "
+                      "file or its directory, or place it in the torch hub cache); continuing from random "
+                      "initialisation -- this box has no network to download it like the reference does")
+        return 0
+    ckpt = torch.load(path, map_location="cpu")
+    own = trunk.state_dict()
+    hit = {k: v for k, v in ckpt.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
+    own.update(hit)
+    trunk.load_state_dict(own)
+    return len(hit)
 
 
 def _gn(ch):
@@ -78,10 +119,10 @@ class VFANet(nn.Module):
         super().__init__()
         assert base in _DEPTHS, f"Unrecognized model, expect `resnet18` or `resnet34`, got {base}."
         assert mode in ("2D", "3D"), f"mode error, expect `2D` or `3D`, got{mode}"
-        if pretrained:
-            raise RuntimeError("pretrained ImageNet weights need a download; load a state_dict instead")
         self.mode = mode
         self.base = _Trunk(_DEPTHS[base])
+        if pretrained:
+            load_pretrained_trunk(self.base, base)
         for s in (8, 16, 32):
             setattr(self, f"vfa{s}", VFA(channel=256, grid_height=grid_height, cube_size=cube_size, feat_scale=1. / s,
                                          args=args))
@@ -116,9 +157,34 @@ class VFANet(nn.Module):
     def forward(self, images, calibs, grid, visualize=False, visualize_ortho=False, distributed=False):
         """images (N,3,iH,iW), calibs (N,3,4), grid (1,L,W,3) -> dict like the reference (vfanet.py:141-149)."""
         if visualize or visualize_ortho:
-            raise NotImplementedError("the matplotlib side paths of the reference are not part of the MI355X build; "
-                                      "use VFA.visualize_cube for the box overlay")
+            self._visualize(images, calibs, grid, boxes=visualize_ortho)
         topdown = self.ortho_features(images, calibs, grid, distributed)
+        return self.heads(topdown)
+
+    def _visualize(self, images, calibs, grid, boxes=False):
+        """Slow matplotlib side path (reference vfanet.py:84-128): per camera, the norms of the three lateral maps, of
+        that camera's BEV contribution and of the running fused map; ``boxes`` also draws the projected cubes
+        (``VFA.visualize_cube``, reference vfa_op.py:90-101)."""
+        import matplotlib.pyplot as plt
+        with torch.no_grad():
+            lats = self.laterals(images)
+            fused = 0
+            for cam in range(images.shape[0]):
+                one = [l[cam:cam + 1] for l in lats]
+                part = aggregate_views(self.vfa8, self.vfa16, self.vfa32, *one, calibs[cam:cam + 1], grid)
+                fused = fused + part
+                fig, axes = plt.subplots(1, 5, figsize=(15, 3))
+                for ax, t, title in zip(axes, one + [part, fused], ("feat8", "feat16", "feat32", "ortho", "fused ortho")):
+                    ax.imshow(torch.norm(t, dim=1)[0].cpu().numpy())
+                    ax.set_title(f"C{cam + 1} {title}")
+                    ax.axis("off")
+                plt.show()
+                plt.close(fig)
+                if boxes:
+                    self.vfa8.visualize_cube(one[0], calibs[cam], grid)
+
+    def heads(self, topdown):
+        """The BEV heads on the fused map (reference vfanet.py:131-149)."""
         fused = self.fuse(topdown)
         out = {"heatmap": self.map_classifier(fused), "loc_offset": self.tytx_pred(topdown).permute(0, 2, 3, 1)}
         if self.mode == "3D":
