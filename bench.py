@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the multiview feature -> voxel projection + aggregation path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                   # 1 GPU, BASELINE.json configs[1]
+    python bench.py --gpus N [--steps K --warmup W]   # N > 1 without torchrun: bench.py spawns the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        # or under a launcher (RANK / LOCAL_RANK / WORLD_SIZE in the env)
 
-One step = one pass of the hot path over one synthetic frame batch already resident in HBM: for each of the
-three feature scales the integral images of all local cameras, the fused projection + box-pooling kernel and the
-collapse (Linear + bias + ReLU + view sum: one hand-written MFMA kernel on single-layer grids, MFMA tile GEMM + epilogue
-kernel on multi-layer ones); with N > 1 ranks an RCCL all-reduce of the partial BEV map.  Unit of work ("voxel aggregated") = one (camera, scale, z-layer, BEV cell) box producing
-C = 256 channels.  Scaling is weak: every rank holds `n_cam` cameras of an N-times larger
-rig observing the same grid, and the grids are summed over ranks (camera-sharded data parallelism).
+One step = one pass of the hot path over one synthetic frame already resident in HBM: for each of the three feature
+scales the integral images of the local cameras, projection + box pooling and the collapse (Linear + bias + ReLU + view
+sum); with N > 1 ranks an RCCL all-reduce of the partial BEV map.  Unit of work ("voxel aggregated") = one (camera,
+scale, z-layer, BEV cell) box producing C = 256 channels.
+
+Workload and scaling.  The primary line is `multiviewc_200x200x1` (BASELINE.json configs[1]: 7 cameras 1280x720 -> the
+37.5 m x 37.5 m grid) at EVERY N, so the driver's per-N values compare like with like.  N > 1 defaults to STRONG
+scaling, the north-star partitioning: the 7 cameras of each frame are sharded over the ranks (one camera per GPU at
+N >= 7; a rank without a camera contributes zeros), the partial maps are fused by one RCCL all-reduce over xGMI, frames
+are streamed and the all-reduce of frame i overlaps the projection of frame i+1.  The same line also carries
+`scaling_curve_c5`: BASELINE.json configs[4] (`synthetic4k_512x512x32`, 8 cameras x 4K, one camera per GPU at N = 8),
+measured the same way with fewer steps -- the configuration on which >= 6x at 8 GPUs is attainable.
+`--scaling weak` (every rank a full rig, grids summed) is kept as an option.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,66 +33,248 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 FP32_MFMA_PEAK_TFLOPS = 157.3
+PRIMARY = "multiviewc_200x200x1"
+C5 = "synthetic4k_512x512x32"
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
-    p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="multiviewc_200x200x1",
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--workload", default=PRIMARY,
                    help="named workload of vfa_amd.synthetic.WORKLOADS (default: BASELINE.json configs[1])")
     p.add_argument("--channels", type=int, default=256)
-    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                   help="weak: n_cam cameras per rank; strong: the frame's cameras are split over ranks")
-    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 disables)")
+    p.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                   help="strong (default for N > 1): the frame's cameras are split over ranks; weak: n_cam cameras per rank")
+    p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables)")
+    p.add_argument("--c5-steps", type=int, default=3, help="timed steps of the synthetic4k_512x512x32 leg (0 disables)")
+    p.add_argument("--rotate", type=int, default=4, help="input sets of the rotating-input leg (0 disables)")
+    p.add_argument("--fp32-steps", type=int, default=20, help="timed steps of the fp32-arithmetic collapse leg (0 disables)")
     p.add_argument("--tune-gemm", type=int, default=0,
                    help="1: TunableOp selects the library GEMM in warm-up (only used with VFA_AMD_COLLAPSE=library)")
     return p.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` without a launcher.  The parent never touches the GPU (no torch.cuda call, no
+# exec of a GPU-initialised process); it starts N fresh children, relays rank 0's JSON line and returns their status.
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(wl, budget_s):
-    """The CPU oracle (a port of the reference's arithmetic, oracle/vfa_oracle.c) timed on this box's host cores on a
-    bounded sample of the same workload.  Baseline only -- never the thing shipped or measured as `value`."""
-    import numpy as np
+    """the torch-op CPU restatement of the reference path (oracle/torch_reference.py: the reference's
+    own op sequence, bit-identical pre-GEMM to the reference's run -- tests/test_oracle_golden.py) timed on this box's
+    host cores with every thread and with one thread, on a bounded sample of the same frame.  Baseline only -- never
+    the thing shipped or measured as `value`."""
+    import torch
+    from oracle import torch_reference as tr
     from oracle import vfa_oracle as oracle
-    oracle.build()
     cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     C = wl["channels"]
-    nl = len(oracle.z_layers_of(wl["grid_height"], wl["cube_size"]))
-    rng = np.random.default_rng(0)
-    w = (rng.standard_normal((C, C * nl)) * 0.02).astype(np.float32)
-    b = np.zeros(C, np.float32)
-    grid = wl["grid"][0].cpu().numpy()
-    units, t0, cams = 0, time.perf_counter(), 0
-    for cam in range(wl["n_cam"]):
-        for s in range(3):
-            f = wl["features"][cam][s][0].cpu().numpy()
-            oracle.vfa_forward(f, wl["calibs"][cam].cpu().numpy(), grid, w, b, wl["args"].data, wl["args"].image_size,
-                               wl["cube_size"], wl["grid_height"])
-            units += nl * grid.shape[0] * grid.shape[1]
-        cams += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": units / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": f"{cams} of {wl['n_cam']} cameras x 3 scales of the same frame ({units} box-units, {dt:.1f} s), "
-                      f"oracle/vfa_oracle.c with OpenMP on {cores} host threads"}
+    zl = torch.from_numpy(oracle.z_layers_of(wl["grid_height"], wl["cube_size"]))
+    co = torch.from_numpy(oracle.corner_offsets(wl["cube_size"]))
+    nl = zl.numel()
+    gen = torch.Generator().manual_seed(0)
+    ws = {s: (torch.rand(C, C * nl, generator=gen) - 0.5) * 0.1 for s in (8, 16, 32)}
+    bs = {s: torch.zeros(C) for s in (8, 16, 32)}
+    grid = wl["grid"][0].cpu()
+    L, W = grid.shape[:2]
+    cams_have = [c for c in range(wl["n_cam"]) if wl["features"][c] is not None]
+    lats = {s: torch.cat([wl["features"][c][i] if wl["features"][c] is not None else
+                          torch.zeros_like(wl["features"][cams_have[0]][i]) for c in range(wl["n_cam"])]).cpu()
+            for i, s in enumerate((8, 16, 32))}
+    calibs = wl["calibs"].cpu()
+
+    def run(threads, budget):
+        torch.set_num_threads(threads)
+        done, t0 = 0, time.perf_counter()
+        with torch.no_grad():
+            for cam in cams_have:
+                tr.vfanet_aggregate(lats, calibs, grid, ws, bs, zl, co, wl["args"].data, wl["args"].image_size,
+                                    cameras=[cam])
+                done += 1
+                if time.perf_counter() - t0 > budget:
+                    break
+        dt = time.perf_counter() - t0
+        return done * 3 * nl * L * W / dt, done, dt
+
+    prev = torch.get_num_threads()
+    try:
+        run(cores, 0.0)  # warm the allocator / thread pool on one camera
+        v_all, n_all, t_all = run(cores, 0.6 * budget_s)
+        v_one, n_one, t_one = run(1, 0.4 * budget_s)
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": v_all, "unit": "voxels/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "one_thread_value": v_one,
+            "sample": f"torch-op restatement of the reference path (oracle/torch_reference.py, torch {torch.__version__} CPU, "
+                      f"fp32, no_grad): {n_all} of {wl['n_cam']} cameras x 3 scales of the same frame with {cores} threads "
+                      f"({t_all:.1f} s), {n_one} camera(s) x 3 scales with 1 thread ({t_one:.1f} s)"}
+
+
+class Leg:
+    """One workload on this rank: inputs in HBM, the three projector modules, a step function and its timing."""
+
+    def __init__(self, name, a, rank, world, dev, scaling, rotate=1):
+        import torch
+        import torch.distributed as dist
+        import vfa_amd
+        from vfa_amd.synthetic import WORKLOADS, make_workload
+        self.torch, self.dist, self.vfa_amd = torch, dist, vfa_amd
+        self.name, self.world, self.rank, self.dev, self.scaling = name, world, rank, dev, scaling
+        n_frame = WORKLOADS[name]["n_cam"]
+        self.cams = list(range(n_frame)) if scaling == "weak" else vfa_amd.camera_shard(n_frame, rank, world)
+        seeds = [rank * 100 + k for k in range(max(rotate, 1))] if scaling == "weak" else list(range(max(rotate, 1)))
+        self.sets = []
+        wl = None
+        for seed in seeds:
+            wl = make_workload(name, channels=a.channels, seed=seed, cameras=self.cams)
+            self.sets.append([torch.cat([wl["features"][c][s] for c in self.cams]).to(dev) if self.cams else
+                              torch.zeros((0, a.channels) + tuple(wl["feat_sizes"][s]), device=dev) for s in range(3)])
+        self.wl = wl
+        n = len(self.cams)
+        self.calibs = wl["calibs"][torch.tensor(self.cams, dtype=torch.long)].to(dev)
+        self.grid = wl["grid"].to(dev)
+        torch.manual_seed(0)
+        self.mods = [vfa_amd.VFA(a.channels, grid_height=wl["grid_height"], cube_size=wl["cube_size"], feat_scale=1 / 8.,
+                                 args=wl["args"]).to(dev) for _ in range(3)]
+        self.L, self.W = self.grid.shape[1:3]
+        self.nl = self.mods[0].num_grid_layer
+        self.n_frame = n_frame
+        self.units_step = (n * world if scaling == "weak" else n_frame) * 3 * self.nl * self.L * self.W
+        # N > 1: the all-reduce of frame i is launched asynchronously and overlaps the projection of frame i+1 (one map
+        # in flight); every collective completes inside the timed region.  VFA_BENCH_SYNC_REDUCE=1 reduces synchronously.
+        self.overlap = world > 1 and os.environ.get("VFA_BENCH_SYNC_REDUCE", "0") != "1"
+        self.pending = []
+        self.k = 0
+
+    def step(self):
+        torch, vfa_amd = self.torch, self.vfa_amd
+        lats = self.sets[self.k % len(self.sets)]
+        self.k += 1
+        with torch.no_grad():
+            if not self.overlap:
+                return vfa_amd.aggregate_views(*self.mods, *lats, self.calibs, self.grid, distributed=self.world > 1)
+            while self.pending:
+                self.pending.pop().wait()  # frame i-1 is fused before frame i's collective is queued
+            self.pending.append(vfa_amd.aggregate_views(*self.mods, *lats, self.calibs, self.grid, distributed="async"))
+
+    def drain(self):
+        while self.pending:
+            self.pending.pop().wait()
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, timer=None):
+        """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        torch = self.torch
+        self.drain()
+        self.fence()
+        ctx = timer if timer is not None else _Null()
+        with ctx:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.drain()
+            self.fence()
+            dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+# entry point -> the kernel that does the work, for the roofline label
+KERNEL_NAMES = {"vfa_project_gather_f32": {"tap_cache": "gather_cached_kernel", "direct": "gather_kernel<4, true>"}}
+
+
+def roofline_of(ks, ops, workload):
+    """Roofline of the pooling kernel (HBM-bound by SURVEY.md 8d): algorithmic bytes of one launch = integral images read
+    once + voxel features written once + grid + calibs; achieved = those bytes / mean launch time from HIP events
+    recorded on the launch stream inside the timed loop."""
+    g = ks.get("vfa_project_gather_f32", dict(launches=0, ms=0.0, by_tag={}))
+    if not g["launches"]:
+        return None
+    alg_bytes = 0
+    for (nv, Ct, Hf, Wf, nlt, cells), rec in g["by_tag"].items():
+        alg_bytes += rec["launches"] * (nv * Ct * Hf * Wf * 4 + nv * nlt * cells * Ct * 4 + cells * 12 + nv * 48)
+    chosen = sorted(set(ops._gather_choice.values())) or ["default"]
+    kname = KERNEL_NAMES["vfa_project_gather_f32"]
+    traffic, src = None, None
+    for tag in ("r02", "r01"):
+        tpath = os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")
+        if workload == PRIMARY and os.path.exists(tpath) and len(chosen) == 1 and chosen[0] in kname:
+            for name, rec in json.load(open(tpath))["kernels"].items():
+                if kname[chosen[0]] in name:
+                    traffic, src = rec["hbm_bytes_per_dispatch"], f"profiles/{tag}_pmc_traffic.json"
+            if traffic is not None:
+                break
+    avg_ms = g["ms"] / g["launches"]
+    achieved = alg_bytes / g["launches"] / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "vfa_project_gather_f32: " + "/".join(kname.get(c, c) for c in chosen) +
+            " (picked per shape on first use)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": (src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                               "tools/pmc_to_traffic.py; not measured in this run)") if src else None,
+            "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes / g["launches"],
+            "launches": g["launches"]}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and rank == 0:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to record a run of the wrong size",
+              file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     # functional test hook for 1-GPU boxes: all ranks on device 0 with gloo (VFA_BENCH_BACKEND=gloo); never used for numbers
     backend = os.environ.get("VFA_BENCH_BACKEND", "nccl")
@@ -97,117 +288,82 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
     import vfa_amd
-    from vfa_amd import ops
-    from vfa_amd.synthetic import make_workload
+    from vfa_amd import ops, vfa_op
 
     torch.backends.cuda.matmul.allow_tf32 = False
     if a.tune_gemm:
-        # let PyTorch's TunableOp pick the rocBLAS / hipBLASLt solution for the three collapse products during warm-up
-        # (fp32 in, fp32 accumulate either way; +6 % step throughput on MI355X).  Results stay in this process only.
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(True)
         torch.cuda.tunable.set_max_tuning_duration(200)
         torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"vfa_tunableop_{rank}.csv"))
-    wl = make_workload(a.workload, channels=a.channels, seed=rank)
-    n_frame = wl["n_cam"]
-    cams = list(range(n_frame)) if a.scaling == "weak" else vfa_amd.camera_shard(n_frame, rank, world)
-    n = len(cams)
-    idx = torch.tensor(cams, dtype=torch.long)
-    lats = [torch.cat([wl["features"][c][s] for c in cams]).to(dev) if n else
-            torch.zeros((0, a.channels) + tuple(wl["feat_sizes"][s]), device=dev) for s in range(3)]
-    calibs = wl["calibs"][idx].to(dev)
-    grid = wl["grid"].to(dev)
-    torch.manual_seed(0)
-    mods = [vfa_amd.VFA(a.channels, grid_height=wl["grid_height"], cube_size=wl["cube_size"], feat_scale=1 / 8.,
-                        args=wl["args"]).to(dev) for _ in range(3)]
-    L, W = grid.shape[1:3]
-    nl = mods[0].num_grid_layer
-    C = a.channels
-    units_rank = n * 3 * nl * L * W
-    units_total = units_rank * world if a.scaling == "weak" else n_frame * 3 * nl * L * W
+    scaling = a.scaling or ("strong" if world > 1 else "weak")  # at N = 1 the two coincide; "weak" per the contract
 
-    # N > 1: the all-reduce of frame i is launched asynchronously and overlaps the projection of frame i+1 (one map in
-    # flight); every collective completes inside the timed region.  VFA_BENCH_SYNC_REDUCE=1 reduces synchronously.
-    overlap = world > 1 and os.environ.get("VFA_BENCH_SYNC_REDUCE", "0") != "1"
-    pending = []
-
-    def step():
-        with torch.no_grad():
-            if not overlap:
-                return vfa_amd.aggregate_views(*mods, *lats, calibs, grid, distributed=world > 1)
-            while pending:
-                pending.pop().wait()  # frame i-1 is fused before frame i's collective is queued
-            pending.append(vfa_amd.aggregate_views(*mods, *lats, calibs, grid, distributed="async"))
-
-    def drain():
-        while pending:
-            pending.pop().wait()
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    step()  # one-off set-up outside warm-up and timing: GEMM kernel selection (TunableOp) and pooling-kernel choice
-    drain()
+    leg = Leg(a.workload, a, rank, world, dev, scaling)
+    leg.step()  # one-off set-up outside warm-up and timing: kernel selection per problem shape
+    leg.drain()
     # Warm-up steps: HIP events around EVERY entry point (the `kernels` table).  Timed steps: only around the roofline
-    # kernel -- each timed launch puts two event records in the queue (~3 us apiece), and timing all nine launches
-    # of a frame slowed the 0.9 ms frame by 6 %.
+    # kernel -- each timed launch puts two event records in the queue (~3 us apiece).
     with ops.KernelTimer() as kt_warm:
         for _ in range(a.warmup):
-            step()
-        drain()
-        fence()
-    with ops.KernelTimer(only=("vfa_project_gather_f32",)) as kt:
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        drain()
-        fence()
-        dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-
+            leg.step()
+        leg.drain()
+        leg.fence()
+    kt = ops.KernelTimer(only=("vfa_project_gather_f32",))
+    dt = leg.timed(a.steps, kt)
     ks = kt.summary()
-    # roofline of the dominant hand-written kernel: fused projection + box pooling (HBM-bound).
-    # algorithmic bytes of one launch = integral images read once + voxel features written once + grid + calibs
-    g = ks.get("vfa_project_gather_f32", dict(launches=0, ms=0.0, by_tag={}))
-    alg_bytes = 0
-    for (nv, Ct, Hf, Wf, nlt, cells), rec in g["by_tag"].items():
-        alg_bytes += rec["launches"] * (nv * Ct * Hf * Wf * 4 + nv * nlt * cells * Ct * 4 + cells * 12 + nv * 48)
-    # HBM traffic of that kernel from the PMC counters: collected by separate `rocprofv3 --pmc FETCH_SIZE` /
-    # `--pmc WRITE_SIZE` passes over this same command (tools/pmc_to_traffic.py, summary committed under profiles/)
-    traffic = None
-    chosen = sorted(set(ops._gather_choice.values())) or ["default"]
-    kname = {"tap_cache": "gather_cached_kernel", "direct": "gather_kernel<4, true>"}
-    tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if a.workload == "multiviewc_200x200x1" and os.path.exists(tpath) and len(chosen) == 1 and chosen[0] in kname:
-        for name, rec in json.load(open(tpath))["kernels"].items():
-            if kname[chosen[0]] in name:
-                traffic = rec["hbm_bytes_per_dispatch"]
-    roofline = None
-    if g["launches"]:
-        avg_ms = g["ms"] / g["launches"]
-        achieved = alg_bytes / g["launches"] / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "vfa_project_gather_f32: " + "/".join(kname.get(c, c) for c in chosen) +
-                    " (picked per shape on first use)", "achieved": achieved,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes / g["launches"],
-                    "launches": g["launches"]}
+    roofline = roofline_of(ks, ops, a.workload)
     ks_all = kt_warm.summary() if a.warmup > 0 else ks
     kernels = {k: {"launches": v["launches"], "avg_us": 1e3 * v["ms"] / max(v["launches"], 1)} for k, v in ks_all.items()}
-    kernels_note = f"HIP events around every entry point during the {a.warmup} warm-up steps; the timed steps time only the roofline kernel"
-    gemm_flops = 3 * 2.0 * n * L * W * (C * nl) * C
     hip_ms = sum(v["ms"] for v in ks_all.values()) / max(a.warmup, 1)
+    n, L, W, nl, C = len(leg.cams), leg.L, leg.W, leg.nl, a.channels
+    gemm_flops = 3 * 2.0 * n * L * W * (C * nl) * C
+
+    extra = {}
+    # ---- same frame stream with ROTATING inputs: `--rotate` distinct lateral sets (4 x 135 MB > the 256 MB Infinity
+    # Cache), so no step re-reads the laterals of the previous one from the cache
+    if a.rotate > 1 and a.steps > 0:
+        rot = Leg(a.workload, a, rank, world, dev, scaling, rotate=a.rotate)
+        rot.mods = leg.mods
+        for _ in range(max(a.rotate, 3)):
+            rot.step()
+        dtr = rot.timed(a.steps)
+        extra["rotating_inputs"] = {"sets": a.rotate, "ms_per_step": 1e3 * dtr / a.steps,
+                                    "value": rot.units_step * a.steps / dtr,
+                                    "note": "the primary value re-reads the same lateral maps every step (what a frame "
+                                            "stream sees when the backbone has just written them); this leg rotates "
+                                            f"{a.rotate} distinct input sets through HBM"}
+        del rot
+    # ---- the same step with fp32 arithmetic in `collapse` (library fp32 GEMM + epilogue kernels): the default forms each
+    # fp32 product from three bf16 MFMA products, which is narrower than the reference's sgemm
+    if a.fp32_steps > 0 and vfa_op.COLLAPSE_KERNEL != "library":
+        saved = vfa_op.COLLAPSE_KERNEL
+        vfa_op.COLLAPSE_KERNEL = "library"
+        try:
+            for _ in range(3):
+                leg.step()
+            dtf = leg.timed(a.fp32_steps)
+        finally:
+            vfa_op.COLLAPSE_KERNEL = saved
+        extra["collapse_fp32_ms_per_step"] = 1e3 * dtf / a.fp32_steps
+        extra["collapse_fp32_value"] = leg.units_step * a.fp32_steps / dtf
+    # ---- BASELINE.json configs[4]: synthetic 8 x 4K -> 512 x 512 x 32, cameras sharded over the ranks
+    if a.c5_steps > 0 and a.workload == PRIMARY and a.channels == 256:
+        c5 = Leg(C5, a, rank, world, dev, "strong")
+        c5.step()
+        c5.drain()
+        dt5 = c5.timed(a.c5_steps)
+        extra["scaling_curve_c5"] = {"workload": C5, "n_gpus": world, "steps": a.c5_steps, "scaling": "strong",
+                                     "cameras_per_rank": len(c5.cams), "cameras_total": c5.n_frame,
+                                     "grid": [c5.L, c5.W, c5.nl], "units_per_step": c5.units_step,
+                                     "ms_per_step": 1e3 * dt5 / a.c5_steps, "value": c5.units_step * a.c5_steps / dt5,
+                                     "unit": "voxels/s", "ortho_bytes": c5.L * c5.W * 256 * 4}
+        del c5
 
     ck = ks_all.get("vfa_collapse_relu_sum_f32")
     if ck and ck["launches"]:
-        # hand-written kernel: every fp32 product = 3 bf16 MFMA products of an exact hi/lo split, fp32 accumulation,
-        # fused with bias + ReLU + view sum (inference, K = N = 256).  TFLOP/s below counts the fp32-equivalent flops.
         collapse_info = {"flops_per_step": gemm_flops, "backend": "vfa_collapse_relu_sum_f32 (3xbf16-split MFMA, fp32 "
                          "accumulate, fused bias+ReLU+view sum)", "avg_us": 1e3 * ck["ms"] / ck["launches"],
                          "fp32_equivalent_tflops": gemm_flops / 3 / (ck["ms"] / ck["launches"] * 1e-3) / 1e12,
@@ -226,28 +382,33 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "voxels aggregated/sec (7 views->BEV grid)", "value": units_total * a.steps / dt,
+            "metric": "voxels aggregated/sec (7 views->BEV grid)", "value": leg.units_step * a.steps / dt,
             "unit": "voxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 in / out and fp32 accumulation everywhere; pre-GEMM stages bit-exact with the reference's CPU path; the "
                           "collapse product forms each fp32 product from three bf16 MFMA products of an exact hi/lo split "
-                          "(error ~3e-6 of max|out|, tolerance 1e-5; VFA_AMD_COLLAPSE=library selects the fp32 library GEMM)",
-            "config": {"workload": a.workload, "cameras_per_rank": n, "cameras_total": n * world if a.scaling == "weak"
-                       else n_frame, "channels": C, "feature_maps": [list(s) for s in wl["feat_sizes"]],
-                       "grid": [L, W, nl], "units_per_step": units_total,
-                       "parallelism": (f"camera-sharded dp{world}, RCCL all-reduce of the BEV map"
-                                       + (" overlapped with the next frame" if overlap else "")) if world > 1
+                          "(error ~3e-6 of max|out|, tolerance 1e-5); `collapse_fp32_ms_per_step` is the same step with the "
+                          "fp32 library GEMM",
+            "config": {"workload": a.workload, "cameras_per_rank": n,
+                       "cameras_total": n * world if scaling == "weak" else leg.n_frame, "channels": C,
+                       "feature_maps": [list(s) for s in leg.wl["feat_sizes"]], "grid": [L, W, nl],
+                       "units_per_step": leg.units_step,
+                       "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                       "parallelism": (f"camera-sharded dp{world} ({scaling}), RCCL all-reduce of the BEV map"
+                                       + (" overlapped with the next frame" if leg.overlap else "")) if world > 1
                        else "single GPU"},
             "bev_cells_per_s": nl * L * W * a.steps / dt,
             "roofline": roofline,
             "kernels": kernels,
-            "kernels_note": kernels_note,
+            "kernels_note": f"HIP events around every entry point during the {a.warmup} warm-up steps; the timed steps "
+                            "time only the roofline kernel",
             "hip_kernel_ms_per_step": hip_ms,
             "collapse_gemm": collapse_info,
         }
+        out.update(extra)
         if world == 1 and a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(leg.wl, a.cpu_seconds)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

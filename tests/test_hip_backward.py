@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-import torch_reference as ref
+from oracle import torch_reference as ref
 
 pytestmark = pytest.mark.gpu
 

@@ -675,7 +675,8 @@ def test_mfma_collapse_path_matches_library_path_and_float64(name, monkeypatch):
     torch.testing.assert_close(s[:cells].double(), want, rtol=RTOL, atol=ATOL_REL * scale)
 
 
-@pytest.mark.parametrize("M,K,terms", [(128, 128, 3), (1000, 1280, 3), (4097, 2048, 4), (31, 256, 0), (8192 + 17, 768, 3)])
+@pytest.mark.parametrize("M,K,terms", [(128, 128, 3), (1000, 1280, 3), (4097, 2048, 4), (31, 256, 0), (8192 + 17, 768, 3),
+                                       (2500, 8192, 3)])  # K = 8192: BASELINE configs[4] (32 layers x 256 channels)
 def test_collapse_gemm_kernel_matches_float64(M, K, terms):
     """`vfa_collapse_gemm_f32` (K-looped bf16-split MFMA tile GEMM, N = 256) against the float64 product at the path's
     post-GEMM tolerance: ragged last tile, masked (all-zero) rows, several chunk counts."""
@@ -696,6 +697,34 @@ def test_collapse_gemm_kernel_matches_float64(M, K, terms):
     w2 = torch.flip(w, dims=(0,))
     got2 = ops.collapse_gemm(vox.to(dev), w2.to(dev), terms=terms)
     torch.testing.assert_close(got2.cpu().double(), vox.double() @ w2.double().T, rtol=RTOL, atol=ATOL_REL * scale)
+
+
+@pytest.mark.parametrize("K", [256, 2048, 8192])
+def test_collapse_kernels_heavy_tailed_operands(K):
+    """Adversarial operands for the bf16-split arithmetic: Student-t (2 d.o.f.) weights and log-normal voxel features, so a
+    few huge terms dominate each dot product and every dropped low-order term is as large as it can be relative to the
+    rest.  The bar is the path's post-GEMM tolerance against the float64 product; the measured share of it is printed."""
+    from vfa_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(K)
+    M = 3000
+    z = torch.randn(256, K, generator=gen)
+    chi = (torch.randn(256, K, generator=gen) ** 2 + torch.randn(256, K, generator=gen) ** 2) / 2
+    w = (z / chi.sqrt()) * (0.5 / K ** 0.5)
+    vox = torch.exp(1.5 * torch.randn(M, K, generator=gen))
+    vox[torch.rand(M, generator=gen) < 0.2] = 0.0
+    want = vox.double() @ w.double().T
+    scale = want.abs().max().item()
+    for terms in (3, 4):
+        got = ops.collapse_gemm(vox.to(dev), w.to(dev), terms=terms).cpu().double()
+        tol = RTOL * want.abs() + ATOL_REL * scale
+        print(f"[margin] heavy-tailed K={K} terms={terms}: worst |err| / tolerance = {((got - want).abs() / tol).max().item():.3f}")
+        torch.testing.assert_close(got, want, rtol=RTOL, atol=ATOL_REL * scale)
+    if K == 256:
+        b = torch.randn(256, generator=gen) * 0.1
+        want1 = torch.relu(vox.double() @ w.double().T + b.double())
+        got1 = ops.collapse_relu_sum(vox[None].to(dev), w.to(dev), b.to(dev)).cpu().double()
+        torch.testing.assert_close(got1, want1, rtol=RTOL, atol=ATOL_REL * want1.abs().max().item())
 
 
 def test_collapse_gemm_rejects_other_shapes():

@@ -95,3 +95,29 @@ def test_product_make_grid_matches_reference_fixture():
         assert np.array_equal(g.numpy().view(np.uint32), d[key].view(np.uint32)), key
         n += 1
     assert n == 5
+
+
+@pytest.mark.parametrize("case", VFA_CASES)
+def test_torch_restatement_bitwise(case):
+    """oracle/torch_reference.py (the CPU baseline bench.py times, and in float64 the gradient reference) against the
+    reference's own stage tensors: same torch ops in the same order, so every pre-GEMM tensor is bit-identical."""
+    import torch
+    from oracle import torch_reference as tr
+    torch.set_num_threads(2)
+    d = np.load(golden_path(case))
+    m = _meta(d)
+    zl = torch.from_numpy(d["z_corners"][:, 0, 0, 2].copy())  # int64, like the reference buffer
+    co = torch.from_numpy(d["corners_offset"].reshape(8, 3))
+    with torch.no_grad():
+        st = tr.vfa_stages(torch.from_numpy(d["feature"])[None], torch.from_numpy(d["calib"]), torch.from_numpy(d["grid"]),
+                           zl, co, m["data"], m["image_size"])
+        out = tr.vfa_forward(torch.from_numpy(d["feature"])[None], torch.from_numpy(d["calib"]),
+                             torch.from_numpy(d["grid"]), torch.from_numpy(d["weight"]), torch.from_numpy(d["bias"]), zl,
+                             co, m["data"], m["image_size"])
+    for key, got in (("box", st["box"][0]), ("area", st["area"][0, 0]), ("integral", st["integral"][0]), ("vox", st["vox"])):
+        a, b = got.numpy(), d[key]
+        assert a.shape == b.shape, key
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), f"{key}: {np.count_nonzero(~same)} elements differ"
+    assert np.array_equal(st["visible"][0, 0].numpy(), d["visible"])
+    np.testing.assert_allclose(out[0].numpy(), d["ortho"], rtol=1e-4, atol=1e-5 * np.abs(d["ortho"]).max())

@@ -102,24 +102,29 @@ def _cameras_for(cfg):
     raise ValueError(data)
 
 
-def make_workload(name, channels=256, seed=0, device="cpu", n_cam=None):
+def make_workload(name, channels=256, seed=0, device="cpu", n_cam=None, cameras=None):
     """Build the synthetic inputs of one named workload.
 
     Returns a dict with ``args`` (namespace with .data/.image_size, what the projector reads from
     the reference's argparse bag), ``calibs`` (N,3,4), ``grid`` (1,L,W,3), ``features`` (list over
     cameras of the three (1,C,Hf,Wf) lateral maps, ``relu(randn)``), and the constructor kwargs.
+    ``cameras``: only these cameras get feature maps (the others ``None``) -- a rank of a camera-sharded run needs
+    its own cameras only; every camera has its own generator, so the maps do not depend on who builds them.
     """
     cfg = dict(WORKLOADS[name])
     if n_cam is not None:
         cfg["n_cam"] = n_cam
-    gen = torch.Generator().manual_seed(seed)
     args = SimpleNamespace(data=cfg["data"], image_size=tuple(cfg["image_size"]))
     cs = cfg["cube_size"]
     grid = make_grid(world_size=cfg["world_size"], cube_LW=cs[:2], dataset=cfg["data"]).unsqueeze(0)
     calibs = _cameras_for(cfg)
     sizes = feature_sizes(cfg["feat_image"])
     feats = []
-    for _ in range(cfg["n_cam"]):
+    for cam in range(cfg["n_cam"]):
+        if cameras is not None and cam not in cameras:
+            feats.append(None)
+            continue
+        gen = torch.Generator().manual_seed(seed * 1000 + cam)
         feats.append([torch.relu(torch.randn(1, channels, h, w, generator=gen)).to(device) for (h, w) in sizes])
     return dict(name=name, args=args, calibs=calibs.to(device), grid=grid.to(device), features=feats,
                 cube_size=cs, grid_height=cfg["grid_height"], n_cam=cfg["n_cam"], feat_sizes=sizes,
