@@ -178,6 +178,34 @@ size_t vfa_collapse_gemm_workspace_bytes(int K, int N);
 int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, void *workspace, size_t workspace_bytes, size_t M,
                           int K, int N, int flags, void *stream);
 
+/* ---- single-layer grids (nl = 1), C = c_out = 256, inference: the whole frame in two launches ------------------------------
+ *
+ * vfa_frame_records_f32: geometry ONCE per frame.  Every (view, cell) cube is projected once (vfa_op.py:64-88,
+ * utils.py:50-59) and turned, per feature scale, into a 96-byte box record (16 bilinear tap weights, 1 / area, visibility,
+ * tap coordinates: vfa_op.py:104-106 and the set-up of the four F.grid_sample calls :112-115) plus, per (view, 8 x 4-cell
+ * tile, scale), the window of the integral image holding the tile's taps; `weights[k]` (collapse.weight of scale k, (256,
+ * 256) fp32, may be NULL as a whole to skip) is split into bf16 hi / lo planes in MFMA fragment order.  All of it goes to
+ * `workspace` (vfa_frame_workspace_bytes() bytes of caller-owned device memory, valid until the next call that uses it).
+ *   n_scales in 1..3; feat_hw = HOST array {Hf0, Wf0, Hf1, Wf1, ...}; weights = HOST array of n_scales device pointers.
+ *   grid (L * W, 3) row-major; z_layers[0] is the single layer.  n_views <= 32 (else VFA_ERR_UNSUPPORTED).
+ *
+ * vfa_pool_collapse_relu_sum_f32: box pooling + Linear + bias + ReLU + view sum + scale sum in ONE persistent kernel,
+ *   out[cell, :] = (accumulate ? out[cell, :] : 0) + sum_scale sum_view relu(vox_{scale,view}[cell, :] . W_scale^T + b_scale)
+ *                                                replaces vfa_op.py:112-125 and vfanet.py:79, 82 for every scale and camera
+ * The voxel features never reach HBM: per (tile, scale, view) the tap window is brought into LDS by LDS-DMA, the 32 boxes are
+ * pooled with the reference's FMA chains into bf16 hi / lo planes and multiplied on the matrix cores (same bf16-split
+ * arithmetic and `flags` as vfa_collapse_relu_sum_f32); the quotient is v * RN(1 / area) instead of a division (<= 1.5 ulp,
+ * far below the split).  Results: within the path's post-GEMM tolerance, not bitwise.
+ *   integrals / biases = HOST arrays of n_scales device pointers ((n_views, Hf+2, Wf+2, 256) each / (256) or NULL);
+ *   workspace = what vfa_frame_records_f32 filled for the same (n_views, L, W, n_scales, feat_hw). */
+size_t vfa_frame_workspace_bytes(int n_views, int L, int W, int n_scales);
+int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
+                          int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
+                          const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream);
+int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, const void *workspace,
+                                   size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales, const int *feat_hw,
+                                   int accumulate, int flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

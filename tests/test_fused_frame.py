@@ -1,0 +1,252 @@
+"""The two-launch inference path of single-layer grids (``vfa_frame_records_f32`` + ``vfa_pool_collapse_relu_sum_f32``:
+geometry once per frame, pooling + collapse + ReLU + view / scale sums in one persistent kernel, vox never in HBM) against
+the unfused kernels, the CPU oracle and float64.   ``-m gpu``.
+
+Reference lines covered: vfa/model/vfa_op.py:61-125 (all of VFA.forward), vfa/model/vfanet.py:64-82 (camera loop).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL_REL = 1e-4, 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _mods(wl, dev, seed=1, scale=3.0):
+    import vfa_amd
+    torch.manual_seed(seed)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+            for _ in range(3)]
+    with torch.no_grad():
+        for m in mods:  # bigger weights and a negative-leaning bias: the ReLU cuts a real share of the outputs
+            m.collapse.weight.mul_(scale)
+            m.collapse.bias.uniform_(-0.3, 0.1)
+    return mods
+
+
+def _float64_reference(mods, lats, calibs, grid, wl, cells=None):
+    """sum_scale sum_view relu(vox . W^T + b) in float64 from the BITWISE-pinned voxel features of the pooling kernel."""
+    from vfa_amd import _lib, ops
+    dev = grid.device
+    n = calibs.shape[0]
+    grid_flat = grid.reshape(-1, 3).contiguous()
+    cells = grid_flat.shape[0] if cells is None else cells
+    want = torch.zeros(cells, 256, dtype=torch.float64, device=dev)
+    for m, lat in zip(mods, lats):
+        zl, co = m._kernel_geometry(dev)
+        vox = ops.project_gather(ops.integral_image(lat), calibs.reshape(n, 12).contiguous(), grid_flat, zl, co,
+                                 _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1], cell_count=cells, kernel="direct")
+        want += torch.relu(vox.double() @ m.collapse.weight.double().T + m.collapse.bias.double()).sum(0)
+    return want
+
+
+def _check(name, got, want):
+    scale = want.abs().max().item()
+    assert scale > 0
+    tol = RTOL * want.abs() + ATOL_REL * scale
+    worst = ((got.double() - want).abs() / tol).max().item()
+    print(f"[margin] {name}: worst |err| / tolerance = {worst:.3f}")
+    torch.testing.assert_close(got.double(), want, rtol=RTOL, atol=ATOL_REL * scale, msg=lambda m: f"{name}: {m}")
+
+
+CASES = [  # workload, cameras, grid crop (rows, cols) or None
+    ("multiviewc_200x200x1", None, None),          # the bench frame: 7 cameras x 3 scales, 1250 full tiles
+    ("multiviewc_200x200x1", 2, (37, 53)),         # ragged grid: partial tiles on both edges
+    ("wildtrack_480x1440x1", 3, (100, 1440)),      # Wildtrack conversion, 1080p maps
+]
+
+
+@pytest.mark.parametrize("name,n_cam,crop", CASES)
+def test_fused_frame_matches_unfused_kernels_and_float64(name, n_cam, crop, monkeypatch):
+    import vfa_amd
+    from vfa_amd import ops, vfa_op
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload(name, channels=256, seed=3, **({"n_cam": n_cam} if n_cam else {}))
+    n = wl["n_cam"]
+    grid = wl["grid"] if crop is None else wl["grid"][:, 11:11 + crop[0], 5:5 + crop[1]].contiguous()
+    grid = grid.to(dev)
+    mods = _mods(wl, dev)
+    lats = [torch.cat([wl["features"][c][s] for c in range(n)]).to(dev) for s in range(3)]
+    calibs = wl["calibs"].to(dev)
+    L, W = grid.shape[1:3]
+    with torch.no_grad():
+        monkeypatch.setattr(vfa_op, "FUSED_POOL", True)
+        with ops.KernelTimer() as kt:
+            fused = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        torch.cuda.synchronize()
+        assert "vfa_pool_collapse_relu_sum_f32" in kt.summary() and "vfa_project_gather_f32" not in kt.summary(), sorted(kt.summary())
+        monkeypatch.setattr(vfa_op, "FUSED_POOL", False)
+        with ops.KernelTimer() as kt:
+            unfused = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        torch.cuda.synchronize()
+        assert "vfa_collapse_relu_sum_f32" in kt.summary() and "vfa_pool_collapse_relu_sum_f32" not in kt.summary()
+        cells = min(L * W, 30000)
+        want = _float64_reference(mods, lats, calibs, grid, wl, cells)
+    f = fused[0].permute(1, 2, 0).reshape(L * W, 256)
+    u = unfused[0].permute(1, 2, 0).reshape(L * W, 256)
+    assert torch.isfinite(f).all()
+    _check(f"{name} fused vs float64", f[:cells], want)
+    _check(f"{name} unfused vs float64", u[:cells], want)
+    _check(f"{name} fused vs unfused", f, u.double())
+    # same frame twice: the persistent kernel writes every output row exactly once, deterministically
+    with torch.no_grad():
+        monkeypatch.setattr(vfa_op, "FUSED_POOL", True)
+        again = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+    assert torch.equal(again, fused)
+
+
+@pytest.mark.parametrize("data,image_size,cube,gh,world,step,cam", [
+    ("MultiviewC", (720, 1280), (18.75, 18.75, 160), 160, (3750, 3750), (75.0, 75.0), "ring"),
+    ("MultiviewX", (1080, 1920), (4, 4, 64), 64, (640, 1000), (8, 8), "mx"),
+    ("Wildtrack", (1080, 1920), (4, 4, 32), 32, (480, 1440), (12, 12), "wt"),
+    ("MultiviewC", (720, 1280), (150.0, 150.0, 300), 300, (3750, 3750), (150.0, 150.0), "inside"),  # huge near boxes: direct tiles
+])
+def test_fused_frame_vs_oracle_small_scenes(oracle, data, image_size, cube, gh, world, step, cam):
+    """Single-layer scenes of every dataset conversion against the CPU oracle end to end (oracle voxel features, float64
+    product): cameras far, near and INSIDE the field (boxes behind the camera, tiles whose tap window does not fit LDS and
+    take the direct path, fully masked tiles and views)."""
+    import vfa_amd
+    from vfa_amd.synthetic import look_at_camera, ring_cameras
+    from vfa_amd.utils import make_grid
+    dev = _dev()
+    H, W_img = image_size
+    if cam == "ring":
+        calibs = ring_cameras(3, (1875.0, 1875.0, 0.0), 2700.0, 600.0, 900.0, (W_img, H))
+    elif cam == "inside":
+        calibs = torch.tensor(np.stack([look_at_camera((1500.0, 1700.0, 250.0), (2600.0, 2300.0, 0.0), 700.0, (W_img, H)),
+                                        look_at_camera((300.0, 300.0, 200.0), (1800.0, 1900.0, 0.0), 500.0, (W_img, H))]),
+                              dtype=torch.float32)
+    elif cam == "mx":
+        calibs = torch.tensor(np.stack([look_at_camera((-5.0, 8.0, 3.0), (12.0, 8.0, 0.0), 1700.0, (W_img, H)),
+                                        look_at_camera((30.0, 20.0, 2.5), (12.0, 6.0, 0.0), 1400.0, (W_img, H))]),
+                              dtype=torch.float32)
+    else:
+        wt_c = (480 * 2.5 / 2 - 300.0, 1440 * 2.5 / 2 - 900.0, 0.0)
+        calibs = ring_cameras(2, wt_c, 0.45 * 1440 * 2.5, 400.0, 1100.0, (W_img, H))
+    grid = make_grid(world_size=world, cube_LW=list(step), dataset=data)
+    args = SimpleNamespace(data=data, image_size=image_size)
+    n = calibs.shape[0]
+    gen = torch.Generator().manual_seed(7)
+    sizes = [(45, 80), (23, 40), (12, 20)]
+    lats = [torch.relu(torch.randn(n, 256, h, w, generator=gen)) for h, w in sizes]
+    torch.manual_seed(3)
+    mods = [vfa_amd.VFA(256, grid_height=gh, cube_size=cube, args=args).to(dev) for _ in range(3)]
+    with torch.no_grad():
+        for m in mods:
+            m.collapse.weight.mul_(3.0)
+            m.collapse.bias.uniform_(-0.3, 0.1)
+        with vfa_amd.ops.KernelTimer() as kt:
+            out = vfa_amd.aggregate_views(*mods, *(l.to(dev) for l in lats), calibs.to(dev), grid.to(dev)[None])
+        torch.cuda.synchronize()
+    assert "vfa_pool_collapse_relu_sum_f32" in kt.summary()
+    L, W = grid.shape[:2]
+    zl_h, co_h = oracle.z_layers_of(gh, cube), oracle.corner_offsets(cube)
+    want = np.zeros((L * W, 256), np.float64)
+    vis_total = 0
+    for si, m in enumerate(mods):
+        w64 = m.collapse.weight.detach().cpu().double().numpy()
+        b64 = m.collapse.bias.detach().cpu().double().numpy()
+        for c in range(n):
+            f = lats[si][c].numpy()
+            box, area, vis = oracle.box_params(calibs[c].numpy(), grid.reshape(-1, 3).numpy(), zl_h, co_h, data, image_size,
+                                               f.shape[1], f.shape[2])
+            vox = oracle.gather(oracle.integral_image(f), box, area, vis)
+            vis_total += int(vis.sum())
+            want += np.maximum(vox.astype(np.float64) @ w64.T + b64, 0.0)
+    assert vis_total > 0
+    got = out[0].permute(1, 2, 0).reshape(L * W, 256).cpu()
+    _check(f"{data}/{cam}", got, torch.from_numpy(want))
+
+
+def test_fused_frame_single_scale_accumulate_and_degenerate_grids():
+    """`VFA.forward` (one camera, one scale -- the reference's own interface) runs the same two launches; accumulate on top of
+    an existing map; grids smaller than one 8 x 4 tile; a view that sees nothing."""
+    import vfa_amd
+    from vfa_amd import ops, vfa_op
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload("multiviewc_200x200x1", channels=256, seed=5, n_cam=2)
+    mods = _mods(wl, dev, seed=2)
+    lat = wl["features"][0][1].to(dev)
+    calib = wl["calibs"][0].to(dev)
+    for rows, cols in ((3, 5), (4, 8), (1, 1), (9, 17)):
+        grid = wl["grid"][:, 90:90 + rows, 100:100 + cols].contiguous().to(dev)
+        with torch.no_grad(), ops.KernelTimer() as kt:
+            out = mods[1](lat, calib, grid)
+        torch.cuda.synchronize()
+        assert "vfa_pool_collapse_relu_sum_f32" in kt.summary()
+        want = _float64_reference([mods[1]], [lat], calib[None], grid, wl)
+        _check(f"forward {rows}x{cols}", out[0].permute(1, 2, 0).reshape(rows * cols, 256), want)
+    # accumulate
+    grid = wl["grid"][:, 40:61, 30:70].contiguous().to(dev)
+    base = torch.randn(21 * 40, 256, device=dev)
+    with torch.no_grad():
+        got = vfa_op.fused_frame([mods[0]], [wl["features"][1][0].to(dev)], wl["calibs"][1:2].to(dev), grid, out=base.clone(),
+                                 accumulate=True)
+        want = base.double() + _float64_reference([mods[0]], [wl["features"][1][0].to(dev)], wl["calibs"][1:2].to(dev), grid, wl)
+    _check("accumulate", got, want)
+    # a camera looking away: every box masked -> every output row is relu(bias) (vox = 0)
+    away = torch.tensor([[900., 0, 640, 0.], [0, 900., 360, 0.], [0, 0, 1., 1e7]], device=dev)
+    with torch.no_grad():
+        out = mods[2](wl["features"][0][2].to(dev), away, grid)
+    want = torch.relu(mods[2].collapse.bias.detach()).expand(21 * 40, 256)
+    assert torch.equal(out[0].permute(1, 2, 0).reshape(-1, 256), want)
+
+
+def test_frame_records_match_the_box_parameter_kernel():
+    """The per-frame geometry pass against the bit-exact box-parameter entry point: visibility, area and 1 / area of every
+    record, scale by scale (the tap weights and coordinates are covered end to end above)."""
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    import vfa_amd
+    dev = _dev()
+    wl = make_workload("multiviewc_200x200x1", channels=256, seed=0, n_cam=3)
+    grid = wl["grid"][:, 20:61, 10:77].contiguous().to(dev)  # 41 x 67: ragged
+    L, W = grid.shape[1:3]
+    mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+    zl, co = mod._kernel_geometry(dev)
+    kind = _lib.CONV_KIND[wl["args"].data]
+    img_wh = wl["args"].image_size[::-1]
+    sizes = [tuple(s) for s in wl["feat_sizes"]]
+    calibs = wl["calibs"].to(dev)
+    ws = ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes).cpu().numpy()
+    n = 3
+    tiles_l, tiles_w = (L + 3) // 4, (W + 7) // 8
+    n_tiles = tiles_l * tiles_w
+
+    def up(v):
+        return (v + 255) // 256 * 256
+    off = 0
+    for s, (Hf, Wf) in enumerate(sizes):
+        live_off = off
+        off = up(off + n_tiles * 4)
+        hdr_off = off
+        off = up(off + n * n_tiles * 32)
+        rec_off = off
+        off = up(off + (n * n_tiles * 32 + 1) * 96)
+        off = up(off + 8 * 16 * 2 * 64 * 16)
+        rec = ws[rec_off:rec_off + n * n_tiles * 32 * 96].view(np.uint32).reshape(n, tiles_l, tiles_w, 4, 8, 24)
+        box, area, vis = ops.box_params(calibs, grid.reshape(-1, 3), zl, co, kind, img_wh, (Hf, Wf))
+        area = area.cpu().numpy().reshape(n, L, W)
+        vis = vis.cpu().numpy().reshape(n, L, W).astype(bool)
+        # tile-major -> grid order
+        g = rec.transpose(0, 1, 3, 2, 4, 5).reshape(n, tiles_l * 4, tiles_w * 8, 24)[:, :L, :W]
+        assert np.array_equal((g[..., 17] & 1).astype(bool), vis), f"scale {s}: visibility"
+        assert np.array_equal(g[..., 23], area.view(np.uint32)), f"scale {s}: area"
+        rcp = (np.float32(1) / area).view(np.uint32)
+        assert np.array_equal(g[..., 16][vis], rcp[vis]), f"scale {s}: 1 / area"
+        live = ws[live_off:live_off + n_tiles * 4].view(np.uint32)
+        tile_vis = np.zeros((n, tiles_l * 4, tiles_w * 8), bool)
+        tile_vis[:, :L, :W] = vis
+        tile_any = tile_vis.reshape(n, tiles_l, 4, tiles_w, 8).any(axis=(2, 4)).reshape(n, n_tiles)
+        want_live = sum((tile_any[v].astype(np.uint32) << v) for v in range(n))
+        assert np.array_equal(live, want_live), f"scale {s}: live-view masks"

@@ -47,6 +47,11 @@ SIGNATURES = {
     "vfa_collapse_gemm_workspace_bytes": [_c_int, _c_int],
     "vfa_collapse_gemm_f32": [_vp, _vp, _vp, _vp, _c_size_t, _c_size_t, _c_int, _c_int, _c_int, _vp],
     "vfa_collapse_relu_sum_f32": [_vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
+    "vfa_frame_workspace_bytes": [_c_int, _c_int, _c_int, _c_int],
+    "vfa_frame_records_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
+                              _c_int, _vp, _vp, _vp, _c_size_t, _vp],
+    "vfa_pool_collapse_relu_sum_f32": [_vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
+                                       _vp],
 }
 
 _lib = None
@@ -87,6 +92,15 @@ def call(name, *args):
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """HOST array of device pointers (None entries -> NULL), for the entry points that take one pointer per scale."""
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def int_array(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
 
 
 def current_stream_handle():

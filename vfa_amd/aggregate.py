@@ -15,7 +15,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import ops, vfa_op
 
 # The three scale chains (integral image -> projection + pooling -> collapse GEMM) are independent until the final
 # sum, so they are issued on separate HIP streams: the MFMA-bound GEMM of one scale overlaps the latency-bound
@@ -157,8 +157,13 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
         # sums the views into the map (sum over views per scale, then over scales: the reference's sums re-associated,
         # inside the post-GEMM tolerance)
         ortho = torch.empty((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
-        for i, (m, lat) in enumerate(work):
-            m.project_sum(lat, calibs, grid, crange, out=ortho, accumulate=i > 0, reserved_cus=reserved)
+        if vfa_op.fused_frame_ok([vfa8, vfa16, vfa32], n):
+            # geometry once per frame + one persistent kernel for pooling, collapse, ReLU and every sum: vox stays on chip
+            vfa_op.fused_frame([vfa8, vfa16, vfa32], [lat8, lat16, lat32], calibs, grid, crange, out=ortho,
+                               reserved_cus=reserved)
+        else:
+            for i, (m, lat) in enumerate(work):
+                m.project_sum(lat, calibs, grid, crange, out=ortho, accumulate=i > 0, reserved_cus=reserved)
     elif n > 0:
         if N_STREAMS == 1 or not grid.is_cuda:
             lins = [m.project_views(lat, calibs, grid, crange, reserved_cus=reserved) for m, lat in work]

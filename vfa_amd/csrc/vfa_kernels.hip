@@ -19,32 +19,10 @@
 
 #include "vfa_hip.h"
 
+#include "vfa_geom.h"
+
 namespace {
-
-constexpr int kWave = 64;
-
-// ------------------------------------------------------------------------------------------------
-// small helpers
-// ------------------------------------------------------------------------------------------------
-// torch.clamp / min / max propagate NaN; ordered comparisons do that for free.
-__device__ __forceinline__ float clamp_t(float v, float lo, float hi)
-{
-    if (v < lo) return lo;
-    if (v > hi) return hi;
-    return v;
-}
-__device__ __forceinline__ float min_t(float a, float b) { return (a != a || a < b) ? a : b; }
-__device__ __forceinline__ float max_t(float a, float b) { return (a != a || a > b) ? a : b; }
-
-__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Give every XCD one
-// contiguous eighth of the logical work so that neighbouring boxes -- whose image footprints overlap --
-// are served by the same L2.  Speed only; any placement is correct.
-__device__ __forceinline__ long long xcd_contiguous(long long block, long long per_xcd)
-{
-    return (block & 7) * per_xcd + (block >> 3);
-}
+using namespace vfa_dev;
 
 // ------------------------------------------------------------------------------------------------
 // integral image, pass 1: cumsum along W.                                reference vfa_op.py:173 (inner)
@@ -179,61 +157,6 @@ __global__ __launch_bounds__(256) void integral_cols_kernel(float *__restrict__ 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// box parameters                                           reference vfa_op.py:64-88, 104-106; utils.py:56-59
-// ------------------------------------------------------------------------------------------------
-struct BoxGeom {
-    const float *calibs;     // (n_views, 12)
-    const float *grid;       // (n_cells, 3)
-    const float *z_layers;   // (nl)
-    const float *corner_off; // (8, 3)
-    int conv_kind;
-    float img_w, img_h;
-    float cmin, cmax;
-};
-
-// Normalised image coordinates of cube corner k of (cell, layer) seen by `P` (3x4, row-major).
-// Every operation is a separately rounded fp32 op in the reference's order.
-__device__ __forceinline__ void project_corner(const BoxGeom &g, const float *__restrict__ P, float gx, float gy,
-                                               float gz, int k, float &nu, float &nv)
-{
-    float x = gx + g.corner_off[k * 3 + 0];
-    float y = gy + g.corner_off[k * 3 + 1];
-    float z = gz + g.corner_off[k * 3 + 2];
-    if (g.conv_kind == VFA_CONV_MULTIVIEWX) {
-        x = x / 40.0f; y = y / 40.0f; z = z / 40.0f;
-    } else if (g.conv_kind == VFA_CONV_WILDTRACK) {
-        x = x * 2.5f; x = x - 300.0f;
-        y = y * 2.5f; y = y - 900.0f;
-        z = z * 2.5f;
-    }
-    float h[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const float a0 = P[r * 4 + 0] * x, a1 = P[r * 4 + 1] * y, a2 = P[r * 4 + 2] * z;
-        float s = a0 + a1;
-        s = s + a2;
-        h[r] = s + P[r * 4 + 3];
-    }
-    const float u = h[0] / h[2], w = h[1] / h[2];
-    nu = (2.0f * u) / g.img_w; nu = nu - 1.0f; nu = clamp_t(nu, g.cmin, g.cmax);
-    nv = (2.0f * w) / g.img_h; nv = nv - 1.0f; nv = clamp_t(nv, g.cmin, g.cmax);
-}
-
-__device__ __forceinline__ float box_area(float l, float t, float r, float b, int Hf, int Wf)
-{
-    const float dx = r - l, dy = b - t;
-    float a = dx * dy;
-    a = a * (float)Hf;
-    a = a * (float)Wf;
-    a = a + (float)1e-6;
-    return a;
-}
-__device__ __forceinline__ bool box_visible(float a, int Hf, int Wf)
-{
-    return (a > (float)1e-6) && (a < (float)((double)(Hf * Wf) * 0.3));
-}
-
 // one thread per (view, layer, cell)
 __global__ __launch_bounds__(256) void box_params_kernel(BoxGeom g, int n_cells, int nl, size_t total, int Hf,
                                                          int Wf, float4 *__restrict__ box, float *__restrict__ area,
@@ -265,20 +188,6 @@ __global__ __launch_bounds__(256) void box_params_kernel(BoxGeom g, int n_cells,
 // ------------------------------------------------------------------------------------------------
 // box pooling                                                               reference vfa_op.py:112-120
 // ------------------------------------------------------------------------------------------------
-// One axis of F.grid_sample's bilinear set-up (align_corners=False): pixel coordinate by ONE fma,
-// i0 = floor, hi = weight of tap i0+1, lo = weight of tap i0.              SURVEY.md A.5
-struct Axis { int i0; float hi, lo; };
-__device__ __forceinline__ Axis make_axis(float g, int size)
-{
-    const float X = fmaf(g + 1.0f, (float)size / 2.0f, -0.5f);
-    const float f = floorf(X);
-    Axis a;
-    a.i0 = (int)f;
-    a.hi = X - f;
-    a.lo = 1.0f - a.hi;
-    return a;
-}
-
 template <int VEC> __device__ __forceinline__ typename vec_of<VEC>::type vmul(typename vec_of<VEC>::type a, float w);
 template <> __device__ __forceinline__ float vmul<1>(float a, float w) { return a * w; }
 template <> __device__ __forceinline__ float4 vmul<4>(float4 a, float w)
@@ -399,14 +308,6 @@ static_assert(sizeof(BoxRec) == 128, "BoxRec must stay 8 x 16 bytes");
 
 constexpr int kTileBoxes = 128;           // boxes per workgroup
 constexpr int kPerWave = kTileBoxes / 4;  // contiguous boxes per wave in phase 2 (a power of two <= 64)
-
-__device__ __forceinline__ void bilinear_weights(float (&w)[4], const Axis &ax, const Axis &ay)
-{
-    w[0] = ay.lo * ax.lo; // nw
-    w[1] = ay.lo * ax.hi; // ne
-    w[2] = ay.hi * ax.lo; // sw
-    w[3] = ay.hi * ax.hi; // se
-}
 
 __device__ __forceinline__ void fill_record(BoxRec &rc, int view, float l, float t, float r, float b, float area, bool vis,
                                             const GatherDims &d, unsigned &key_x, unsigned &key_y)

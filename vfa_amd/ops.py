@@ -309,3 +309,56 @@ def collapse_gemm(vox2d, weight, out=None, terms=0, reserved_cus=0):
     _launch("vfa_collapse_gemm_f32", _lib.ptr(vox2d), _lib.ptr(weight), _lib.ptr(out), _lib.ptr(ws), ws.numel(), M, K, N,
             _lib.collapse_flags(terms, reserved_cus), _lib.current_stream_handle(), tag=(M, K, N))
     return out
+
+
+def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_hws, weights=None, crange=(-1, 0.95),
+                  workspace=None):
+    """Geometry of one frame for the fused inference kernel (``pool_collapse``): box records of every (view, cell) for each
+    feature scale + the split collapse weights -> workspace tensor (reference vfa_op.py:64-106, set-up of :112-115).
+
+    calibs (n,3,4), grid (L,W,3) or (1,L,W,3), feat_hws = [(Hf,Wf), ...] (1..3 scales), weights = one (256,256) per scale."""
+    _lib.require_device(calibs, grid, z_layers, corner_off)
+    grid = _f32c(grid.reshape(grid.shape[-3], grid.shape[-2], 3))
+    L, W = grid.shape[:2]
+    calibs = _f32c(calibs.reshape(-1, 12))
+    n = calibs.shape[0]
+    z_layers, corner_off = _f32c(z_layers), _f32c(corner_off.reshape(8, 3))
+    if z_layers.numel() != 1:
+        raise _lib.VFAHipError("frame_records / pool_collapse cover single-layer grids (nl = 1) only")
+    ns = len(feat_hws)
+    need = _lib.lib().vfa_frame_workspace_bytes(n, L, W, ns)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=calibs.device)
+    hw = _lib.int_array([v for f in feat_hws for v in f])
+    wts = None
+    if weights is not None:
+        weights = [_f32c(w) for w in weights]
+        assert len(weights) == ns and all(tuple(w.shape) == (256, 256) for w in weights)
+        _lib.require_device(*weights)
+        wts = _lib.ptr_array(weights)
+    _launch("vfa_frame_records_f32", _lib.ptr(calibs), _lib.ptr(grid), _lib.ptr(z_layers), _lib.ptr(corner_off), n, L, W,
+            int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), ns, hw, wts,
+            _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(), tag=(n, L, W, ns))
+    return workspace
+
+
+def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=False, terms=0, reserved_cus=0):
+    """out (L*W, 256) (+)= sum_scale sum_view relu(vox . W^T + b): pooling + collapse + ReLU + view / scale sum in one
+    persistent kernel, the voxel features never touch HBM (reference vfa_op.py:112-125, vfanet.py:79, 82).
+
+    integrals = one (n, Hf+2, Wf+2, 256) zero-bordered channels-last integral image per scale (``integral_image``);
+    workspace = ``frame_records`` of the same frame."""
+    _lib.require_device(*integrals, workspace, out)
+    ns = len(integrals)
+    n = integrals[0].shape[0]
+    L, W = grid_lw
+    assert all(i.shape[0] == n and i.shape[3] == 256 and i.is_contiguous() and i.dtype == torch.float32 for i in integrals)
+    if out is None:
+        out = torch.empty((L * W, 256), dtype=torch.float32, device=integrals[0].device)
+        accumulate = False
+    biases = [None if b is None else _f32c(b) for b in (biases if biases is not None else [None] * ns)]
+    hw = _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)])
+    _launch("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array(biases), _lib.ptr(workspace),
+            workspace.numel(), _lib.ptr(out), n, L, W, ns, hw, 1 if accumulate else 0, _lib.collapse_flags(terms, reserved_cus),
+            _lib.current_stream_handle(), tag=(n, L, W, ns))
+    return out

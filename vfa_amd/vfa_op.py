@@ -41,6 +41,10 @@ USE_FUSED = os.environ.get("VFA_AMD_FUSED", "0") == "1"
 # tile GEMM `vfa_collapse_gemm_f32` in front of the epilogue kernels; "library" = fp32 library GEMM everywhere.
 COLLAPSE_KERNEL = os.environ.get("VFA_AMD_COLLAPSE", "mfma_bf16")
 COLLAPSE_TERMS = int(os.environ.get("VFA_AMD_COLLAPSE_TERMS", "3"))
+# Inference on single-layer grids with C = 256: "1" (default) = geometry once per frame (`vfa_frame_records_f32`) + ONE
+# persistent kernel for pooling, collapse, bias, ReLU and the view / scale sums (`vfa_pool_collapse_relu_sum_f32`): the voxel
+# features never reach HBM.  "0" = pooling kernel -> vox in HBM -> MFMA collapse kernel, per scale (the round-1 path).
+FUSED_POOL = os.environ.get("VFA_AMD_FUSED_POOL", "1") == "1"
 
 
 def _conv_kind(args):
@@ -106,6 +110,37 @@ class _CollapseGemm(torch.autograd.Function):
         return g_vox, g_w, None
 
 
+def fused_frame_ok(mods, n_views):
+    """The two-launch inference path covers these projector modules (one per feature scale) for this many cameras."""
+    m0 = mods[0]
+    return (FUSED_POOL and COLLAPSE_KERNEL != "library" and 1 <= len(mods) <= 3 and 0 < n_views <= 32
+            and all(m.channel == 256 and m.num_grid_layer == 1 and m.collapse.out_features == 256 for m in mods)
+            and all(m.geometry_key == m0.geometry_key and getattr(m.args, "data", None) == getattr(m0.args, "data", None)
+                    and tuple(m.args.image_size) == tuple(m0.args.image_size) for m in mods))
+
+
+def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0):
+    """All scales and all cameras of one frame: ``out (L*W, 256) (+)= sum_scale sum_view relu(collapse_scale(vox))``.
+
+    mods / features: one ``VFA`` and one (n,256,Hf,Wf) lateral batch per scale.  Integral images (one launch pair per
+    scale), then ``ops.frame_records`` (geometry once per frame) and ``ops.pool_collapse`` (everything else).  Inference
+    only (no autograd); needs ``fused_frame_ok``."""
+    _lib.require_device(calibs, grid, *features)
+    m0 = mods[0]
+    conv_kind = _conv_kind(m0.args)
+    img_h, img_w = (float(v) for v in m0.args.image_size)  # the path uses image_size[::-1] (vfa_op.py:75)
+    length, width = grid.shape[-3], grid.shape[-2]
+    dev = features[0].device
+    z_layers, corner_off = m0._kernel_geometry(dev)
+    with torch.no_grad():
+        integrals = [ops.integral_image(f) for f in features]
+        ws = ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h),
+                               [tuple(f.shape[-2:]) for f in features], weights=[m.layer_major_weight() for m in mods],
+                               crange=crange)
+        return ops.pool_collapse(integrals, [m.collapse.bias for m in mods], ws, (length, width), out=out,
+                                 accumulate=accumulate, terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
+
+
 def mfma_gemm_ok(K, N):
     """The K-looped MFMA GEMM covers this `collapse` shape (any layer count at C = 256)."""
     return COLLAPSE_KERNEL != "library" and N == 256 and K % 128 == 0
@@ -143,6 +178,8 @@ class VFA(nn.Module):
         self.num_grid_layer = z.numel()
         self.collapse = nn.Linear(channel * self.num_grid_layer, channel)
         self._geom_cache = None
+        # modules built from the same cube share box geometry (the fused frame path projects each cube once for all scales)
+        self.geometry_key = (tuple(float(v) for v in cube_size), float(grid_height))
 
     # ------------------------------------------------------------------ geometry buffers for the kernels
     def generate_cube(self, cub_size):
@@ -243,6 +280,9 @@ class VFA(nn.Module):
             return out
         if n == 0:
             return out if accumulate else out.zero_()
+        if fused_frame_ok([self], n):
+            return fused_frame([self], [features], calibs, grid, crange, out=out, accumulate=accumulate,
+                               reserved_cus=reserved_cus)
         with torch.no_grad():
             integral = ops.integral_image(features)
             weight = self.layer_major_weight()
