@@ -195,7 +195,7 @@ def test_fused_frame_single_scale_accumulate_and_degenerate_grids():
         want = base.double() + _float64_reference([mods[0]], [wl["features"][1][0].to(dev)], wl["calibs"][1:2].to(dev), grid, wl)
     _check("accumulate", got, want)
     # a camera looking away: every box masked -> every output row is relu(bias) (vox = 0)
-    away = torch.tensor([[900., 0, 640, 0.], [0, 900., 360, 0.], [0, 0, 1., 1e7]], device=dev)
+    away = torch.tensor([[900., 0, 640, -1e9], [0, 900., 360, -1e9], [0, 0, 0., 1.]], device=dev)  # every corner clamps to -1
     with torch.no_grad():
         out = mods[2](wl["features"][0][2].to(dev), away, grid)
     want = torch.relu(mods[2].collapse.bias.detach()).expand(21 * 40, 256)

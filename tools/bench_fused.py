@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Diagnostics of the fused frame kernel on the bench workload: launch time of `vfa_pool_collapse_relu_sum_f32` and of the
+geometry pass, phase ablations (VFA_FLAG_DEBUG) and in-kernel cycle stamps.  Numbers only; ablated results are meaningless."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import vfa_amd  # noqa: E402
+from vfa_amd import _lib, ops  # noqa: E402
+from vfa_amd.synthetic import make_workload  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "multiviewc_200x200x1"
+dev = torch.device("cuda:0")
+wl = make_workload(name, channels=256, seed=0)
+n = wl["n_cam"]
+torch.manual_seed(0)
+mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
+lats = [torch.cat([wl["features"][c][s] for c in range(n)]).to(dev) for s in range(3)]
+calibs, grid = wl["calibs"].to(dev), wl["grid"].to(dev)
+L, W = grid.shape[1:3]
+zl, co = mods[0]._kernel_geometry(dev)
+kind = _lib.CONV_KIND[wl["args"].data]
+img_wh = wl["args"].image_size[::-1]
+sizes = [tuple(l.shape[-2:]) for l in lats]
+
+
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+with torch.no_grad():
+    integrals = [ops.integral_image(l) for l in lats]
+    weights = [m.layer_major_weight().contiguous() for m in mods]
+    biases = [m.collapse.bias for m in mods]
+    ws = ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights)
+    print(f"{name}: frame_records {timed(lambda: ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws)):.1f} us")
+    out = torch.empty(L * W, 256, device=dev)
+    # header statistics
+    host = ws.cpu().numpy()
+    tiles = ((L + 3) // 4) * ((W + 7) // 8)
+    off = 0
+    up = lambda v: (v + 255) // 256 * 256  # noqa: E731
+    for s in range(3):
+        off = up(off + tiles * 4)
+        hdr = host[off:off + n * tiles * 32].view(np.uint32).reshape(n * tiles, 8)
+        off = up(off + n * tiles * 32)
+        off = up(off + (n * tiles * 32 + 1) * 96)
+        off = up(off + 8 * 16 * 2 * 64 * 16)
+        live = hdr[:, 0] & 1
+        direct = (hdr[:, 0] >> 1) & 1
+        slots = hdr[:, 1][(live == 1) & (direct == 0)]
+        print(f"  scale {s}: items {n * tiles}, live {int(live.sum())}, direct {int(direct.sum())}, slots mean {slots.mean():.1f} max {slots.max()}")
+    diag_off = off
+    for mask, label in ((0, "full"), (128, "full + stamps"), (1, "no fills"), (2, "no pool"), (4, "no mfma"), (3, "no fills, no pool"),
+                        (6, "no pool, no mfma"), (5, "no fills, no mfma"), (7, "skeleton only")):
+        us = timed(lambda: ops.pool_collapse(integrals, biases, ws, (L, W), out=out, debug=mask))
+        print(f"  pool_collapse [{label:>18}] {us:8.1f} us")
+        if mask == 128:
+            torch.cuda.synchronize()
+            d = ws[diag_off:diag_off + 256 * 64].cpu().numpy().view(np.uint64).reshape(256, 8).astype(np.float64)
+            d = d[d[:, 7] > 0]
+            items = d[:, 7]
+            names = ["top: seek + first record", "wait window + barrier", "pool (+ W loads)", "barrier", "issue fills + header",
+                     "MFMA + epilogue", "tile store"]
+            print(f"    stamps of wave 0, cycles per item (mean over {len(d)} workgroups, {items.mean():.1f} items each):")
+            for k, nm in enumerate(names):
+                print(f"      {nm:28s} {np.mean(d[:, k] / items):9.0f}")
+            print(f"      {'sum':28s} {np.mean(d[:, :7].sum(1) / items):9.0f}")

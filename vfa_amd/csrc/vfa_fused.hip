@@ -19,6 +19,7 @@
 // tolerance (rtol 1e-4, atol 1e-5 max|ref|), not bitwise -- no GEMM order is.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "vfa_geom.h"
 
@@ -206,19 +207,15 @@ struct FusedArgs {
     int n_scales, n_views, L, W, tiles_w, n_tiles;
     float *out;                     // (L * W, 256)
     int accumulate;
+    int debug;                      // diagnostic build only: ablation mask (kDbg*), results are then meaningless
+    unsigned long long *diag;       // diagnostic build only: per workgroup 8 cycle counters
 };
+// diagnostic ablations (VFA_FLAG_DEBUG(mask), pool_collapse_kernel<TERMS, true> only)
+constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgStamps = 128;
 
 struct Frag { bf16x8 hi, lo; };
 
 __device__ __forceinline__ float relu_t(float x) { return (x < 0.0f) ? 0.0f : x; } // NaN stays NaN
-
-// one box record in SGPRs (wave-uniform): dwords 0-15 the tap weights, 16-23 rcp, flags, rows, cols, masked, area
-struct SRec { f32x16 w; i32x8 t; };
-__device__ __forceinline__ void sload_rec(SRec &o, const unsigned char *p)
-{
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40" : "=&s"(o.w), "=&s"(o.t) : "s"(p));
-}
-__device__ __forceinline__ void swait_rec(SRec &o) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(o.w), "+s"(o.t)); }
 
 __device__ __forceinline__ float4 mul4(float4 a, float w) { return make_float4(a.x * w, a.y * w, a.z * w, a.w * w); }
 __device__ __forceinline__ float4 fma4(float4 a, float w, float4 c)
@@ -234,63 +231,16 @@ __device__ __forceinline__ float4 sample4(float4 nw, float4 ne, float4 sw, float
     v = fma4(se, w3, v);
     return v;
 }
-__device__ __forceinline__ float box_quot(float lt, float rb, float rt, float lb, float rcp)
-{
-    float v = lt + rb; // (((lt + rb) - rt) - lb): the reference's order (A.6)
-    v = v - rt;
-    v = v - lb;
-    return v * rcp;
-}
-
-// The 16 taps of a box are {top rows yt, yt+1, bottom rows yb, yb+1} x {left cols xl, xl+1, right cols xr, xr+1}; when the pairs
-// coincide or overlap (DYC / DXC = 0 or 1) the shared rows / columns are loaded once.  The two samples of the top rows (lt,
-// rt) are formed first, then the bottom rows replace the top ones in registers (at most 2 rows x 4 columns of taps are live:
-// the W fragments hold half of the register file).  LDS: `lds` = tap window, offsets in slots; DIRECT: `img` = the view's
-// padded integral image, offsets in pixels.  Every variant is a straight-line body.
-template <bool DIRECT>
-__device__ __forceinline__ float4 tap_at(const float4 *lds, const char *img, unsigned row, unsigned col, int lane)
-{
-    if constexpr (DIRECT) return *reinterpret_cast<const float4 *>(img + ((size_t)(row + col) * kSlotBytes + lane * 16));
-    else return lds[(row + col) * 64 + lane];
-}
-template <bool DIRECT, int DXC>
-__device__ __forceinline__ void load_row(float4 (&R)[4], const float4 *lds, const char *img, unsigned row, const unsigned (&col)[4], int lane)
-{
-    constexpr int NC = DXC == 0 ? 2 : (DXC == 1 ? 3 : 4);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) R[c] = tap_at<DIRECT>(lds, img, row, col[(DXC == 1 && c == 2) ? 3 : c], lane); // unique cols: {0,1}, {0,1,3}, {0,1,2,3}
-}
-template <bool DIRECT, int DYC, int DXC>
-__device__ __forceinline__ float4 pool_box(const float4 *lds, const char *img, const unsigned (&row)[4], const unsigned (&col)[4],
-                                           int lane, const f32x16 &w, float rcp)
-{
-    constexpr int CR0 = DXC == 0 ? 0 : (DXC == 1 ? 1 : 2), CR1 = CR0 + 1; // right column pair inside a loaded row
-    float4 A[4], B[4];
-    load_row<DIRECT, DXC>(A, lds, img, row[0], col, lane);
-    load_row<DIRECT, DXC>(B, lds, img, row[1], col, lane);
-    const float4 lt = sample4(A[0], A[1], B[0], B[1], w[0], w[1], w[2], w[3]);
-    const float4 rt = sample4(A[CR0], A[CR1], B[CR0], B[CR1], w[8], w[9], w[10], w[11]);
-    float4 lb, rb;
-    if constexpr (DYC == 0) { // bottom rows = top rows
-        lb = sample4(A[0], A[1], B[0], B[1], w[12], w[13], w[14], w[15]);
-        rb = sample4(A[CR0], A[CR1], B[CR0], B[CR1], w[4], w[5], w[6], w[7]);
-    } else if constexpr (DYC == 1) { // bottom rows = (yt + 1, yb + 1): the second top row stays
-        load_row<DIRECT, DXC>(A, lds, img, row[3], col, lane);
-        lb = sample4(B[0], B[1], A[0], A[1], w[12], w[13], w[14], w[15]);
-        rb = sample4(B[CR0], B[CR1], A[CR0], A[CR1], w[4], w[5], w[6], w[7]);
-    } else {
-        load_row<DIRECT, DXC>(A, lds, img, row[2], col, lane);
-        load_row<DIRECT, DXC>(B, lds, img, row[3], col, lane);
-        lb = sample4(A[0], A[1], B[0], B[1], w[12], w[13], w[14], w[15]);
-        rb = sample4(A[CR0], A[CR1], B[CR0], B[CR1], w[4], w[5], w[6], w[7]);
-    }
-    return make_float4(box_quot(lt.x, rb.x, rt.x, lb.x, rcp), box_quot(lt.y, rb.y, rt.y, lb.y, rcp),
-                       box_quot(lt.z, rb.z, rt.z, lb.z, rcp), box_quot(lt.w, rb.w, rt.w, lb.w, rcp));
-}
+// Pooling layout: a wave owns four boxes of the tile and pools them SIDE BY SIDE -- 16 lanes x float4 = 64 channels of one
+// box, four boxes per wave instruction, four channel quarters per item.  Box parameters are per-lane registers (the box
+// record, loaded with ordinary vector loads one item ahead), control flow is the same for every box (always 16 taps: the
+// duplicates of narrow boxes hit the same LDS words), so the quarter loop is one straight-line body that the compiler
+// software-pipelines.  A 16-lane group reads 256 contiguous bytes of a tap slot: conflict-free for any mix of slots.
+struct LRec { uint4 v[6]; }; // one box record per lane: v[0..3] the 16 tap weights, v[4] rcp, flags, rows; v[5] cols, masked, area
 
 // x = hi + lo + r exactly in fp32 arithmetic: hi = RNE bf16(x), lo = RNE bf16(x - hi); row `row` of the A tile, channels
-// 4 lane .. 4 lane + 3, written into the XOR-swizzled hi / lo planes
-__device__ __forceinline__ void store_row(unsigned char *planes, int row, int lane, float4 v)
+// 4 c4 .. 4 c4 + 3, written into the XOR-swizzled hi / lo planes
+__device__ __forceinline__ void store_quad(unsigned char *planes, int row, int c4, float4 v)
 {
     const float x[4] = {v.x, v.y, v.z, v.w};
     union { __bf16 b[4]; uint2 u; } hi, lo;
@@ -299,14 +249,14 @@ __device__ __forceinline__ void store_row(unsigned char *planes, int row, int la
         hi.b[j] = (__bf16)x[j];
         lo.b[j] = (__bf16)(x[j] - (float)hi.b[j]);
     }
-    const int off = row * kRowBytes + ((((lane >> 1) ^ (row & 15)) << 4) | ((lane & 1) << 3));
+    const int off = row * kRowBytes + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
     *reinterpret_cast<uint2 *>(planes + off) = hi.u;
     *reinterpret_cast<uint2 *>(planes + kPlane + off) = lo.u;
 }
 
 struct Item { int tile, scale, view; unsigned rest; bool valid; }; // rest: live views of (tile, scale) above `view`
 
-template <int TERMS>
+template <int TERMS, bool DIAG>
 __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 {
     __shared__ float4 s_taps[kMaxSlots * 64];                       // 126 KiB: the tap window of the current item
@@ -339,12 +289,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         return it;
     };
 
-    float bcol[kMaxScales], brelu[kMaxScales];
-#pragma unroll
-    for (int s = 0; s < kMaxScales; ++s) {
-        bcol[s] = (s < a.n_scales && a.sc[s].bias) ? a.sc[s].bias[wave * 32 + r] : 0.0f;
-        brelu[s] = relu_t(bcol[s]);
-    }
+    auto bias_of = [&](int scale) { return a.sc[scale].bias ? a.sc[scale].bias[wave * 32 + r] : 0.0f; };
 
     // output rows of a tile: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 MFMA block, column r
     auto write_tile = [&](int tile, const f32x16 &sum, bool have_sum) {
@@ -352,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         float extra = 0.0f; // fully masked (view, scale) items of this tile: vox = 0 -> relu(bias)
 #pragma unroll
         for (int s = 0; s < kMaxScales; ++s)
-            if (s < a.n_scales) extra += (float)(a.n_views - __popc(live_of(tile, s))) * brelu[s];
+            if (s < a.n_scales) extra += (float)(a.n_views - __popc(live_of(tile, s))) * relu_t(bias_of(s));
         float *ocol = a.out + wave * 32 + r;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -368,16 +313,17 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     };
 
     // LDS-DMA of the item's tap window: slot s = (window row, window column), 1 KiB per wave instruction
-    auto header_of = [&](const Item &it, uint4 &h0, uint4 &h1) {
-        const uint4 *hdr = reinterpret_cast<const uint4 *>(a.sc[it.scale].hdrs + ((size_t)it.view * a.n_tiles + it.tile) * kHdrBytes);
-        h0 = hdr[0];
-        h1 = hdr[1];
+    // tile headers travel in SGPRs: a scalar load issued one item ahead, waited for (lgkmcnt) where the header is used
+    auto header_of = [&](const Item &it, i32x8 &hd) {
+        const unsigned char *p = a.sc[it.scale].hdrs + ((size_t)it.view * a.n_tiles + it.tile) * kHdrBytes;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(hd) : "s"(p));
     };
-    auto issue_fills = [&](const Item &it, const uint4 &h0, const uint4 &h1) {
+    auto header_wait = [&](i32x8 &hd) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hd)); };
+    auto issue_fills = [&](const Item &it, const i32x8 &hd) {
         const FusedScale &sc = a.sc[it.scale];
-        const int flags = uniform_i((int)h0.x), n_slots = uniform_i((int)h0.y), cwid = uniform_i((int)h0.z), inv = uniform_i((int)h0.w);
+        const int flags = hd[0], n_slots = hd[1], cwid = hd[2], inv = hd[3];
         if (flags & kTileDirect) return;
-        const int x0 = uniform_i((int)h1.x), t0 = uniform_i((int)h1.y), top_rows = uniform_i((int)h1.z), b0 = uniform_i((int)h1.w);
+        const int x0 = hd[4], t0 = hd[5], top_rows = hd[6], b0 = hd[7];
         const int Wp = sc.Wf + 2;
         const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)it.view * (sc.Hf + 2) * Wp * kSlotBytes;
         for (int s = wave; s < n_slots; s += kThreads / 64) {
@@ -389,55 +335,78 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         }
     };
 
-    // pool this wave's four boxes of the item into rows 4 wave .. 4 wave + 3 of the A tile
+    // pool this wave's four boxes of the item into rows 4 wave .. 4 wave + 3 of the A tile (lane = box lane >> 4, channel
+    // quad lane & 15 of each 64-channel quarter)
+    const int grp = lane >> 4, cq = lane & 15;
+    LRec rec; // record of THIS lane's box of the item to be pooled next
+    auto load_record = [&](const Item &it) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(a.sc[it.scale].recs + (((size_t)it.view * a.n_tiles + it.tile) * kTileBoxes + 4 * wave + grp) * kRecBytes);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rec.v[k] = p[k];
+    };
     auto pool = [&](const Item &it, int tflags) {
         const FusedScale &sc = a.sc[it.scale];
-        const unsigned char *recs = sc.recs + (((size_t)it.view * a.n_tiles + it.tile) * kTileBoxes + 4 * wave) * kRecBytes;
         const bool direct = (tflags & kTileDirect) != 0;
         const unsigned Wp = (unsigned)sc.Wf + 2u;
         const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)it.view * (sc.Hf + 2) * Wp * kSlotBytes;
-        SRec rc;
-        sload_rec(rc, recs);
-        swait_rec(rc);
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j) {
-            SRec nx;
-            sload_rec(nx, recs + (j + 1) * kRecBytes); // one spare record follows the last tile of the workspace
-            const int flags = rc.t[1];
-            const int row = 4 * wave + j;
-            if (!(flags & kVis)) {
-                const float z = __int_as_float(rc.t[6]);
-                store_row(s_planes, row, lane, make_float4(z, z, z, z));
-            } else {
-                const float rcp = __int_as_float(rc.t[0]);
-                unsigned rw[4] = {(unsigned)rc.t[2] & 0xffffu, (unsigned)rc.t[2] >> 16, (unsigned)rc.t[3] & 0xffffu, (unsigned)rc.t[3] >> 16};
-                const unsigned cl[4] = {(unsigned)rc.t[4] & 0xffffu, (unsigned)rc.t[4] >> 16, (unsigned)rc.t[5] & 0xffffu, (unsigned)rc.t[5] >> 16};
-                if (direct) {
+        const float wt[16] = {__uint_as_float(rec.v[0].x), __uint_as_float(rec.v[0].y), __uint_as_float(rec.v[0].z), __uint_as_float(rec.v[0].w),
+                              __uint_as_float(rec.v[1].x), __uint_as_float(rec.v[1].y), __uint_as_float(rec.v[1].z), __uint_as_float(rec.v[1].w),
+                              __uint_as_float(rec.v[2].x), __uint_as_float(rec.v[2].y), __uint_as_float(rec.v[2].z), __uint_as_float(rec.v[2].w),
+                              __uint_as_float(rec.v[3].x), __uint_as_float(rec.v[3].y), __uint_as_float(rec.v[3].z), __uint_as_float(rec.v[3].w)};
+        const float rcp = __uint_as_float(rec.v[4].x), masked = __uint_as_float(rec.v[5].z);
+        const bool vis = (rec.v[4].y & (unsigned)kVis) != 0u;
+        // tap coordinates of a masked box are meaningless: point them at slot / pixel 0 (the value is discarded)
+        unsigned rw[4] = {rec.v[4].z & 0xffffu, rec.v[4].z >> 16, rec.v[4].w & 0xffffu, rec.v[4].w >> 16};
+        unsigned cl[4] = {rec.v[5].x & 0xffffu, rec.v[5].x >> 16, rec.v[5].y & 0xffffu, rec.v[5].y >> 16};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) rw[k] *= Wp;
-                }
-                float4 res;
-#define VFA_VARIANT(DY, DX)                                                                          \
-    res = direct ? pool_box<true, DY, DX>(s_taps, img, rw, cl, lane, rc.w, rcp)                      \
-                 : pool_box<false, DY, DX>(s_taps, img, rw, cl, lane, rc.w, rcp);                    \
-    break;
-                switch ((flags >> 1) & 15) { // DXC | DYC << 2
-                case 0: VFA_VARIANT(0, 0)
-                case 1: VFA_VARIANT(0, 1)
-                case 2: VFA_VARIANT(0, 2)
-                case 4: VFA_VARIANT(1, 0)
-                case 5: VFA_VARIANT(1, 1)
-                case 6: VFA_VARIANT(1, 2)
-                case 8: VFA_VARIANT(2, 0)
-                case 9: VFA_VARIANT(2, 1)
-                default: VFA_VARIANT(2, 2)
-                }
-#undef VFA_VARIANT
-                store_row(s_planes, row, lane, res);
-            }
-            swait_rec(nx);
-            rc = nx;
+        for (int k = 0; k < 4; ++k) {
+            rw[k] = vis ? (direct ? rw[k] * Wp : rw[k]) : 0u;
+            cl[k] = vis ? cl[k] : 0u;
         }
+        const int row = 4 * wave + grp;
+        // tap positions in float4 units (LDS: inside the window; direct: inside the view's image): row part + column part
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rw[k] = rw[k] * 64u + (unsigned)cq;
+            cl[k] = cl[k] * 64u;
+        }
+        auto quarters = [&](auto is_direct) {
+            constexpr bool D = decltype(is_direct)::value;
+            // 16 steps = 4 quarters x 4 samples (lt, rb, rt, lb); the taps of step k + 1 are requested before step k is
+            // evaluated and the scheduler may not look further (the W fragments hold half of the register file)
+            auto fetch = [&](int step, float4 (&t)[4]) {
+                const int q = step >> 2, smp = step & 3;
+                const int ri = (smp == 0 || smp == 2) ? 0 : 2, ci = (smp == 0 || smp == 3) ? 0 : 2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned o = rw[ri + (k >> 1)] + cl[ci + (k & 1)] + (unsigned)(q * 16);
+                    if constexpr (D) t[k] = *reinterpret_cast<const float4 *>(img + (size_t)o * 16);
+                    else t[k] = s_taps[o];
+                }
+            };
+            float4 now[4], nxt4[4], box = make_float4(0.f, 0.f, 0.f, 0.f);
+            fetch(0, now);
+#pragma unroll
+            for (int step = 0; step < 16; ++step) {
+                const int q = step >> 2, smp = step & 3;
+                if (step + 1 < 16) fetch(step + 1, nxt4);
+                const float4 v = sample4(now[0], now[1], now[2], now[3], wt[4 * smp + 0], wt[4 * smp + 1], wt[4 * smp + 2], wt[4 * smp + 3]);
+                // (((lt + rb) - rt) - lb): the samples arrive in exactly this order (A.6)
+                if (smp == 0) box = v;
+                else if (smp == 1) box = make_float4(box.x + v.x, box.y + v.y, box.z + v.z, box.w + v.w);
+                else box = make_float4(box.x - v.x, box.y - v.y, box.z - v.z, box.w - v.w);
+                if (smp == 3) {
+                    float4 res = make_float4(box.x * rcp, box.y * rcp, box.z * rcp, box.w * rcp);
+                    if (!vis) res = make_float4(masked, masked, masked, masked);
+                    store_quad(s_planes, row, q * 16 + cq, res);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) now[k] = nxt4[k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (direct) quarters(std::true_type{});
+        else quarters(std::false_type{});
     };
 
     Frag w[kSteps];
@@ -461,54 +430,86 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         for (int t2 = t_begin; t2 < (cur.valid ? cur.tile : t_end); ++t2) write_tile(t2, none, false);
     }
     if (!cur.valid) return;
-    uint4 nh0, nh1;
-    header_of(cur, nh0, nh1);
-    issue_fills(cur, nh0, nh1);
-    int cur_flags = uniform_i((int)nh0.x);
+    const int dbg = DIAG ? a.debug : 0;
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+    auto tick = [&](int k) { // diagnostic build: cycles of this wave between consecutive marks
+        if (DIAG && (dbg & kDbgStamps)) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            stamp[k] += now - t_prev;
+            t_prev = now;
+        }
+    };
+    i32x8 nh;
+    header_of(cur, nh);
+    load_record(cur);
+    header_wait(nh);
+    if (!(dbg & kDbgNoFills)) issue_fills(cur, nh);
+    int cur_flags = nh[0], nxt_flags = 0;
+    Item nxt = seek(cur.tile, cur.scale, cur.rest);
+    if (nxt.valid) header_of(nxt, nh);
     int w_scale = -1;
+    float bc = 0.0f;
     f32x16 sum;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
+    if (DIAG) t_prev = __builtin_amdgcn_s_memtime();
 
+    // Per item:  wait for its tap window | pool -> A tile | issue the NEXT item's window and box records, fetch the header
+    // after that | MFMAs of this item (the DMA and the loads land underneath).  Headers run two items ahead.
     while (cur.valid) {
-        const Item nxt = seek(cur.tile, cur.scale, cur.rest);
-        if (nxt.valid) header_of(nxt, nh0, nh1); // needed after the MFMA-side barrier: in flight until then
-        if (cur.scale != w_scale) { // W of this scale: lands while the boxes are pooled
-            load_weights(cur.scale);
-            w_scale = cur.scale;
-        }
+        Item nn;
+        nn.valid = false;
+        if (nxt.valid) nn = seek(nxt.tile, nxt.scale, nxt.rest);
+        tick(0);
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's share of the tap window has landed
         __syncthreads();                    // ... and everybody else's
-        pool(cur, cur_flags);
+        tick(1);
+        if (cur.scale != w_scale) { // W and bias of this scale: land while the boxes are pooled
+            load_weights(cur.scale);
+            bc = bias_of(cur.scale);
+            w_scale = cur.scale;
+        }
+        if (!(dbg & kDbgNoPool)) pool(cur, cur_flags);
+        tick(2);
         __syncthreads();                    // A tile complete; the tap window is free again
-        if (nxt.valid) issue_fills(nxt, nh0, nh1); // in flight under the MFMAs below
+        tick(3);
+        if (nxt.valid) {
+            header_wait(nh);
+            if (!(dbg & kDbgNoFills)) issue_fills(nxt, nh); // in flight under the MFMAs below
+            nxt_flags = nh[0];
+            load_record(nxt); // this lane's box of the next item: lands under the MFMAs
+        }
+        if (nn.valid) header_of(nn, nh);
+        tick(4);
 
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        const unsigned char *pa = s_planes + frag_base;
+        if (!(dbg & kDbgNoMfma)) {
+            const unsigned char *pa = s_planes + frag_base;
 #pragma unroll
-        for (int c = 0; c < kSteps / 2; ++c) {
-            const int off0 = ((2 * c) ^ (key >> 1)) << 5, off1 = ((2 * c + 1) ^ (key >> 1)) << 5;
-            const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(pa + off0);
-            const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(pa + off1);
-            const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off0);
-            const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off1);
-            // the four hi products first: they cover the latency of the lo reads
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].lo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].lo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].hi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].hi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, w[2 * c].hi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].hi, acc, 0, 0, 0);
-            if (TERMS >= 4) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, w[2 * c].lo, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].lo, acc, 0, 0, 0);
+            for (int c = 0; c < kSteps / 2; ++c) {
+                const int off0 = ((2 * c) ^ (key >> 1)) << 5, off1 = ((2 * c + 1) ^ (key >> 1)) << 5;
+                const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(pa + off0);
+                const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(pa + off1);
+                const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off0);
+                const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off1);
+                // the four hi products first: they cover the latency of the lo reads
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].lo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].lo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, w[2 * c].hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].hi, acc, 0, 0, 0);
+                if (TERMS >= 4) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, w[2 * c].lo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].lo, acc, 0, 0, 0);
+                }
             }
         }
-        const float bc = cur.scale == 0 ? bcol[0] : (cur.scale == 1 ? bcol[1] : bcol[2]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[i] + bc); // vfa_op.py:124; vfanet.py:79, 82
+        tick(5);
 
         if (!nxt.valid || nxt.tile != cur.tile) {
             write_tile(cur.tile, sum, true);
@@ -516,15 +517,20 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
             for (int t2 = cur.tile + 1; t2 < (nxt.valid ? nxt.tile : t_end); ++t2) write_tile(t2, sum, false);
         }
+        tick(6);
+        if (DIAG) stamp[7] += 1;
         cur = nxt;
-        cur_flags = uniform_i((int)nh0.x);
+        cur_flags = nxt_flags;
+        nxt = nn;
     }
+    if (DIAG && (dbg & kDbgStamps) && a.diag && tid == 0)
+        for (int k = 0; k < 8; ++k) a.diag[(size_t)blockIdx.x * 8 + k] = stamp[k];
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
-    size_t live[kMaxScales], hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], total;
+    size_t live[kMaxScales], hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], diag, total;
     int tiles_l, tiles_w, n_tiles;
 };
 inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
@@ -541,6 +547,8 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
         w.recs[s] = off;  off = align_up(off + (on ? ((size_t)n_views * w.n_tiles * kTileBoxes + 1) * kRecBytes : 0), 256);
         w.wfrag[s] = off; off = align_up(off + (on ? (size_t)8 * kSteps * 2 * 64 * 16 : 0), 256);
     }
+    w.diag = off;
+    off = align_up(off + 512 * 8 * sizeof(unsigned long long), 256); // diagnostic build: 8 counters per workgroup
     w.total = off;
     return w;
 }
@@ -604,8 +612,8 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
                                    size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales, const int *feat_hw,
                                    int accumulate, int flags, void *stream)
 {
-    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
-    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xff00)) return VFA_ERR_BAD_ARGUMENT;
+    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xff;
+    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xffff00)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales || !feat_hw || !integrals ||
         (terms != 0 && terms != 3 && terms != 4))
         return VFA_ERR_BAD_ARGUMENT;
@@ -634,6 +642,8 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     }
     a.n_scales = n_scales; a.n_views = n_views; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles;
     a.out = out; a.accumulate = accumulate;
+    a.debug = debug;
+    a.diag = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(ws) + lay.diag);
     int n_cu = 256;
     {
         int dev = 0, cus = 0;
@@ -644,10 +654,13 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     if (reserved_cus > 0 && n_cu - reserved_cus >= 8) n_cu -= reserved_cus;
     int nblk = lay.n_tiles < n_cu ? lay.n_tiles : n_cu;
     nblk = (nblk + 7) / 8 * 8; // xcd_contiguous deals whole eighths; surplus blocks find an empty range and leave
-    if (terms == 4)
-        hipLaunchKernelGGL((pool_collapse_kernel<4>), dim3(nblk), dim3(kThreads), 0, s, a);
+    if (nblk > 512) nblk = 512;
+    if (debug) // diagnostic build (ablations / cycle stamps): never used by the product path
+        hipLaunchKernelGGL((pool_collapse_kernel<3, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+    else if (terms == 4)
+        hipLaunchKernelGGL((pool_collapse_kernel<4, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     else
-        hipLaunchKernelGGL((pool_collapse_kernel<3>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((pool_collapse_kernel<3, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 

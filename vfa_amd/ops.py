@@ -342,7 +342,7 @@ def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_
     return workspace
 
 
-def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=False, terms=0, reserved_cus=0):
+def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0):
     """out (L*W, 256) (+)= sum_scale sum_view relu(vox . W^T + b): pooling + collapse + ReLU + view / scale sum in one
     persistent kernel, the voxel features never touch HBM (reference vfa_op.py:112-125, vfanet.py:79, 82).
 
@@ -359,6 +359,7 @@ def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=Fa
     biases = [None if b is None else _f32c(b) for b in (biases if biases is not None else [None] * ns)]
     hw = _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)])
     _launch("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array(biases), _lib.ptr(workspace),
-            workspace.numel(), _lib.ptr(out), n, L, W, ns, hw, 1 if accumulate else 0, _lib.collapse_flags(terms, reserved_cus),
+            workspace.numel(), _lib.ptr(out), n, L, W, ns, hw, 1 if accumulate else 0,
+            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xff) << 16),  # debug: diagnostic build, tools/ only
             _lib.current_stream_handle(), tag=(n, L, W, ns))
     return out
