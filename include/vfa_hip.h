@@ -202,9 +202,20 @@ int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, voi
  *   integrals / biases = HOST arrays of n_scales device pointers ((n_views, Hf+2, Wf+2, 256) each / (256) or NULL);
  *   workspace = what vfa_frame_records_f32 filled for the same (n_views, L, W, n_scales, feat_hw). */
 size_t vfa_frame_workspace_bytes(int n_views, int L, int W, int n_scales);
+/* Where things are inside that workspace (tests and tools/ read the records back): offsets[5 k + {0..4}] = live-view masks,
+ * direct-item masks, tile headers (32 B), box records (96 B), split weight of scale k; offsets[15] diagnostics, offsets[16]
+ * total bytes; tiles = {tile rows, tile columns, tap-window capacity in slots}.  Tiles are 4 x 8 cells. */
+int vfa_frame_workspace_layout(int n_views, int L, int W, int n_scales, size_t *offsets, int *tiles);
 int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
                           int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
                           const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream);
+/* Box pooling alone from the same workspace: vox (n_views, L * W, 256) fp32, BIT-IDENTICAL to vfa_project_gather_f32 (layer-major,
+ * nl = 1): four bilinear samples of the integral image of scale `scale`, (((lt + rb) - rt) - lb) / area * visible.
+ *                                                                                            replaces vfa_op.py:112-120
+ * One 64-channel quarter of one (view, tile) per workgroup; the tile's tap window comes in by LDS-DMA, so every distinct tap is
+ * read from L2 / HBM once; bound by the HBM write of `vox`.  Hf, Wf must be the sizes the records of `scale` were built for. */
+int vfa_pool_windows_f32(const float *integral, const void *workspace, size_t workspace_bytes, float *vox, int n_views, int L, int W,
+                         int n_scales, int scale, int Hf, int Wf, void *stream);
 int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, const void *workspace,
                                    size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales, const int *feat_hw,
                                    int accumulate, int flags, void *stream);

@@ -85,6 +85,7 @@ def test_fused_frame_matches_unfused_kernels_and_float64(name, n_cam, crop, monk
         torch.cuda.synchronize()
         assert "vfa_pool_collapse_relu_sum_f32" in kt.summary() and "vfa_project_gather_f32" not in kt.summary(), sorted(kt.summary())
         monkeypatch.setattr(vfa_op, "FUSED_POOL", False)
+        monkeypatch.setattr(vfa_op, "WINDOW_POOL", False)
         with ops.KernelTimer() as kt:
             unfused = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
         torch.cuda.synchronize()
@@ -220,20 +221,12 @@ def test_frame_records_match_the_box_parameter_kernel():
     calibs = wl["calibs"].to(dev)
     ws = ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes).cpu().numpy()
     n = 3
-    tiles_l, tiles_w = (L + 3) // 4, (W + 7) // 8
+    lay = ops.frame_workspace_layout(n, L, W, 3)
+    tiles_l, tiles_w = lay["tiles_l"], lay["tiles_w"]
+    assert (tiles_l, tiles_w) == ((L + 3) // 4, (W + 7) // 8) and lay["total"] <= ws.size
     n_tiles = tiles_l * tiles_w
-
-    def up(v):
-        return (v + 255) // 256 * 256
-    off = 0
     for s, (Hf, Wf) in enumerate(sizes):
-        live_off = off
-        off = up(off + n_tiles * 4)
-        hdr_off = off
-        off = up(off + n * n_tiles * 32)
-        rec_off = off
-        off = up(off + (n * n_tiles * 32 + 1) * 96)
-        off = up(off + 8 * 16 * 2 * 64 * 16)
+        live_off, direct_off, hdr_off, rec_off = lay["live"][s], lay["direct"][s], lay["hdrs"][s], lay["recs"][s]
         rec = ws[rec_off:rec_off + n * n_tiles * 32 * 96].view(np.uint32).reshape(n, tiles_l, tiles_w, 4, 8, 24)
         box, area, vis = ops.box_params(calibs, grid.reshape(-1, 3), zl, co, kind, img_wh, (Hf, Wf))
         area = area.cpu().numpy().reshape(n, L, W)
@@ -250,3 +243,68 @@ def test_frame_records_match_the_box_parameter_kernel():
         tile_any = tile_vis.reshape(n, tiles_l, 4, tiles_w, 8).any(axis=(2, 4)).reshape(n, n_tiles)
         want_live = sum((tile_any[v].astype(np.uint32) << v) for v in range(n))
         assert np.array_equal(live, want_live), f"scale {s}: live-view masks"
+        # items whose tap window exceeds the LDS capacity are flagged in the header and in the direct mask, nowhere else
+        hdr = ws[hdr_off:hdr_off + n * n_tiles * 32].view(np.uint32).reshape(n, n_tiles, 8)
+        is_direct = ((hdr[..., 0] >> 1) & 1).astype(bool) & (hdr[..., 0] & 1).astype(bool)
+        assert ((hdr[..., 1][~is_direct]) <= lay["max_slots"]).all()
+        direct = ws[direct_off:direct_off + n_tiles * 4].view(np.uint32)
+        assert np.array_equal(direct, sum((is_direct[v].astype(np.uint32) << v) for v in range(n))), f"scale {s}: direct masks"
+        assert (direct & ~live == 0).all()
+
+
+@pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", None, None), ("multiviewc_200x200x1", 2, (37, 53)),
+                                             ("wildtrack_480x1440x1", 2, (64, 1440))])
+def test_window_pooling_kernel_is_bitwise_the_direct_kernel(name, n_cam, crop):
+    """`vfa_pool_windows_f32` (LDS tap windows from the per-frame records) against `vfa_project_gather_f32` (which is pinned
+    bitwise to the reference's voxel features): every scale, every camera, ragged grids, tiles whose window does not fit."""
+    import vfa_amd
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload(name, channels=256, seed=6, **({"n_cam": n_cam} if n_cam else {}))
+    n = wl["n_cam"]
+    grid = wl["grid"] if crop is None else wl["grid"][:, 7:7 + crop[0], 3:3 + crop[1]].contiguous()
+    grid = grid.to(dev)
+    L, W = grid.shape[1:3]
+    mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+    zl, co = mod._kernel_geometry(dev)
+    kind = _lib.CONV_KIND[wl["args"].data]
+    img_wh = wl["args"].image_size[::-1]
+    calibs = wl["calibs"].to(dev)
+    lats = [torch.cat([wl["features"][c][s] for c in range(n)]).to(dev) for s in range(3)]
+    ws = ops.frame_records(calibs, grid, zl, co, kind, img_wh, [tuple(l.shape[-2:]) for l in lats])
+    for k, lat in enumerate(lats):
+        integral = ops.integral_image(lat)
+        got = ops.pool_windows(integral, ws, (L, W), 3, k)
+        want = ops.project_gather(integral, calibs.reshape(n, 12).contiguous(), grid.reshape(-1, 3).contiguous(), zl, co, kind,
+                                  img_wh, kernel="direct")
+        same = (got.view(torch.int32) == want.view(torch.int32)) | ((got == 0) & (want == 0))
+        assert bool(same.all()), f"{name} scale {k}: {int((~same).sum())} voxel features differ"
+        assert float(want.abs().max()) > 0
+
+
+def test_window_path_is_used_when_the_fused_kernel_is_off(monkeypatch):
+    import vfa_amd
+    from vfa_amd import ops, vfa_op
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload("multiviewc_200x200x1", channels=256, seed=1, n_cam=3)
+    grid = wl["grid"][:, 50:90, 20:100].contiguous().to(dev)
+    mods = _mods(wl, dev)
+    lats = [torch.cat([wl["features"][c][s] for c in range(3)]).to(dev) for s in range(3)]
+    calibs = wl["calibs"].to(dev)
+    outs = {}
+    for fused, window in ((True, True), (False, True), (False, False)):
+        monkeypatch.setattr(vfa_op, "FUSED_POOL", fused)
+        monkeypatch.setattr(vfa_op, "WINDOW_POOL", window)
+        with torch.no_grad(), ops.KernelTimer() as kt:
+            outs[(fused, window)] = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        torch.cuda.synchronize()
+        names = set(kt.summary())
+        assert ("vfa_pool_collapse_relu_sum_f32" in names) == fused
+        assert ("vfa_pool_windows_f32" in names) == (window and not fused)
+        assert ("vfa_project_gather_f32" in names) == (not fused and not window)
+    # window path and legacy path share the collapse kernel and bit-identical voxel features: identical maps
+    assert torch.equal(outs[(False, True)], outs[(False, False)])
+    scale = outs[(False, False)].abs().max().item()
+    torch.testing.assert_close(outs[(True, True)], outs[(False, False)], rtol=RTOL, atol=2 * ATOL_REL * scale)

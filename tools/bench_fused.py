@@ -47,24 +47,29 @@ with torch.no_grad():
     ws = ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights)
     print(f"{name}: frame_records {timed(lambda: ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws)):.1f} us")
     out = torch.empty(L * W, 256, device=dev)
+    vox = torch.empty(n, L * W, 256, device=dev)
+    cal12, gflat = calibs.reshape(n, 12).contiguous(), grid.reshape(-1, 3).contiguous()
+    for k in range(3):
+        tw = timed(lambda: ops.pool_windows(integrals[k], ws, (L, W), 3, k, out=vox))
+        tt = timed(lambda: ops.project_gather(integrals[k], cal12, gflat, zl, co, kind, img_wh, out=vox, kernel="tap_cache"))
+        tc = timed(lambda: ops.collapse_relu_sum(vox, weights[k], biases[k], out=out))
+        alg = n * 256 * sizes[k][0] * sizes[k][1] * 4 + n * L * W * 1024 + L * W * 12 + n * 48
+        print(f"  scale {k}: pool_windows {tw:6.1f} us ({alg / tw / 1e3:6.0f} GB/s algorithmic, {alg / tw / 8e6:.2f} of 8 TB/s) | "
+              f"round-1 tap-cache kernel {tt:6.1f} us | collapse_relu_sum {tc:6.1f} us")
     # header statistics
     host = ws.cpu().numpy()
-    tiles = ((L + 3) // 4) * ((W + 7) // 8)
-    off = 0
-    up = lambda v: (v + 255) // 256 * 256  # noqa: E731
+    lay = ops.frame_workspace_layout(n, L, W, 3)
+    tiles = lay["tiles_l"] * lay["tiles_w"]
     for s in range(3):
-        off = up(off + tiles * 4)
+        off = lay["hdrs"][s]
         hdr = host[off:off + n * tiles * 32].view(np.uint32).reshape(n * tiles, 8)
-        off = up(off + n * tiles * 32)
-        off = up(off + (n * tiles * 32 + 1) * 96)
-        off = up(off + 8 * 16 * 2 * 64 * 16)
         live = hdr[:, 0] & 1
         direct = (hdr[:, 0] >> 1) & 1
         slots = hdr[:, 1][(live == 1) & (direct == 0)]
-        print(f"  scale {s}: items {n * tiles}, live {int(live.sum())}, direct {int(direct.sum())}, slots mean {slots.mean():.1f} max {slots.max()}")
-    diag_off = off
+        print(f"  scale {s}: items {n * tiles}, live {int(live.sum())}, direct {int((direct & live).sum())}, slots mean {slots.mean():.1f} max {slots.max()}")
+    diag_off = lay["diag"]
     for mask, label in ((0, "full"), (128, "full + stamps"), (1, "no fills"), (2, "no pool"), (4, "no mfma"), (3, "no fills, no pool"),
-                        (6, "no pool, no mfma"), (5, "no fills, no mfma"), (7, "skeleton only")):
+                        (6, "no pool, no mfma"), (5, "no fills, no mfma"), (7, "skeleton only"), (64, "direct items only")):
         us = timed(lambda: ops.pool_collapse(integrals, biases, ws, (L, W), out=out, debug=mask))
         print(f"  pool_collapse [{label:>18}] {us:8.1f} us")
         if mask == 128:
@@ -72,8 +77,8 @@ with torch.no_grad():
             d = ws[diag_off:diag_off + 256 * 64].cpu().numpy().view(np.uint64).reshape(256, 8).astype(np.float64)
             d = d[d[:, 7] > 0]
             items = d[:, 7]
-            names = ["top: seek + first record", "wait window + barrier", "pool (+ W loads)", "barrier", "issue fills + header",
-                     "MFMA + epilogue", "tile store"]
+            names = ["top: seek", "wait window + barrier", "tile store + W loads + pool", "barrier", "issue fills + records + header",
+                     "MFMA + epilogue", "loop tail"]
             print(f"    stamps of wave 0, cycles per item (mean over {len(d)} workgroups, {items.mean():.1f} items each):")
             for k, nm in enumerate(names):
                 print(f"      {nm:28s} {np.mean(d[:, k] / items):9.0f}")

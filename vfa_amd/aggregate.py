@@ -161,6 +161,11 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
             # geometry once per frame + one persistent kernel for pooling, collapse, ReLU and every sum: vox stays on chip
             vfa_op.fused_frame([vfa8, vfa16, vfa32], [lat8, lat16, lat32], calibs, grid, crange, out=ortho,
                                reserved_cus=reserved)
+        elif (vfa_op.fused_frame_ok([vfa8, vfa16, vfa32], n, "window")
+              and n * length * width * 1024 <= vfa_op.VOX_BYTES_LIMIT):
+            # geometry once per frame; per scale: LDS-window pooling kernel (vox in HBM, bit-exact) + MFMA collapse kernel
+            vfa_op.window_frame([vfa8, vfa16, vfa32], [lat8, lat16, lat32], calibs, grid, crange, out=ortho,
+                                reserved_cus=reserved)
         else:
             for i, (m, lat) in enumerate(work):
                 m.project_sum(lat, calibs, grid, crange, out=ortho, accumulate=i > 0, reserved_cus=reserved)

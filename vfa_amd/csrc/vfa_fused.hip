@@ -53,6 +53,7 @@ struct RecordArgs {
     int n_views, L, W, tiles_w, n_tiles, n_scales;
     ScaleDims dims[kMaxScales];
     unsigned *live[kMaxScales];      // (n_tiles) bit v = view v has a visible box in the tile
+    unsigned *direct[kMaxScales];    // (n_tiles) bit v = ... and the tile's tap window does not fit LDS (subset of live)
     unsigned char *hdrs[kMaxScales]; // (n_views, n_tiles, 32 B)
     unsigned char *recs[kMaxScales]; // (n_views, n_tiles, 32 boxes, 96 B)
 };
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
                 hdr[0] = make_uint4((any_live ? kTileLive : 0) | (direct ? kTileDirect : 0), (unsigned)n_slots, (unsigned)cwid, (unsigned)inv);
                 hdr[1] = make_uint4((unsigned)x0, (unsigned)t0, (unsigned)top_rows, (unsigned)b0);
                 if (any_live) atomicOr(a.live[s] + tile, 1u << view);
+                if (any_live && direct) atomicOr(a.direct[s] + tile, 1u << view);
             }
         }
     }
@@ -191,6 +193,45 @@ __global__ __launch_bounds__(256) void split_weight_frag_kernel(const float *__r
     out[((size_t)(wave * kSteps + s) * 2 + 1) * 64 + lane] = lo.u;
 }
 
+// Work balance of the persistent kernel: the cost of a tile is its number of live (view, scale) items, which varies with the
+// camera coverage.  chunk_start[c], c = 0..kChunks, cuts the tile sequence into kChunks pieces of equal cost (weight of a
+// tile = 1 + 4 x live items); a workgroup takes a contiguous run of chunks.  One workgroup, an LDS scan over per-thread sums.
+constexpr int kChunks = 1024;
+__global__ __launch_bounds__(1024) void tile_chunks_kernel(const unsigned *live0, const unsigned *live1, const unsigned *live2,
+                                                           int n_scales, int n_tiles, unsigned view_mask, int *chunk_start)
+{
+    __shared__ unsigned long long part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_tiles + 1023) / 1024, t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
+    auto weight = [&](int t) {
+        int items = __popc(live0[t] & view_mask);
+        if (n_scales > 1) items += __popc(live1[t] & view_mask);
+        if (n_scales > 2) items += __popc(live2[t] & view_mask);
+        return (unsigned long long)(1 + 4 * items);
+    };
+    unsigned long long local = 0;
+    for (int t = t0; t < t1; ++t) local += weight(t);
+    part[tid] = local;
+    for (int c = tid; c <= kChunks; c += 1024) chunk_start[c] = n_tiles;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { // inclusive Hillis-Steele scan
+        const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const unsigned long long total = part[1023];
+    unsigned long long before = part[tid] - local; // weight of all tiles in front of tile t
+    // chunk c starts at the first tile t with  before(t) * kChunks >= total * c
+    for (int t = t0; t < t1; ++t) {
+        // i.e. c <= before(t) K / total  and  c > before(t - 1) K / total
+        const unsigned long long hi = before * kChunks / total;
+        const long long lo = t == 0 ? 0 : (long long)((before - weight(t - 1)) * kChunks / total) + 1;
+        for (long long c = lo; c <= (long long)hi && c < kChunks; ++c) chunk_start[c] = t;
+        before += weight(t);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. pooling + collapse + bias + ReLU + view / scale sum
 // ------------------------------------------------------------------------------------------------
@@ -198,7 +239,7 @@ struct FusedScale {
     const float *integral;          // (n_views, Hf+2, Wf+2, 256) zero-bordered channels-last
     const float *bias;              // (256) or NULL
     const uint4 *wfrag;             // split_weight_frag_kernel output
-    const unsigned *live;           // (n_tiles)
+    const unsigned *live, *direct;  // (n_tiles) each
     const unsigned char *hdrs, *recs;
     int Hf, Wf;
 };
@@ -206,12 +247,13 @@ struct FusedArgs {
     FusedScale sc[kMaxScales];
     int n_scales, n_views, L, W, tiles_w, n_tiles;
     float *out;                     // (L * W, 256)
+    const int *chunk_start;         // (kChunks + 1) tile_chunks_kernel
     int accumulate;
     int debug;                      // diagnostic build only: ablation mask (kDbg*), results are then meaningless
     unsigned long long *diag;       // diagnostic build only: per workgroup 8 cycle counters
 };
 // diagnostic ablations (VFA_FLAG_DEBUG(mask), pool_collapse_kernel<TERMS, true> only)
-constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgStamps = 128;
+constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgStamps = 128; // (64: only the direct-item launch)
 
 struct Frag { bf16x8 hi, lo; };
 
@@ -256,22 +298,33 @@ __device__ __forceinline__ void store_quad(unsigned char *planes, int row, int c
 
 struct Item { int tile, scale, view; unsigned rest; bool valid; }; // rest: live views of (tile, scale) above `view`
 
-template <int TERMS, bool DIAG>
+// DIRECT = false: every item whose tap window fits LDS (all but the tiles right in front of a camera); DIRECT = true: a second
+// launch for exactly the others -- taps read straight from the integral image, contribution ADDED to the map.
+template <int TERMS, bool DIAG, bool DIRECT>
 __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 {
     __shared__ float4 s_taps[kMaxSlots * 64];                       // 126 KiB: the tap window of the current item
     __shared__ __align__(16) unsigned char s_planes[2 * kPlane];    // 32 KiB: bf16 hi / lo planes of the 32 x 256 A tile
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
 
-    // contiguous range of tiles for this workgroup; neighbouring ranges share an XCD (their tap windows overlap)
+    // Main launch: a contiguous range of tiles of equal COST for this workgroup (tile_chunks_kernel); neighbouring ranges
+    // share an XCD (their tap windows overlap).  Direct-item launch: tiles dealt round-robin -- those items sit in clusters
+    // in front of the cameras.
     const int nblk = gridDim.x;
     const int lb = (int)xcd_contiguous(blockIdx.x, (nblk + 7) / 8);
     if (lb >= nblk) return;
-    const int t_begin = (int)((long long)a.n_tiles * lb / nblk), t_end = (int)((long long)a.n_tiles * (lb + 1) / nblk);
+    const int t_step = DIRECT ? nblk : 1;
+    const int t_begin = DIRECT ? lb : uniform_i(a.chunk_start[(int)((long long)kChunks * lb / nblk)]);
+    const int t_end = DIRECT ? a.n_tiles : uniform_i(a.chunk_start[(int)((long long)kChunks * (lb + 1) / nblk)]);
     if (t_begin >= t_end) return;
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
 
-    auto live_of = [&](int tile, int scale) { return (unsigned)uniform_i((int)(a.sc[scale].live[tile] & view_mask)); };
+    auto live_all = [&](int tile, int scale) { return (unsigned)uniform_i((int)(a.sc[scale].live[tile] & view_mask)); };
+    // the views of (tile, scale) this launch works on
+    auto live_of = [&](int tile, int scale) {
+        const unsigned dm = a.sc[scale].direct[tile] & view_mask;
+        return (unsigned)uniform_i((int)(DIRECT ? dm : (a.sc[scale].live[tile] & view_mask & ~dm)));
+    };
     // first live item at or after (tile, scale) with view bits `rest`
     auto seek = [&](int tile, int scale, unsigned rest) {
         Item it;
@@ -283,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                 it.tile = tile; it.scale = scale; it.valid = true;
                 return it;
             }
-            if (++scale == a.n_scales) { scale = 0; ++tile; }
+            if (++scale == a.n_scales) { scale = 0; tile += t_step; }
             if (tile < t_end) rest = live_of(tile, scale);
         }
         return it;
@@ -295,9 +348,11 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     auto write_tile = [&](int tile, const f32x16 &sum, bool have_sum) {
         const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
         float extra = 0.0f; // fully masked (view, scale) items of this tile: vox = 0 -> relu(bias)
+        if (!DIRECT) {
 #pragma unroll
-        for (int s = 0; s < kMaxScales; ++s)
-            if (s < a.n_scales) extra += (float)(a.n_views - __popc(live_of(tile, s))) * relu_t(bias_of(s));
+            for (int s = 0; s < kMaxScales; ++s)
+                if (s < a.n_scales) extra += (float)(a.n_views - __popc(live_all(tile, s))) * relu_t(bias_of(s));
+        }
         float *ocol = a.out + wave * 32 + r;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -306,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             if (cl < a.L && cw < a.W) {
                 float *o = ocol + (size_t)(cl * a.W + cw) * kC;
                 float v = (have_sum ? sum[i] : 0.0f) + extra;
-                if (a.accumulate) v += *o; // the workgroup owns these rows: a plain read-modify-write
+                if (DIRECT || a.accumulate) v += *o; // the workgroup owns these rows: a plain read-modify-write
                 *o = v;
             }
         }
@@ -319,24 +374,33 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(hd) : "s"(p));
     };
     auto header_wait = [&](i32x8 &hd) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hd)); };
-    auto issue_fills = [&](const Item &it, const i32x8 &hd) {
+    // The window is brought in by LDS-DMA, 1 KiB (one slot) per wave instruction, slot s = (window row, window column).  The
+    // instructions are issued ONE AT A TIME between groups of MFMAs: eight waves issuing their whole share at once queue up
+    // behind the texture addresser for ~1000 cycles and enter the MFMA phase skewed by as much.
+    int f_slot = 0, f_n = 0, f_cw = 1, f_inv = 0, f_x0 = 0, f_t0 = 0, f_top = 0, f_b0 = 0, f_wp = 0;
+    const char *f_img = nullptr;
+    auto begin_fills = [&](const Item &it, const i32x8 &hd) {
         const FusedScale &sc = a.sc[it.scale];
-        const int flags = hd[0], n_slots = hd[1], cwid = hd[2], inv = hd[3];
-        if (flags & kTileDirect) return;
-        const int x0 = hd[4], t0 = hd[5], top_rows = hd[6], b0 = hd[7];
-        const int Wp = sc.Wf + 2;
-        const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)it.view * (sc.Hf + 2) * Wp * kSlotBytes;
-        for (int s = wave; s < n_slots; s += kThreads / 64) {
-            const int wr = (s * inv) >> 16, wc = s - wr * cwid;
-            const int y = wr < top_rows ? t0 + wr : b0 + (wr - top_rows), x = x0 + wc;
-            const char *src = img + ((size_t)(y + 1) * Wp + (x + 1)) * kSlotBytes + lane * 16;
+        f_n = (DIRECT || (hd[0] & kTileDirect)) ? 0 : hd[1];
+        f_cw = hd[2]; f_inv = hd[3]; f_x0 = hd[4]; f_t0 = hd[5]; f_top = hd[6]; f_b0 = hd[7];
+        f_wp = sc.Wf + 2;
+        f_img = reinterpret_cast<const char *>(sc.integral) + (size_t)it.view * (sc.Hf + 2) * f_wp * kSlotBytes;
+        f_slot = wave;
+    };
+    auto one_fill = [&]() {
+        if (f_slot < f_n) {
+            const int wr = (f_slot * f_inv) >> 16, wc = f_slot - wr * f_cw;
+            const int y = wr < f_top ? f_t0 + wr : f_b0 + (wr - f_top), x = f_x0 + wc;
+            const char *src = f_img + ((size_t)(y + 1) * f_wp + (x + 1)) * kSlotBytes + lane * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(s_taps + s * 64), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(s_taps + f_slot * 64), 16, 0, 0);
+            f_slot += kThreads / 64;
         }
     };
+    auto rest_fills = [&]() {
+        while (f_slot < f_n) one_fill();
+    };
 
-    // pool this wave's four boxes of the item into rows 4 wave .. 4 wave + 3 of the A tile (lane = box lane >> 4, channel
-    // quad lane & 15 of each 64-channel quarter)
     const int grp = lane >> 4, cq = lane & 15;
     LRec rec; // record of THIS lane's box of the item to be pooled next
     auto load_record = [&](const Item &it) {
@@ -344,9 +408,8 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 #pragma unroll
         for (int k = 0; k < 6; ++k) rec.v[k] = p[k];
     };
-    auto pool = [&](const Item &it, int tflags) {
+    auto pool = [&](const Item &it) {
         const FusedScale &sc = a.sc[it.scale];
-        const bool direct = (tflags & kTileDirect) != 0;
         const unsigned Wp = (unsigned)sc.Wf + 2u;
         const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)it.view * (sc.Hf + 2) * Wp * kSlotBytes;
         const float wt[16] = {__uint_as_float(rec.v[0].x), __uint_as_float(rec.v[0].y), __uint_as_float(rec.v[0].z), __uint_as_float(rec.v[0].w),
@@ -355,58 +418,49 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                               __uint_as_float(rec.v[3].x), __uint_as_float(rec.v[3].y), __uint_as_float(rec.v[3].z), __uint_as_float(rec.v[3].w)};
         const float rcp = __uint_as_float(rec.v[4].x), masked = __uint_as_float(rec.v[5].z);
         const bool vis = (rec.v[4].y & (unsigned)kVis) != 0u;
-        // tap coordinates of a masked box are meaningless: point them at slot / pixel 0 (the value is discarded)
+        // tap positions in float4 units (LDS: slot inside the window; DIRECT: pixel inside the view's padded image): row part +
+        // column part.  The coordinates of a masked box are meaningless: point them at slot / pixel 0 (the value is discarded).
         unsigned rw[4] = {rec.v[4].z & 0xffffu, rec.v[4].z >> 16, rec.v[4].w & 0xffffu, rec.v[4].w >> 16};
         unsigned cl[4] = {rec.v[5].x & 0xffffu, rec.v[5].x >> 16, rec.v[5].y & 0xffffu, rec.v[5].y >> 16};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            rw[k] = vis ? (direct ? rw[k] * Wp : rw[k]) : 0u;
-            cl[k] = vis ? cl[k] : 0u;
+            rw[k] = (vis ? (DIRECT ? rw[k] * Wp : rw[k]) : 0u) * 64u + (unsigned)cq;
+            cl[k] = (vis ? cl[k] : 0u) * 64u;
         }
         const int row = 4 * wave + grp;
-        // tap positions in float4 units (LDS: inside the window; direct: inside the view's image): row part + column part
+        // a 64-channel quarter at a time, its taps requested eight at a time (two samples; the W fragments hold half of the
+        // register file): the partner wave of the SIMD covers the two LDS latencies per quarter
+        auto pair = [&](int q, int ra, int ca, int rb2, int cb, const float *wa, const float *wb, float4 &sa, float4 &sb) {
+            float4 t[2][4]; // sample a = rows (ra, ra + 1) x cols (ca, ca + 1), sample b likewise: nw, ne, sw, se each
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            rw[k] = rw[k] * 64u + (unsigned)cq;
-            cl[k] = cl[k] * 64u;
-        }
-        auto quarters = [&](auto is_direct) {
-            constexpr bool D = decltype(is_direct)::value;
-            // 16 steps = 4 quarters x 4 samples (lt, rb, rt, lb); the taps of step k + 1 are requested before step k is
-            // evaluated and the scheduler may not look further (the W fragments hold half of the register file)
-            auto fetch = [&](int step, float4 (&t)[4]) {
-                const int q = step >> 2, smp = step & 3;
-                const int ri = (smp == 0 || smp == 2) ? 0 : 2, ci = (smp == 0 || smp == 3) ? 0 : 2;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned o = rw[ri + (k >> 1)] + cl[ci + (k & 1)] + (unsigned)(q * 16);
-                    if constexpr (D) t[k] = *reinterpret_cast<const float4 *>(img + (size_t)o * 16);
-                    else t[k] = s_taps[o];
+            for (int k = 0; k < 4; ++k) {
+                const unsigned oa = rw[ra + (k >> 1)] + cl[ca + (k & 1)] + (unsigned)(q * 16);
+                const unsigned ob = rw[rb2 + (k >> 1)] + cl[cb + (k & 1)] + (unsigned)(q * 16);
+                if constexpr (DIRECT) {
+                    t[0][k] = *reinterpret_cast<const float4 *>(img + (size_t)oa * 16);
+                    t[1][k] = *reinterpret_cast<const float4 *>(img + (size_t)ob * 16);
+                } else {
+                    t[0][k] = s_taps[oa];
+                    t[1][k] = s_taps[ob];
                 }
-            };
-            float4 now[4], nxt4[4], box = make_float4(0.f, 0.f, 0.f, 0.f);
-            fetch(0, now);
-#pragma unroll
-            for (int step = 0; step < 16; ++step) {
-                const int q = step >> 2, smp = step & 3;
-                if (step + 1 < 16) fetch(step + 1, nxt4);
-                const float4 v = sample4(now[0], now[1], now[2], now[3], wt[4 * smp + 0], wt[4 * smp + 1], wt[4 * smp + 2], wt[4 * smp + 3]);
-                // (((lt + rb) - rt) - lb): the samples arrive in exactly this order (A.6)
-                if (smp == 0) box = v;
-                else if (smp == 1) box = make_float4(box.x + v.x, box.y + v.y, box.z + v.z, box.w + v.w);
-                else box = make_float4(box.x - v.x, box.y - v.y, box.z - v.z, box.w - v.w);
-                if (smp == 3) {
-                    float4 res = make_float4(box.x * rcp, box.y * rcp, box.z * rcp, box.w * rcp);
-                    if (!vis) res = make_float4(masked, masked, masked, masked);
-                    store_quad(s_planes, row, q * 16 + cq, res);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) now[k] = nxt4[k];
-                __builtin_amdgcn_sched_barrier(0);
             }
+            sa = sample4(t[0][0], t[0][1], t[0][2], t[0][3], wa[0], wa[1], wa[2], wa[3]);
+            sb = sample4(t[1][0], t[1][1], t[1][2], t[1][3], wb[0], wb[1], wb[2], wb[3]);
         };
-        if (direct) quarters(std::true_type{});
-        else quarters(std::false_type{});
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            float4 lt, rb, rt, lb;
+            pair(q, 0, 0, 2, 2, wt + 0, wt + 4, lt, rb);
+            // (((lt + rb) - rt) - lb) * RN(1 / area)                                              (A.6)
+            float4 v = make_float4(lt.x + rb.x, lt.y + rb.y, lt.z + rb.z, lt.w + rb.w);
+            __builtin_amdgcn_sched_barrier(0);
+            pair(q, 0, 2, 2, 0, wt + 8, wt + 12, rt, lb);
+            v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
+            v = make_float4(v.x - lb.x, v.y - lb.y, v.z - lb.z, v.w - lb.w);
+            float4 res = make_float4(v.x * rcp, v.y * rcp, v.z * rcp, v.w * rcp);
+            if (!vis) res = make_float4(masked, masked, masked, masked);
+            store_quad(s_planes, row, q * 16 + cq, res);
+        }
     };
 
     Frag w[kSteps];
@@ -427,7 +481,8 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     Item cur = seek(t_begin, 0, live_of(t_begin, 0));
     {
         f32x16 none;
-        for (int t2 = t_begin; t2 < (cur.valid ? cur.tile : t_end); ++t2) write_tile(t2, none, false);
+        if (!DIRECT)
+            for (int t2 = t_begin; t2 < (cur.valid ? cur.tile : t_end); ++t2) write_tile(t2, none, false);
     }
     if (!cur.valid) return;
     const int dbg = DIAG ? a.debug : 0;
@@ -443,8 +498,10 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     header_of(cur, nh);
     load_record(cur);
     header_wait(nh);
-    if (!(dbg & kDbgNoFills)) issue_fills(cur, nh);
-    int cur_flags = nh[0], nxt_flags = 0;
+    if (!(dbg & kDbgNoFills)) {
+        begin_fills(cur, nh);
+        rest_fills();
+    }
     Item nxt = seek(cur.tile, cur.scale, cur.rest);
     if (nxt.valid) header_of(nxt, nh);
     int w_scale = -1;
@@ -452,6 +509,17 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     f32x16 sum;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
+    // a finished tile keeps its sums in registers until the NEXT barrier: its stores then drain under a whole item
+    int pend_tile = -1, pend_next = 0;
+    auto flush = [&]() {
+        if (pend_tile < 0) return;
+        write_tile(pend_tile, sum, true);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
+        if (!DIRECT)
+            for (int t2 = pend_tile + 1; t2 < pend_next; ++t2) write_tile(t2, sum, false); // fully masked tiles in between
+        pend_tile = -1;
+    };
     if (DIAG) t_prev = __builtin_amdgcn_s_memtime();
 
     // Per item:  wait for its tap window | pool -> A tile | issue the NEXT item's window and box records, fetch the header
@@ -464,19 +532,20 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's share of the tap window has landed
         __syncthreads();                    // ... and everybody else's
         tick(1);
+        flush();
         if (cur.scale != w_scale) { // W and bias of this scale: land while the boxes are pooled
             load_weights(cur.scale);
             bc = bias_of(cur.scale);
             w_scale = cur.scale;
         }
-        if (!(dbg & kDbgNoPool)) pool(cur, cur_flags);
+        if (!(dbg & kDbgNoPool)) pool(cur);
         tick(2);
         __syncthreads();                    // A tile complete; the tap window is free again
         tick(3);
+        f_n = 0;
         if (nxt.valid) {
             header_wait(nh);
-            if (!(dbg & kDbgNoFills)) issue_fills(nxt, nh); // in flight under the MFMAs below
-            nxt_flags = nh[0];
+            if (!(dbg & kDbgNoFills)) begin_fills(nxt, nh); // issued between the MFMAs below
             load_record(nxt); // this lane's box of the next item: lands under the MFMAs
         }
         if (nn.valid) header_of(nn, nh);
@@ -489,6 +558,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             const unsigned char *pa = s_planes + frag_base;
 #pragma unroll
             for (int c = 0; c < kSteps / 2; ++c) {
+                one_fill(); // (wave-uniform branch; nothing to issue once the wave's share of the window is on its way)
                 const int off0 = ((2 * c) ^ (key >> 1)) << 5, off1 = ((2 * c + 1) ^ (key >> 1)) << 5;
                 const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(pa + off0);
                 const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(pa + off1);
@@ -507,30 +577,121 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                 }
             }
         }
+        rest_fills(); // windows of more than 64 slots
 #pragma unroll
         for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[i] + bc); // vfa_op.py:124; vfanet.py:79, 82
         tick(5);
 
         if (!nxt.valid || nxt.tile != cur.tile) {
-            write_tile(cur.tile, sum, true);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
-            for (int t2 = cur.tile + 1; t2 < (nxt.valid ? nxt.tile : t_end); ++t2) write_tile(t2, sum, false);
+            pend_tile = cur.tile;
+            pend_next = nxt.valid ? nxt.tile : t_end;
         }
         tick(6);
         if (DIAG) stamp[7] += 1;
         cur = nxt;
-        cur_flags = nxt_flags;
         nxt = nn;
     }
+    flush();
     if (DIAG && (dbg & kDbgStamps) && a.diag && tid == 0)
         for (int k = 0; k < 8; ++k) a.diag[(size_t)blockIdx.x * 8 + k] = stamp[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3. box pooling alone, through LDS tap windows, with the voxel features written to HBM bit-exactly  (reference vfa_op.py:112-120)
+// The same records and windows as the fused kernel, but as a plain high-occupancy kernel: a 256-thread workgroup owns ONE
+// 64-channel quarter of one (view, tile): its window slice (256 B per tap, <= 31.5 KiB) arrives by LDS-DMA, then every wave pools
+// 8 boxes (two instructions' worth: 16 lanes x float4 per box), divides exactly (box_mean) and streams 256 B per box to `vox`.
+// Four workgroups per CU hide each other's DMA and LDS latencies; nothing is pipelined by hand.  The kernel is bound by the
+// HBM write of the voxel features.  Items whose window does not fit read their taps from the image itself.
+// ------------------------------------------------------------------------------------------------
+struct PoolArgs {
+    const float *integral;  // (n_views, Hf+2, Wf+2, 256)
+    const unsigned char *hdrs, *recs;
+    float *vox;             // (n_views, L * W, 256)
+    int n_views, L, W, tiles_w, n_tiles, Hf, Wf;
+    long long per_xcd;      // blocks per XCD
+};
+
+__global__ __launch_bounds__(256, 4) void pool_windows_kernel(PoolArgs a)
+{
+    __shared__ float4 s_win[kMaxSlots * 16]; // 256 B per slot: this quarter of every tap of the window
+    const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, grp = lane >> 4, cq = lane & 15;
+    const long long unit = xcd_contiguous(blockIdx.x, a.per_xcd); // (view, tile, quarter), quarter fastest
+    if (unit >= (long long)a.n_views * a.n_tiles * 4) return;
+    const int q = (int)(unit & 3);
+    const int item = (int)(unit >> 2), view = item / a.n_tiles, tile = item - view * a.n_tiles;
+    const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
+    const uint4 *hp = reinterpret_cast<const uint4 *>(a.hdrs + (size_t)item * kHdrBytes);
+    const uint4 h0 = hp[0], h1 = hp[1];
+    const int flags = uniform_i((int)h0.x), n_slots = uniform_i((int)h0.y), cwid = uniform_i((int)h0.z), inv = uniform_i((int)h0.w);
+    const int x0 = uniform_i((int)h1.x), t0 = uniform_i((int)h1.y), top_rows = uniform_i((int)h1.z), b0 = uniform_i((int)h1.w);
+    const bool direct = (flags & kTileDirect) != 0;
+    const int Wp = a.Wf + 2;
+    const char *img = reinterpret_cast<const char *>(a.integral) + (size_t)view * (a.Hf + 2) * Wp * kSlotBytes + q * 256;
+    // this lane's two boxes: 8 wave + grp and 8 wave + 4 + grp
+    uint4 rv[2][6];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + ((size_t)item * kTileBoxes + 8 * wave + 4 * p + grp) * kRecBytes);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rv[p][k] = rp[k];
+    }
+    if ((flags & kTileLive) && !direct) {
+        // window slice: one DMA instruction = 4 slots x 256 B (16 lanes each)
+        for (int s = 4 * wave; s < n_slots; s += 16) {
+            const int sl = min(s + grp, n_slots - 1);
+            const int wr = (sl * inv) >> 16, wc = sl - wr * cwid;
+            const int y = wr < top_rows ? t0 + wr : b0 + (wr - top_rows), x = x0 + wc;
+            const char *src = img + ((size_t)(y + 1) * Wp + (x + 1)) * kSlotBytes + cq * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(s_win + s * 16), 16, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int b = 8 * wave + 4 * p + grp;
+        const int cl = tl * kTileL + (b >> 3), cw = tw * kTileW + (b & 7);
+        if (cl >= a.L || cw >= a.W) continue;
+        const uint4(&r)[6] = rv[p];
+        const float wt[16] = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), __uint_as_float(r[0].w),
+                              __uint_as_float(r[1].x), __uint_as_float(r[1].y), __uint_as_float(r[1].z), __uint_as_float(r[1].w),
+                              __uint_as_float(r[2].x), __uint_as_float(r[2].y), __uint_as_float(r[2].z), __uint_as_float(r[2].w),
+                              __uint_as_float(r[3].x), __uint_as_float(r[3].y), __uint_as_float(r[3].z), __uint_as_float(r[3].w)};
+        const float rcp = __uint_as_float(r[4].x), masked = __uint_as_float(r[5].z), area = __uint_as_float(r[5].w);
+        const bool vis = (r[4].y & (unsigned)kVis) != 0u;
+        float4 res = make_float4(masked, masked, masked, masked);
+        if (vis) {
+            const unsigned rws[4] = {r[4].z & 0xffffu, r[4].z >> 16, r[4].w & 0xffffu, r[4].w >> 16};
+            const unsigned cls[4] = {r[5].x & 0xffffu, r[5].x >> 16, r[5].y & 0xffffu, r[5].y >> 16};
+            float4 t[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (direct) t[i][j] = *reinterpret_cast<const float4 *>(img + ((size_t)(rws[i] * Wp + cls[j]) * kSlotBytes + cq * 16));
+                    else t[i][j] = s_win[(rws[i] + cls[j]) * 16 + cq];
+                }
+            const float4 lt = sample4(t[0][0], t[0][1], t[1][0], t[1][1], wt[0], wt[1], wt[2], wt[3]);
+            const float4 rb = sample4(t[2][2], t[2][3], t[3][2], t[3][3], wt[4], wt[5], wt[6], wt[7]);
+            const float4 rt = sample4(t[0][2], t[0][3], t[1][2], t[1][3], wt[8], wt[9], wt[10], wt[11]);
+            const float4 lb = sample4(t[2][0], t[2][1], t[3][0], t[3][1], wt[12], wt[13], wt[14], wt[15]);
+            res = make_float4(box_mean(lt.x, rb.x, rt.x, lb.x, area, rcp), box_mean(lt.y, rb.y, rt.y, lb.y, area, rcp),
+                              box_mean(lt.z, rb.z, rt.z, lb.z, area, rcp), box_mean(lt.w, rb.w, rt.w, lb.w, area, rcp));
+        }
+        // written once, read once by the collapse kernel: non-temporal, 256 B per box
+        float *o = a.vox + ((size_t)view * a.L * a.W + (size_t)cl * a.W + cw) * kC + q * 64 + cq * 4;
+        typedef float nt4 __attribute__((ext_vector_type(4)));
+        nt4 x = {res.x, res.y, res.z, res.w};
+        __builtin_nontemporal_store(x, reinterpret_cast<nt4 *>(o));
+    }
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
-    size_t live[kMaxScales], hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], diag, total;
+    size_t live[kMaxScales], direct[kMaxScales], hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, diag, total;
     int tiles_l, tiles_w, n_tiles;
 };
 inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
@@ -543,10 +704,13 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     for (int s = 0; s < kMaxScales; ++s) {
         const bool on = s < n_scales;
         w.live[s] = off;  off = align_up(off + (on ? (size_t)w.n_tiles * 4 : 0), 256);
+        w.direct[s] = off; off = align_up(off + (on ? (size_t)w.n_tiles * 4 : 0), 256);
         w.hdrs[s] = off;  off = align_up(off + (on ? (size_t)n_views * w.n_tiles * kHdrBytes : 0), 256);
         w.recs[s] = off;  off = align_up(off + (on ? ((size_t)n_views * w.n_tiles * kTileBoxes + 1) * kRecBytes : 0), 256);
         w.wfrag[s] = off; off = align_up(off + (on ? (size_t)8 * kSteps * 2 * 64 * 16 : 0), 256);
     }
+    w.chunks = off;
+    off = align_up(off + (kChunks + 1) * sizeof(int), 256);
     w.diag = off;
     off = align_up(off + 512 * 8 * sizeof(unsigned long long), 256); // diagnostic build: 8 counters per workgroup
     w.total = off;
@@ -561,6 +725,25 @@ size_t vfa_frame_workspace_bytes(int n_views, int L, int W, int n_scales)
 {
     if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales) return 0;
     return layout_of(n_views, L, W, n_scales).total;
+}
+
+int vfa_frame_workspace_layout(int n_views, int L, int W, int n_scales, size_t *offsets, int *tiles)
+{
+    if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales || !offsets || !tiles) return VFA_ERR_BAD_ARGUMENT;
+    const WorkspaceLayout lay = layout_of(n_views, L, W, n_scales);
+    for (int k = 0; k < kMaxScales; ++k) {
+        offsets[5 * k + 0] = lay.live[k];
+        offsets[5 * k + 1] = lay.direct[k];
+        offsets[5 * k + 2] = lay.hdrs[k];
+        offsets[5 * k + 3] = lay.recs[k];
+        offsets[5 * k + 4] = lay.wfrag[k];
+    }
+    offsets[15] = lay.diag;
+    offsets[16] = lay.total;
+    tiles[0] = lay.tiles_l;
+    tiles[1] = lay.tiles_w;
+    tiles[2] = kMaxSlots;
+    return 0;
 }
 
 int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
@@ -584,11 +767,13 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
         a.dims[k].Wf = k < n_scales ? feat_hw[2 * k + 1] : 1;
         if (a.dims[k].Hf <= 0 || a.dims[k].Wf <= 0 || a.dims[k].Hf > 65533 || a.dims[k].Wf > 65533) return VFA_ERR_BAD_ARGUMENT;
         a.live[k] = reinterpret_cast<unsigned *>(ws + lay.live[k]);
+        a.direct[k] = reinterpret_cast<unsigned *>(ws + lay.direct[k]);
         a.hdrs[k] = ws + lay.hdrs[k];
         a.recs[k] = ws + lay.recs[k];
     }
     for (int k = 0; k < n_scales; ++k) {
         hipError_t e = hipMemsetAsync(ws + lay.live[k], 0, (size_t)lay.n_tiles * 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(ws + lay.direct[k], 0, (size_t)lay.n_tiles * 4, s);
         if (e == hipSuccess) // the spare record behind the last tile (prefetched, never used)
             e = hipMemsetAsync(ws + lay.recs[k] + (size_t)n_views * lay.n_tiles * kTileBoxes * kRecBytes, 0, kRecBytes, s);
         if (e != hipSuccess) return (int)e;
@@ -596,6 +781,10 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
     const long long pairs = (long long)n_views * lay.n_tiles;
     hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(kWave), 0, s, a);
     int st = (int)hipGetLastError();
+    if (st) return st;
+    hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, s, a.live[0], a.live[n_scales > 1 ? 1 : 0], a.live[n_scales > 2 ? 2 : 0],
+                       n_scales, lay.n_tiles, n_views >= 32 ? 0xffffffffu : ((1u << n_views) - 1u), reinterpret_cast<int *>(ws + lay.chunks));
+    st = (int)hipGetLastError();
     if (st) return st;
     if (weights)
         for (int k = 0; k < n_scales; ++k) {
@@ -606,6 +795,26 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
             if (st) return st;
         }
     return 0;
+}
+
+int vfa_pool_windows_f32(const float *integral, const void *workspace, size_t workspace_bytes, float *vox, int n_views, int L, int W,
+                         int n_scales, int scale, int Hf, int Wf, void *stream)
+{
+    if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales || scale < 0 || scale >= n_scales || Hf <= 0 || Wf <= 0)
+        return VFA_ERR_BAD_ARGUMENT;
+    if (n_views > 32) return VFA_ERR_UNSUPPORTED;
+    const WorkspaceLayout lay = layout_of(n_views, L, W, n_scales);
+    if (lay.n_tiles == 0 || n_views == 0) return 0;
+    if (!workspace || workspace_bytes < lay.total || !integral || !vox) return VFA_ERR_BAD_ARGUMENT;
+    const unsigned char *ws = reinterpret_cast<const unsigned char *>(workspace);
+    PoolArgs a;
+    a.integral = integral; a.hdrs = ws + lay.hdrs[scale]; a.recs = ws + lay.recs[scale]; a.vox = vox;
+    a.n_views = n_views; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles; a.Hf = Hf; a.Wf = Wf;
+    const long long units = (long long)n_views * lay.n_tiles * 4;
+    if (units >= (1ll << 31) - 8) return VFA_ERR_UNSUPPORTED;
+    a.per_xcd = (units + 7) / 8;
+    hipLaunchKernelGGL(pool_windows_kernel, dim3((unsigned)(a.per_xcd * 8)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
 }
 
 int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, const void *workspace,
@@ -634,6 +843,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
         a.sc[k].bias = biases ? biases[q] : nullptr;
         a.sc[k].wfrag = reinterpret_cast<const uint4 *>(ws + lay.wfrag[q]);
         a.sc[k].live = reinterpret_cast<const unsigned *>(ws + lay.live[q]);
+        a.sc[k].direct = reinterpret_cast<const unsigned *>(ws + lay.direct[q]);
         a.sc[k].hdrs = ws + lay.hdrs[q];
         a.sc[k].recs = ws + lay.recs[q];
         a.sc[k].Hf = feat_hw[2 * q];
@@ -642,6 +852,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     }
     a.n_scales = n_scales; a.n_views = n_views; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles;
     a.out = out; a.accumulate = accumulate;
+    a.chunk_start = reinterpret_cast<const int *>(ws + lay.chunks);
     a.debug = debug;
     a.diag = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(ws) + lay.diag);
     int n_cu = 256;
@@ -655,12 +866,24 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     int nblk = lay.n_tiles < n_cu ? lay.n_tiles : n_cu;
     nblk = (nblk + 7) / 8 * 8; // xcd_contiguous deals whole eighths; surplus blocks find an empty range and leave
     if (nblk > 512) nblk = 512;
+    if (debug & 64) { // diagnostic: only the second launch (direct items)
+        hipLaunchKernelGGL((pool_collapse_kernel<3, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (debug) // diagnostic build (ablations / cycle stamps): never used by the product path
-        hipLaunchKernelGGL((pool_collapse_kernel<3, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((pool_collapse_kernel<3, true, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     else if (terms == 4)
-        hipLaunchKernelGGL((pool_collapse_kernel<4, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((pool_collapse_kernel<4, false, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     else
-        hipLaunchKernelGGL((pool_collapse_kernel<3, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((pool_collapse_kernel<3, false, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+    int st = (int)hipGetLastError();
+    if (st || debug) return st;
+    // the few items whose tap window does not fit LDS: same kernel, taps straight from the image, ADDED to the map (the
+    // launch leaves at once where there are none)
+    if (terms == 4)
+        hipLaunchKernelGGL((pool_collapse_kernel<4, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL((pool_collapse_kernel<3, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 

@@ -113,5 +113,22 @@ __device__ __forceinline__ void bilinear_weights(float (&w)[4], const Axis &ax, 
     w[3] = ay.hi * ax.hi; // se
 }
 
+// (((lt + rb) - rt) - lb) / area                                                         (A.6)
+// The quotient must be the correctly rounded IEEE quotient (the reference divides).  All channels of a box divide by
+// the same area, so the reciprocal r = RN(1/area) is formed once per box and each channel runs two Markstein
+// corrections:  q0 = RN(v r); q1 = RN(q0 + (v - area q0) r); q = RN(q1 + (v - area q1) r), residuals exact by FMA.
+// q1 is within half an ulp (+ o(ulp)) of v/area, i.e. faithful, and for a faithful q1 and r = RN(1/area) the last
+// step returns RN(v/area) (Markstein's theorem).  Holds while no intermediate leaves the normal range: v = 0 or
+// 2^-100 < |v / area| < 2^100, always true for feature maps (checked against true division: tools/check_division.c).
+__device__ __forceinline__ float box_mean(float lt, float rb, float rt, float lb, float area, float rcp)
+{
+    float v = lt + rb;
+    v = v - rt;
+    v = v - lb;
+    const float q0 = v * rcp;
+    const float q1 = fmaf(fmaf(-area, q0, v), rcp, q0);
+    return fmaf(fmaf(-area, q1, v), rcp, q1);
+}
+
 } // namespace vfa_dev
 #endif // VFA_GEOM_H

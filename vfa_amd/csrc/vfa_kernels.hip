@@ -203,22 +203,6 @@ template <> __device__ __forceinline__ float4 vfma<4>(float4 a, float w, float4 
     return make_float4(fmaf(a.x, w, c.x), fmaf(a.y, w, c.y), fmaf(a.z, w, c.z), fmaf(a.w, w, c.w));
 }
 
-// (((lt + rb) - rt) - lb) / area                                                         (A.6)
-// The quotient must be the correctly rounded IEEE quotient (the reference divides).  All channels of a box divide by
-// the same area, so the reciprocal r = RN(1/area) is formed once per box and each channel runs two Markstein
-// corrections:  q0 = RN(v r); q1 = RN(q0 + (v - area q0) r); q = RN(q1 + (v - area q1) r), residuals exact by FMA.
-// q1 is within half an ulp (+ o(ulp)) of v/area, i.e. faithful, and for a faithful q1 and r = RN(1/area) the last
-// step returns RN(v/area) (Markstein's theorem).  Holds while no intermediate leaves the normal range: v = 0 or
-// 2^-100 < |v / area| < 2^100, always true for feature maps (checked against true division: tools/check_division.c).
-__device__ __forceinline__ float box_mean(float lt, float rb, float rt, float lb, float area, float rcp)
-{
-    float v = lt + rb;
-    v = v - rt;
-    v = v - lb;
-    const float q0 = v * rcp;
-    const float q1 = fmaf(fmaf(-area, q0, v), rcp, q0);
-    return fmaf(fmaf(-area, q1, v), rcp, q1);
-}
 template <int VEC>
 __device__ __forceinline__ typename vec_of<VEC>::type vbox_mean(typename vec_of<VEC>::type lt, typename vec_of<VEC>::type rb,
                                                                 typename vec_of<VEC>::type rt, typename vec_of<VEC>::type lb,

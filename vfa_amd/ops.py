@@ -363,3 +363,29 @@ def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=Fa
             _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xff) << 16),  # debug: diagnostic build, tools/ only
             _lib.current_stream_handle(), tag=(n, L, W, ns))
     return out
+
+
+def pool_windows(integral, workspace, grid_lw, n_scales, scale, out=None):
+    """Box pooling of one scale from a ``frame_records`` workspace -> vox (n, L*W, 256) fp32, bit-identical to
+    ``project_gather`` (reference vfa_op.py:112-120): tap windows through LDS, one quarter of a (view, tile) per workgroup."""
+    _lib.require_device(integral, workspace, out)
+    n, Hp, Wp, C = integral.shape
+    assert C == 256 and integral.is_contiguous() and integral.dtype == torch.float32
+    L, W = grid_lw
+    vox = out if out is not None else torch.empty((n, L * W, 256), dtype=torch.float32, device=integral.device)
+    _launch("vfa_pool_windows_f32", _lib.ptr(integral), _lib.ptr(workspace), workspace.numel(), _lib.ptr(vox), n, L, W,
+            int(n_scales), int(scale), Hp - 2, Wp - 2, _lib.current_stream_handle(), tag=(n, C, Hp - 2, Wp - 2, 1, L * W))
+    return vox
+
+
+def frame_workspace_layout(n_views, L, W, n_scales):
+    """Offsets inside the ``frame_records`` workspace, for tests and tools: dict with per-scale lists ``live``, ``direct``,
+    ``hdrs``, ``recs``, ``wfrag`` and ``diag``, ``total``, ``tiles_l``, ``tiles_w``, ``max_slots``."""
+    import ctypes
+    off = (ctypes.c_size_t * 17)()
+    tiles = (ctypes.c_int * 3)()
+    _lib.call("vfa_frame_workspace_layout", int(n_views), int(L), int(W), int(n_scales), off, tiles)
+    names = ("live", "direct", "hdrs", "recs", "wfrag")
+    out = {nm: [int(off[5 * k + i]) for k in range(n_scales)] for i, nm in enumerate(names)}
+    out.update(diag=int(off[15]), total=int(off[16]), tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]))
+    return out

@@ -45,6 +45,10 @@ COLLAPSE_TERMS = int(os.environ.get("VFA_AMD_COLLAPSE_TERMS", "3"))
 # persistent kernel for pooling, collapse, bias, ReLU and the view / scale sums (`vfa_pool_collapse_relu_sum_f32`): the voxel
 # features never reach HBM.  "0" = pooling kernel -> vox in HBM -> MFMA collapse kernel, per scale (the round-1 path).
 FUSED_POOL = os.environ.get("VFA_AMD_FUSED_POOL", "1") == "1"
+# With FUSED_POOL off: "1" (default) = the per-frame box records also feed the standalone LDS-window pooling kernel
+# (`vfa_pool_windows_f32`, voxel features bit-identical to `vfa_project_gather_f32`) in front of the MFMA collapse kernel;
+# "0" = the round-1 pooling kernels that project every box themselves.
+WINDOW_POOL = os.environ.get("VFA_AMD_WINDOW_POOL", "1") == "1"
 
 
 def _conv_kind(args):
@@ -110,10 +114,13 @@ class _CollapseGemm(torch.autograd.Function):
         return g_vox, g_w, None
 
 
-def fused_frame_ok(mods, n_views):
-    """The two-launch inference path covers these projector modules (one per feature scale) for this many cameras."""
+def fused_frame_ok(mods, n_views, mode="fused"):
+    """The per-frame-records inference paths (``mode`` "fused": one persistent kernel for everything behind the integral
+    images; "window": LDS-window pooling kernel + MFMA collapse kernel per scale) cover these projector modules (one per
+    feature scale) for this many cameras."""
     m0 = mods[0]
-    return (FUSED_POOL and COLLAPSE_KERNEL != "library" and 1 <= len(mods) <= 3 and 0 < n_views <= 32
+    on = FUSED_POOL if mode == "fused" else (WINDOW_POOL and not FUSED_POOL)
+    return (on and COLLAPSE_KERNEL != "library" and 1 <= len(mods) <= 3 and 0 < n_views <= 32
             and all(m.channel == 256 and m.num_grid_layer == 1 and m.collapse.out_features == 256 for m in mods)
             and all(m.geometry_key == m0.geometry_key and getattr(m.args, "data", None) == getattr(m0.args, "data", None)
                     and tuple(m.args.image_size) == tuple(m0.args.image_size) for m in mods))
@@ -139,6 +146,32 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
                                crange=crange)
         return ops.pool_collapse(integrals, [m.collapse.bias for m in mods], ws, (length, width), out=out,
                                  accumulate=accumulate, terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
+
+
+def window_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0):
+    """Same contract as ``fused_frame``, as separate kernels per scale: geometry once per frame (``ops.frame_records``), then
+    per scale the integral images, the LDS-window pooling kernel (``ops.pool_windows``: voxel features in HBM, bit-exact) and
+    the MFMA collapse + bias + ReLU + view-sum kernel (``ops.collapse_relu_sum``)."""
+    _lib.require_device(calibs, grid, *features)
+    m0 = mods[0]
+    conv_kind = _conv_kind(m0.args)
+    img_h, img_w = (float(v) for v in m0.args.image_size)
+    length, width = grid.shape[-3], grid.shape[-2]
+    dev = features[0].device
+    z_layers, corner_off = m0._kernel_geometry(dev)
+    n = calibs.shape[0]
+    if out is None:
+        out = torch.empty((length * width, 256), dtype=torch.float32, device=dev)
+        accumulate = False
+    with torch.no_grad():
+        ws = ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h),
+                               [tuple(f.shape[-2:]) for f in features], weights=None, crange=crange)
+        vox = torch.empty((n, length * width, 256), dtype=torch.float32, device=dev)
+        for k, (m, f) in enumerate(zip(mods, features)):
+            ops.pool_windows(ops.integral_image(f), ws, (length, width), len(mods), k, out=vox)
+            ops.collapse_relu_sum(vox, m.layer_major_weight(), m.collapse.bias, out=out, accumulate=accumulate or k > 0,
+                                  terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
+    return out
 
 
 def mfma_gemm_ok(K, N):
@@ -283,6 +316,9 @@ class VFA(nn.Module):
         if fused_frame_ok([self], n):
             return fused_frame([self], [features], calibs, grid, crange, out=out, accumulate=accumulate,
                                reserved_cus=reserved_cus)
+        if fused_frame_ok([self], n, "window") and n * n_cells * C * 4 <= VOX_BYTES_LIMIT:
+            return window_frame([self], [features], calibs, grid, crange, out=out, accumulate=accumulate,
+                                reserved_cus=reserved_cus)
         with torch.no_grad():
             integral = ops.integral_image(features)
             weight = self.layer_major_weight()
