@@ -607,84 +607,250 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 struct PoolArgs {
     const float *integral;  // (n_views, Hf+2, Wf+2, 256)
     const unsigned char *hdrs, *recs;
+    const unsigned *direct; // (n_tiles) views whose window does not fit LDS
     float *vox;             // (n_views, L * W, 256)
     int n_views, L, W, tiles_w, n_tiles, Hf, Wf;
     long long per_xcd;      // blocks per XCD
 };
 
-__global__ __launch_bounds__(256, 4) void pool_windows_kernel(PoolArgs a)
+// Persistent form: 512-thread workgroups, two per CU, each walking a contiguous run of (view, tile, quarter) units with the
+// window slice and the 32 box records of unit u + 1 arriving by LDS-DMA (into the other LDS buffer) while unit u is pooled.
+//   wave w, lane (grp = lane >> 4, cq = lane & 15): box 4 w + grp of the tile, channels 64 q + 4 cq .. + 3.
+__global__ __launch_bounds__(512, 2) void pool_windows_kernel(PoolArgs a)
 {
-    __shared__ float4 s_win[kMaxSlots * 16]; // 256 B per slot: this quarter of every tap of the window
+    // two buffers as separate objects: hipcc drains every LDS-DMA in flight before an LDS read it cannot prove disjoint from it
+    // (256 B per slot; a DMA instruction writes four slots, so the capacity is rounded up to a multiple of four)
+    __shared__ float4 s_win0[(kMaxSlots + 3) / 4 * 4 * 16], s_win1[(kMaxSlots + 3) / 4 * 4 * 16];
+    __shared__ __align__(16) unsigned char s_rec0[kTileBoxes * kRecBytes], s_rec1[kTileBoxes * kRecBytes];
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, grp = lane >> 4, cq = lane & 15;
-    const long long unit = xcd_contiguous(blockIdx.x, a.per_xcd); // (view, tile, quarter), quarter fastest
-    if (unit >= (long long)a.n_views * a.n_tiles * 4) return;
-    const int q = (int)(unit & 3);
-    const int item = (int)(unit >> 2), view = item / a.n_tiles, tile = item - view * a.n_tiles;
-    const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
-    const uint4 *hp = reinterpret_cast<const uint4 *>(a.hdrs + (size_t)item * kHdrBytes);
-    const uint4 h0 = hp[0], h1 = hp[1];
-    const int flags = uniform_i((int)h0.x), n_slots = uniform_i((int)h0.y), cwid = uniform_i((int)h0.z), inv = uniform_i((int)h0.w);
-    const int x0 = uniform_i((int)h1.x), t0 = uniform_i((int)h1.y), top_rows = uniform_i((int)h1.z), b0 = uniform_i((int)h1.w);
-    const bool direct = (flags & kTileDirect) != 0;
+    const long long n_units = (long long)a.n_views * a.n_tiles * 4;
+    const int nblk = gridDim.x;
+    const int lb = (int)xcd_contiguous(blockIdx.x, (nblk + 7) / 8);
+    if (lb >= nblk) return;
+    const long long u_begin = n_units * lb / nblk, u_end = n_units * (lb + 1) / nblk;
+    if (u_begin >= u_end) return;
     const int Wp = a.Wf + 2;
-    const char *img = reinterpret_cast<const char *>(a.integral) + (size_t)view * (a.Hf + 2) * Wp * kSlotBytes + q * 256;
-    // this lane's two boxes: 8 wave + grp and 8 wave + 4 + grp
-    uint4 rv[2][6];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + ((size_t)item * kTileBoxes + 8 * wave + 4 * p + grp) * kRecBytes);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) rv[p][k] = rp[k];
-    }
-    if ((flags & kTileLive) && !direct) {
-        // window slice: one DMA instruction = 4 slots x 256 B (16 lanes each)
-        for (int s = 4 * wave; s < n_slots; s += 16) {
-            const int sl = min(s + grp, n_slots - 1);
-            const int wr = (sl * inv) >> 16, wc = sl - wr * cwid;
-            const int y = wr < top_rows ? t0 + wr : b0 + (wr - top_rows), x = x0 + wc;
-            const char *src = img + ((size_t)(y + 1) * Wp + (x + 1)) * kSlotBytes + cq * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(s_win + s * 16), 16, 0, 0);
+    const size_t img_stride = (size_t)(a.Hf + 2) * Wp * kSlotBytes;
+
+    auto header_of = [&](long long u, i32x8 &hd) {
+        const unsigned char *p = a.hdrs + (size_t)(u >> 2) * kHdrBytes;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(hd) : "s"(p));
+    };
+    auto header_wait = [&](i32x8 &hd) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hd)); };
+    // position of a unit, advanced by counting (the CU has ONE scalar unit: divisions per unit and wave made the kernel
+    // scalar-bound)
+    struct Pos { int item, q, view, tl, tw; };
+    auto pos_of = [&](long long u) {
+        Pos p;
+        p.item = (int)(u >> 2); p.q = (int)(u & 3);
+        p.view = p.item / a.n_tiles;
+        const int tile = p.item - p.view * a.n_tiles;
+        p.tl = tile / a.tiles_w; p.tw = tile - p.tl * a.tiles_w;
+        return p;
+    };
+    auto advance = [&](Pos &p) {
+        if (++p.q == 4) {
+            p.q = 0; ++p.item;
+            if (++p.tw == a.tiles_w) {
+                p.tw = 0;
+                if (++p.tl * a.tiles_w >= a.n_tiles) { p.tl = 0; ++p.view; }
+            }
         }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int b = 8 * wave + 4 * p + grp;
+    };
+    // LDS-DMA of unit u into buffer B: the 256-byte quarter of every window slot (4 slots per instruction, 16 lanes each)
+    // and the 3 KiB of box records (waves 0-2)
+    auto fetch = [&](auto buf_tag, const Pos &ps, const i32x8 &hd) {
+        constexpr int B = decltype(buf_tag)::value;
+        const int item = ps.item, q = ps.q, view = ps.view;
+        const int flags = hd[0], n_slots = hd[1], cwid = hd[2], inv = hd[3], x0 = hd[4], t0 = hd[5], top_rows = hd[6], b0 = hd[7];
+        if (wave < 3) {
+            const unsigned char *src = a.recs + (size_t)item * kTileBoxes * kRecBytes + wave * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)((B ? s_rec1 : s_rec0) + wave * 1024), 16, 0, 0);
+        }
+        if ((flags & kTileLive) && !(flags & kTileDirect)) { // (direct items: pool_direct_kernel)
+            const char *img = reinterpret_cast<const char *>(a.integral) + view * img_stride + q * 256 + cq * 16;
+            for (int s = 4 * wave; s < n_slots; s += 32) {
+                const int sl = min(s + grp, n_slots - 1);
+                const int wr = (sl * inv) >> 16, wc = sl - wr * cwid;
+                const int y = wr < top_rows ? t0 + wr : b0 + (wr - top_rows), x = x0 + wc;
+                const char *src = img + ((size_t)(y + 1) * Wp + (x + 1)) * kSlotBytes;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)((B ? s_win1 : s_win0) + s * 16), 16, 0, 0);
+            }
+        }
+    };
+    // The result of a unit is stored one unit LATER, right behind the wait at the head of the loop: the store then has a whole
+    // unit to drain before the next `vmcnt(0)` (which must only wait for the window that was requested a unit ago).
+    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+    float *keep_at = nullptr;
+    auto flush = [&]() {
+        if (keep_at) {
+            typedef float nt4 __attribute__((ext_vector_type(4)));
+            const nt4 x = {keep.x, keep.y, keep.z, keep.w};
+            __builtin_nontemporal_store(x, reinterpret_cast<nt4 *>(keep_at)); // written once, read once by the collapse kernel
+        }
+    };
+    // pool unit u out of buffer B
+    auto pool = [&](auto buf_tag, const Pos &ps, int flags) {
+        constexpr int B = decltype(buf_tag)::value;
+        const int q = ps.q, view = ps.view, tl = ps.tl, tw = ps.tw;
+        if (flags & kTileDirect) { // left to pool_direct_kernel
+            keep_at = nullptr;
+            return;
+        }
+        const int b = 4 * wave + grp;
         const int cl = tl * kTileL + (b >> 3), cw = tw * kTileW + (b & 7);
-        if (cl >= a.L || cw >= a.W) continue;
-        const uint4(&r)[6] = rv[p];
+        // LDS reads by inline asm: the window of the NEXT unit is arriving by DMA in the other buffer, and hipcc puts a
+        // `vmcnt(0)` in front of every LDS read it generates while an LDS-DMA is in flight (it would undo the prefetch); the
+        // barrier at the head of the loop made this buffer visible.
+        uint4 r[6];
+        {
+            const unsigned ra = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(B ? s_rec1 : s_rec0) + (unsigned)(b * kRecBytes);
+            asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+                         "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]) : "v"(ra) : "memory");
+        }
         const float wt[16] = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), __uint_as_float(r[0].w),
                               __uint_as_float(r[1].x), __uint_as_float(r[1].y), __uint_as_float(r[1].z), __uint_as_float(r[1].w),
                               __uint_as_float(r[2].x), __uint_as_float(r[2].y), __uint_as_float(r[2].z), __uint_as_float(r[2].w),
                               __uint_as_float(r[3].x), __uint_as_float(r[3].y), __uint_as_float(r[3].z), __uint_as_float(r[3].w)};
         const float rcp = __uint_as_float(r[4].x), masked = __uint_as_float(r[5].z), area = __uint_as_float(r[5].w);
         const bool vis = (r[4].y & (unsigned)kVis) != 0u;
-        float4 res = make_float4(masked, masked, masked, masked);
-        if (vis) {
-            const unsigned rws[4] = {r[4].z & 0xffffu, r[4].z >> 16, r[4].w & 0xffffu, r[4].w >> 16};
-            const unsigned cls[4] = {r[5].x & 0xffffu, r[5].x >> 16, r[5].y & 0xffffu, r[5].y >> 16};
-            float4 t[4][4];
+        // tap coordinates of a masked box are meaningless: point them at slot / pixel 0 (the value is discarded)
+        unsigned rws[4] = {r[4].z & 0xffffu, r[4].z >> 16, r[4].w & 0xffffu, r[4].w >> 16};
+        unsigned cls[4] = {r[5].x & 0xffffu, r[5].x >> 16, r[5].y & 0xffffu, r[5].y >> 16};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rws[k] = vis ? rws[k] : 0u;
+            cls[k] = vis ? cls[k] : 0u;
+        }
+        typedef float nf4 __attribute__((ext_vector_type(4))); // (a native vector: inline asm cannot tie HIP's float4 struct)
+        nf4 t[4][4];
+        {
+            const unsigned wa = (unsigned)(size_t)(__attribute__((address_space(3))) float4 *)(B ? s_win1 : s_win0) + (unsigned)(cq * 16);
+            unsigned ad[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (direct) t[i][j] = *reinterpret_cast<const float4 *>(img + ((size_t)(rws[i] * Wp + cls[j]) * kSlotBytes + cq * 16));
-                    else t[i][j] = s_win[(rws[i] + cls[j]) * 16 + cq];
-                }
-            const float4 lt = sample4(t[0][0], t[0][1], t[1][0], t[1][1], wt[0], wt[1], wt[2], wt[3]);
-            const float4 rb = sample4(t[2][2], t[2][3], t[3][2], t[3][3], wt[4], wt[5], wt[6], wt[7]);
-            const float4 rt = sample4(t[0][2], t[0][3], t[1][2], t[1][3], wt[8], wt[9], wt[10], wt[11]);
-            const float4 lb = sample4(t[2][0], t[2][1], t[3][0], t[3][1], wt[12], wt[13], wt[14], wt[15]);
-            res = make_float4(box_mean(lt.x, rb.x, rt.x, lb.x, area, rcp), box_mean(lt.y, rb.y, rt.y, lb.y, area, rcp),
-                              box_mean(lt.z, rb.z, rt.z, lb.z, area, rcp), box_mean(lt.w, rb.w, rt.w, lb.w, area, rcp));
+                for (int j = 0; j < 4; ++j) ad[i][j] = wa + (rws[i] + cls[j]) * 256u;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) // eight reads per statement; the wait names all sixteen destinations
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+                             "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+                             : "=&v"(t[i][0]), "=&v"(t[i][1]), "=&v"(t[i][2]), "=&v"(t[i][3]), "=&v"(t[i + 1][0]), "=&v"(t[i + 1][1]),
+                               "=&v"(t[i + 1][2]), "=&v"(t[i + 1][3])
+                             : "v"(ad[i][0]), "v"(ad[i][1]), "v"(ad[i][2]), "v"(ad[i][3]), "v"(ad[i + 1][0]), "v"(ad[i + 1][1]),
+                               "v"(ad[i + 1][2]), "v"(ad[i + 1][3])
+                             : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]),
+                           "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[2][2]), "+v"(t[2][3]), "+v"(t[3][0]), "+v"(t[3][1]), "+v"(t[3][2]), "+v"(t[3][3])
+                         :: "memory");
         }
-        // written once, read once by the collapse kernel: non-temporal, 256 B per box
-        float *o = a.vox + ((size_t)view * a.L * a.W + (size_t)cl * a.W + cw) * kC + q * 64 + cq * 4;
-        typedef float nt4 __attribute__((ext_vector_type(4)));
-        nt4 x = {res.x, res.y, res.z, res.w};
-        __builtin_nontemporal_store(x, reinterpret_cast<nt4 *>(o));
+        auto f4 = [](const nf4 &v) { return make_float4(v.x, v.y, v.z, v.w); };
+        const float4 lt = sample4(f4(t[0][0]), f4(t[0][1]), f4(t[1][0]), f4(t[1][1]), wt[0], wt[1], wt[2], wt[3]);
+        const float4 rb = sample4(f4(t[2][2]), f4(t[2][3]), f4(t[3][2]), f4(t[3][3]), wt[4], wt[5], wt[6], wt[7]);
+        const float4 rt = sample4(f4(t[0][2]), f4(t[0][3]), f4(t[1][2]), f4(t[1][3]), wt[8], wt[9], wt[10], wt[11]);
+        const float4 lb2 = sample4(f4(t[2][0]), f4(t[2][1]), f4(t[3][0]), f4(t[3][1]), wt[12], wt[13], wt[14], wt[15]);
+        float4 res = make_float4(box_mean(lt.x, rb.x, rt.x, lb2.x, area, rcp), box_mean(lt.y, rb.y, rt.y, lb2.y, area, rcp),
+                                 box_mean(lt.z, rb.z, rt.z, lb2.z, area, rcp), box_mean(lt.w, rb.w, rt.w, lb2.w, area, rcp));
+        if (!vis) res = make_float4(masked, masked, masked, masked);
+        const bool inside = cl < a.L && cw < a.W; // 256 B per box
+        keep = res;
+        keep_at = inside ? a.vox + ((size_t)view * a.L * a.W + (size_t)cl * a.W + cw) * kC + q * 64 + cq * 4 : nullptr;
+    };
+
+    i32x8 hc, hn;
+    header_of(u_begin, hc);
+    header_wait(hc);
+    Pos pc = pos_of(u_begin), pn = pc; // the unit being pooled, the unit being fetched
+    fetch(std::integral_constant<int, 0>{}, pc, hc);
+    advance(pn);
+    if (u_begin + 1 < u_end) header_of(u_begin + 1, hn);
+    // the loop is unrolled by two so that the buffer of every LDS access is a compile-time fact
+    for (long long u = u_begin; u < u_end; u += 2) {
+        // ---- even: pool buffer 0, fetch into buffer 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the window of unit u has landed (and the store of unit u - 2)
+        __builtin_amdgcn_s_barrier();                    // ... for every wave, and everybody is done with buffer 1
+        asm volatile("" ::: "memory");
+        flush();
+        if (u + 1 < u_end) {
+            header_wait(hn);
+            fetch(std::integral_constant<int, 1>{}, pn, hn);
+        }
+        pool(std::integral_constant<int, 0>{}, pc, hc[0]);
+        if (u + 1 >= u_end) break;
+        hc = hn;
+        pc = pn;
+        advance(pn);
+        if (u + 2 < u_end) header_of(u + 2, hn);
+        // ---- odd: pool buffer 1, fetch into buffer 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        flush();
+        if (u + 2 < u_end) {
+            header_wait(hn);
+            fetch(std::integral_constant<int, 0>{}, pn, hn);
+        }
+        pool(std::integral_constant<int, 1>{}, pc, hc[0]);
+        hc = hn;
+        pc = pn;
+        advance(pn);
+        if (u + 3 < u_end) header_of(u + 3, hn);
+    }
+    flush();
+}
+
+// The items the window kernel leaves out (tap window larger than the LDS slice: boxes right in front of a camera): one
+// 512-thread workgroup per (tile, quarter) walks the views flagged in the direct mask and reads every tap from the image.
+__global__ __launch_bounds__(512) void pool_direct_kernel(PoolArgs a)
+{
+    const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, grp = lane >> 4, cq = lane & 15;
+    const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;
+    unsigned mask = (unsigned)uniform_i((int)a.direct[tile]);
+    if (a.n_views < 32) mask &= (1u << a.n_views) - 1u;
+    const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
+    const int b = 4 * wave + grp;
+    const int cl = tl * kTileL + (b >> 3), cw = tw * kTileW + (b & 7);
+    const int Wp = a.Wf + 2;
+    while (mask) {
+        const int view = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        const int item = view * a.n_tiles + tile;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs + ((size_t)item * kTileBoxes + b) * kRecBytes);
+        uint4 r[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r[k] = rp[k];
+        const float wt[16] = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), __uint_as_float(r[0].w),
+                              __uint_as_float(r[1].x), __uint_as_float(r[1].y), __uint_as_float(r[1].z), __uint_as_float(r[1].w),
+                              __uint_as_float(r[2].x), __uint_as_float(r[2].y), __uint_as_float(r[2].z), __uint_as_float(r[2].w),
+                              __uint_as_float(r[3].x), __uint_as_float(r[3].y), __uint_as_float(r[3].z), __uint_as_float(r[3].w)};
+        const float rcp = __uint_as_float(r[4].x), masked = __uint_as_float(r[5].z), area = __uint_as_float(r[5].w);
+        const bool vis = (r[4].y & (unsigned)kVis) != 0u;
+        // records of a direct item hold pixel coordinates (+ 1: the zero border); a masked box reads pixel 0 and discards it
+        const unsigned rws[4] = {vis ? r[4].z & 0xffffu : 0u, vis ? r[4].z >> 16 : 0u, vis ? r[4].w & 0xffffu : 0u, vis ? r[4].w >> 16 : 0u};
+        const unsigned cls[4] = {vis ? r[5].x & 0xffffu : 0u, vis ? r[5].x >> 16 : 0u, vis ? r[5].y & 0xffffu : 0u, vis ? r[5].y >> 16 : 0u};
+        const char *img = reinterpret_cast<const char *>(a.integral) + (size_t)view * (a.Hf + 2) * Wp * kSlotBytes + q * 256 + cq * 16;
+        float4 t[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[i][j] = *reinterpret_cast<const float4 *>(img + (size_t)(rws[i] * Wp + cls[j]) * kSlotBytes);
+        const float4 lt = sample4(t[0][0], t[0][1], t[1][0], t[1][1], wt[0], wt[1], wt[2], wt[3]);
+        const float4 rb = sample4(t[2][2], t[2][3], t[3][2], t[3][3], wt[4], wt[5], wt[6], wt[7]);
+        const float4 rt = sample4(t[0][2], t[0][3], t[1][2], t[1][3], wt[8], wt[9], wt[10], wt[11]);
+        const float4 lb2 = sample4(t[2][0], t[2][1], t[3][0], t[3][1], wt[12], wt[13], wt[14], wt[15]);
+        float4 res = make_float4(box_mean(lt.x, rb.x, rt.x, lb2.x, area, rcp), box_mean(lt.y, rb.y, rt.y, lb2.y, area, rcp),
+                                 box_mean(lt.z, rb.z, rt.z, lb2.z, area, rcp), box_mean(lt.w, rb.w, rt.w, lb2.w, area, rcp));
+        if (!vis) res = make_float4(masked, masked, masked, masked);
+        if (cl < a.L && cw < a.W) {
+            typedef float nt4 __attribute__((ext_vector_type(4)));
+            const nt4 x = {res.x, res.y, res.z, res.w};
+            __builtin_nontemporal_store(x, reinterpret_cast<nt4 *>(a.vox + ((size_t)view * a.L * a.W + (size_t)cl * a.W + cw) * kC + q * 64 + cq * 4));
+        }
     }
 }
 
@@ -809,11 +975,26 @@ int vfa_pool_windows_f32(const float *integral, const void *workspace, size_t wo
     const unsigned char *ws = reinterpret_cast<const unsigned char *>(workspace);
     PoolArgs a;
     a.integral = integral; a.hdrs = ws + lay.hdrs[scale]; a.recs = ws + lay.recs[scale]; a.vox = vox;
+    a.direct = reinterpret_cast<const unsigned *>(ws + lay.direct[scale]);
     a.n_views = n_views; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles; a.Hf = Hf; a.Wf = Wf;
     const long long units = (long long)n_views * lay.n_tiles * 4;
     if (units >= (1ll << 31) - 8) return VFA_ERR_UNSUPPORTED;
-    a.per_xcd = (units + 7) / 8;
-    hipLaunchKernelGGL(pool_windows_kernel, dim3((unsigned)(a.per_xcd * 8)), dim3(256), 0, (hipStream_t)stream, a);
+    a.per_xcd = 0;
+    int n_cu = 256;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            cus > 0)
+            n_cu = cus;
+    }
+    long long nblk = 2ll * n_cu; // two persistent workgroups per CU (LDS: two double-buffered windows)
+    if (nblk > units) nblk = units;
+    nblk = (nblk + 7) / 8 * 8;
+    hipLaunchKernelGGL(pool_windows_kernel, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, a);
+    int st = (int)hipGetLastError();
+    if (st) return st;
+    if ((long long)lay.n_tiles * 4 >= (1ll << 31)) return VFA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pool_direct_kernel, dim3((unsigned)(lay.n_tiles * 4)), dim3(512), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 
