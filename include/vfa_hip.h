@@ -220,6 +220,20 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
                                    size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales, const int *feat_hw,
                                    int accumulate, int flags, void *stream);
 
+/* ---- consumers of the path ---------------------------------------------------------------------------
+ *
+ * vfa_sort_vertices_f32: anticlockwise order of the valid vertices of n convex polygons per batch entry (rectangle x rectangle
+ * intersections of the AP/AOS metric).                       replaces vfa/evaluation/pyeval/cuda_op/sort_vert_kernel.cu:42-140
+ *   vertices (b, n, m, 2) fp32 normalised around the polygon centre; mask (b, n, m) bytes (1 = valid candidate, the first 8 are box
+ *   corners, the rest edge intersections); num_valid (b, n) int32; idx (b, n, 9) int32 out: the sorted indices, the first one
+ *   repeated, then padded with an invalid intersection index.  m > 8.  Same selection rule, comparison and corner cases as the
+ *   reference kernel; one lane per polygon.
+ *
+ * vfa_bev_nms_f32: conf (L, W) = sigmoid(heatmap) where it equals its 5 x 5 max-pool (padding 2), else 0.
+ *                                                            replaces vfa/data/encoder.py:230-232 + the sigmoid of :238 / :278 */
+int vfa_sort_vertices_f32(const float *vertices, const uint8_t *mask, const int *num_valid, int *idx, int b, int n, int m, void *stream);
+int vfa_bev_nms_f32(const float *heatmap, float *conf, int L, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

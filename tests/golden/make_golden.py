@@ -225,9 +225,47 @@ def main_nl1():
                 ring_cameras(2, wt_c, 0.45 * 1440 * 2.5, 400.0, 1100.0, (1920, 1080)), (72, 128), 42)
 
 
+def main_decode():
+    """The step AFTER the path: the reference's own BEV decode (vfa/data/encoder.py:230-305) on random head outputs.  The
+    encoder only reads a few attributes of its dataset object, so a stand-in namespace is enough (no images, no labels)."""
+    from vfa.data.encoder import ObjectEncoder
+    for fname, base, ws, cube, shape, seed in (("decode_mc.npz", "MultiviewC", (3900, 3900), (25, 25, 32), (24, 30), 51),
+                                                ("decode_wt.npz", "Wildtrack", (480, 1440), (4, 4, 4), (30, 90), 52),
+                                                ("decode_mx.npz", "MultiviewX", (640, 1000), (4, 4, 8), (40, 63), 53)):
+        torch.manual_seed(seed)
+        mean = np.array([140.0, 60.0, 230.0], dtype=np.float32)
+        base_ns = types.SimpleNamespace(label_names=["Cow"], __name__=base)
+        ds = types.SimpleNamespace(base=base_ns, world_size=ws, cube_LWH=cube,
+                                   classAverage=types.SimpleNamespace(get_mean=lambda name: mean))
+        enc = ObjectEncoder(ds, topk=100)
+        L, W = shape
+        heat = torch.randn(1, 1, L, W) * 2.0 - 1.0
+        heat[0, 0, 3:6, 4:9] = 1.5          # a plateau: ties inside a 5 x 5 window
+        heat[0, 0, 0, 0] = 6.0              # a corner peak
+        pred = {"heatmap": heat, "loc_offset": torch.randn(1, L, W, 2), "dim_offset": torch.randn(1, L, W, 3) * 0.2,
+                "rotation": torch.randn(1, L, W, 360)}
+        out = {}
+        if base == "MultiviewC":
+            d = enc.decode3d(pred, 0.4)
+            out = {k: d[k].numpy() for k in ("conf", "location", "dimension", "rotation")}
+        else:
+            d = enc.decode2d(pred, 0.4)
+            out = {k: d[k].numpy() for k in ("conf", "location")}
+        with torch.no_grad():
+            nms = enc.nms(torch.sigmoid(heat))
+        np.savez_compressed(os.path.join(HERE, fname), base=base, world_size=np.array(ws), cube_LWH=np.array(cube),
+                            dimension_mean=mean, heatmap=heat.numpy(), loc_offset=pred["loc_offset"].numpy(),
+                            nms=nms.numpy(), **({"dim_offset": pred["dim_offset"].numpy(), "rotation_logits": pred["rotation"].numpy()}
+                                                if base == "MultiviewC" else {}), **{"out_" + k: v for k, v in out.items()})
+        print(f"{fname}: {len(out['conf'])} detections above 0.4, nms peaks {int((nms > 0).sum())}")
+
+
 if __name__ == "__main__":
-    if "--nl1" in sys.argv:
+    if "--decode" in sys.argv:
+        main_decode()
+    elif "--nl1" in sys.argv:
         main_nl1()
     else:
         main()
         main_nl1()
+        main_decode()

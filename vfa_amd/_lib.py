@@ -47,6 +47,8 @@ SIGNATURES = {
     "vfa_collapse_gemm_workspace_bytes": [_c_int, _c_int],
     "vfa_collapse_gemm_f32": [_vp, _vp, _vp, _vp, _c_size_t, _c_size_t, _c_int, _c_int, _c_int, _vp],
     "vfa_collapse_relu_sum_f32": [_vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
+    "vfa_sort_vertices_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp],
+    "vfa_bev_nms_f32": [_vp, _vp, _c_int, _c_int, _vp],
     "vfa_frame_workspace_bytes": [_c_int, _c_int, _c_int, _c_int],
     "vfa_frame_workspace_layout": [_c_int, _c_int, _c_int, _c_int, _vp, _vp],
     "vfa_frame_records_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,

@@ -65,6 +65,9 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
 {
+    // the 32 records of a (view, tile) are 3 KiB of consecutive memory: staged here so that the half-wave writes them as six
+    // 512-byte rows instead of 32 x 6 scattered 16-byte pieces (the kernel was bound by those stores)
+    __shared__ uint4 stage[2][kTileBoxes * 6];
     const int lane = threadIdx.x, half = lane >> 5, b = lane & 31;
     const long long pair = (long long)blockIdx.x * 2 + half;
     const bool pair_ok = pair < (long long)a.n_views * a.n_tiles;
@@ -153,15 +156,21 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
             bilinear_weights(q, xl, yb); w[12] = q[0]; w[13] = q[1]; w[14] = q[2]; w[15] = q[3];   // lb
         }
         if (pair_ok) {
-            uint4 *rec = reinterpret_cast<uint4 *>(a.recs[s] + (((size_t)view * a.n_tiles + tile) * kTileBoxes + b) * kRecBytes);
-            rec[0] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
-            rec[1] = make_uint4(__float_as_uint(w[4]), __float_as_uint(w[5]), __float_as_uint(w[6]), __float_as_uint(w[7]));
-            rec[2] = make_uint4(__float_as_uint(w[8]), __float_as_uint(w[9]), __float_as_uint(w[10]), __float_as_uint(w[11]));
-            rec[3] = make_uint4(__float_as_uint(w[12]), __float_as_uint(w[13]), __float_as_uint(w[14]), __float_as_uint(w[15]));
+            uint4 *st = stage[half] + b * 6;
+            st[0] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
+            st[1] = make_uint4(__float_as_uint(w[4]), __float_as_uint(w[5]), __float_as_uint(w[6]), __float_as_uint(w[7]));
+            st[2] = make_uint4(__float_as_uint(w[8]), __float_as_uint(w[9]), __float_as_uint(w[10]), __float_as_uint(w[11]));
+            st[3] = make_uint4(__float_as_uint(w[12]), __float_as_uint(w[13]), __float_as_uint(w[14]), __float_as_uint(w[15]));
             const float rcp = 1.0f / area; // correctly rounded
-            rec[4] = make_uint4(__float_as_uint(rcp), (unsigned)tag | (cont ? (unsigned)kCont : 0u), rows[0] | (rows[1] << 16),
-                                rows[2] | (rows[3] << 16));
-            rec[5] = make_uint4(cols[0] | (cols[1] << 16), cols[2] | (cols[3] << 16), __float_as_uint(masked), __float_as_uint(area));
+            st[4] = make_uint4(__float_as_uint(rcp), (unsigned)tag | (cont ? (unsigned)kCont : 0u), rows[0] | (rows[1] << 16),
+                               rows[2] | (rows[3] << 16));
+            st[5] = make_uint4(cols[0] | (cols[1] << 16), cols[2] | (cols[3] << 16), __float_as_uint(masked), __float_as_uint(area));
+        }
+        __syncthreads(); // (one wave: orders the LDS writes above against the reads below)
+        if (pair_ok) {
+            uint4 *rec = reinterpret_cast<uint4 *>(a.recs[s] + ((size_t)view * a.n_tiles + tile) * kTileBoxes * kRecBytes);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rec[k * 32 + b] = stage[half][k * 32 + b];
             if (b == 0) {
                 uint4 *hdr = reinterpret_cast<uint4 *>(a.hdrs[s] + ((size_t)view * a.n_tiles + tile) * kHdrBytes);
                 const int inv = cwid > 0 ? (65536 + cwid - 1) / cwid : 0; // floor(s / cwid) == (s * inv) >> 16 for s < 128
@@ -171,13 +180,19 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
                 if (any_live && direct) atomicOr(a.direct[s] + tile, 1u << view);
             }
         }
+        __syncthreads(); // the stage is reused by the next scale
+        if (blockIdx.x == 0 && lane < 6) // the spare record behind the table (prefetched by the consumers, never used)
+            reinterpret_cast<uint4 *>(a.recs[s] + (size_t)a.n_views * a.n_tiles * kTileBoxes * kRecBytes)[lane] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
 // collapse.weight (N = 256, K = 256) fp32 -> bf16 hi / lo planes in MFMA B-fragment order:
 //   out[((wave * 16 + s) * 2 + plane) * 64 + lane] (16 B) = W[n = 32 wave + (lane & 31)][k = 16 s + 8 (lane >> 5) + j], j = 0..7
-__global__ __launch_bounds__(256) void split_weight_frag_kernel(const float *__restrict__ w, uint4 *__restrict__ out)
+struct SplitArgs { const float *w[kMaxScales]; uint4 *out[kMaxScales]; };
+__global__ __launch_bounds__(256) void split_weight_frag_kernel(SplitArgs sa)
 {
+    const float *__restrict__ w = sa.w[blockIdx.y];
+    uint4 *__restrict__ out = sa.out[blockIdx.y];
     const int idx = blockIdx.x * 256 + threadIdx.x; // (wave, s, lane)
     if (idx >= 8 * kSteps * 64) return;
     const int lane = idx & 63, s = (idx >> 6) & 15, wave = idx >> 10;
@@ -857,7 +872,7 @@ __global__ __launch_bounds__(512) void pool_direct_kernel(PoolArgs a)
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
-    size_t live[kMaxScales], direct[kMaxScales], hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, diag, total;
+    size_t live[kMaxScales], direct[kMaxScales], hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], masks_bytes, chunks, diag, total;
     int tiles_l, tiles_w, n_tiles;
 };
 inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
@@ -867,10 +882,14 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     w.tiles_w = (W + kTileW - 1) / kTileW;
     w.n_tiles = w.tiles_l * w.tiles_w;
     size_t off = 0;
-    for (int s = 0; s < kMaxScales; ++s) {
+    for (int s = 0; s < kMaxScales; ++s) { // the view masks of all scales first, contiguous: zeroed by ONE memset
         const bool on = s < n_scales;
         w.live[s] = off;  off = align_up(off + (on ? (size_t)w.n_tiles * 4 : 0), 256);
         w.direct[s] = off; off = align_up(off + (on ? (size_t)w.n_tiles * 4 : 0), 256);
+    }
+    w.masks_bytes = off;
+    for (int s = 0; s < kMaxScales; ++s) {
+        const bool on = s < n_scales;
         w.hdrs[s] = off;  off = align_up(off + (on ? (size_t)n_views * w.n_tiles * kHdrBytes : 0), 256);
         w.recs[s] = off;  off = align_up(off + (on ? ((size_t)n_views * w.n_tiles * kTileBoxes + 1) * kRecBytes : 0), 256);
         w.wfrag[s] = off; off = align_up(off + (on ? (size_t)8 * kSteps * 2 * 64 * 16 : 0), 256);
@@ -937,11 +956,10 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
         a.hdrs[k] = ws + lay.hdrs[k];
         a.recs[k] = ws + lay.recs[k];
     }
-    for (int k = 0; k < n_scales; ++k) {
-        hipError_t e = hipMemsetAsync(ws + lay.live[k], 0, (size_t)lay.n_tiles * 4, s);
-        if (e == hipSuccess) e = hipMemsetAsync(ws + lay.direct[k], 0, (size_t)lay.n_tiles * 4, s);
-        if (e == hipSuccess) // the spare record behind the last tile (prefetched, never used)
-            e = hipMemsetAsync(ws + lay.recs[k] + (size_t)n_views * lay.n_tiles * kTileBoxes * kRecBytes, 0, kRecBytes, s);
+    // a single entry point = few launches: one memset (all view masks), the records kernel (which also clears the spare
+    // record behind each scale's table), the chunk boundaries, one weight-split launch
+    {
+        const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s);
         if (e != hipSuccess) return (int)e;
     }
     const long long pairs = (long long)n_views * lay.n_tiles;
@@ -952,14 +970,17 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
                        n_scales, lay.n_tiles, n_views >= 32 ? 0xffffffffu : ((1u << n_views) - 1u), reinterpret_cast<int *>(ws + lay.chunks));
     st = (int)hipGetLastError();
     if (st) return st;
-    if (weights)
-        for (int k = 0; k < n_scales; ++k) {
-            if (!weights[k]) return VFA_ERR_BAD_ARGUMENT;
-            hipLaunchKernelGGL(split_weight_frag_kernel, dim3(8 * kSteps * 64 / 256), dim3(256), 0, s, weights[k],
-                               reinterpret_cast<uint4 *>(ws + lay.wfrag[k]));
-            st = (int)hipGetLastError();
-            if (st) return st;
+    if (weights) {
+        SplitArgs sa;
+        for (int k = 0; k < kMaxScales; ++k) {
+            sa.w[k] = weights[k < n_scales ? k : 0];
+            sa.out[k] = reinterpret_cast<uint4 *>(ws + lay.wfrag[k < n_scales ? k : 0]);
+            if (!sa.w[k]) return VFA_ERR_BAD_ARGUMENT;
         }
+        hipLaunchKernelGGL(split_weight_frag_kernel, dim3(8 * kSteps * 64 / 256, n_scales), dim3(256), 0, s, sa);
+        st = (int)hipGetLastError();
+        if (st) return st;
+    }
     return 0;
 }
 
