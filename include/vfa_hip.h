@@ -81,6 +81,13 @@ int vfa_abi_version(void);
 int vfa_integral_image_f32(const float *feature, float *integral, int n_views, int C, int Hf, int Wf,
                            void *stream);
 
+/* Producer fusion: the same integral image, of  relu(x * scale[v, c] + shift[v, c])  -- the GroupNorm
+ * affine + ReLU of the lateral branch applied while the rows are scanned (two separately rounded fp32 operations), so the
+ * lateral map is never materialised.  x (n_views, C, Hf, Wf) = the lateral 1x1-conv output; scale, shift (n_views, C) with
+ * scale = gamma * rstd, shift = beta - mean * scale of the channel's group.   replaces vfanet.py:72-74 (norm + ReLU) + vfa_op.py:110 */
+int vfa_affine_relu_integral_image_f32(const float *x, const float *scale, const float *shift, float *integral, int n_views, int C,
+                                       int Hf, int Wf, void *stream);
+
 /* Cube corners -> world units -> 3x4 projection -> normalise/clamp -> 2-D bounding box, area and
  * visibility of every (view, layer, cell).                      replaces vfa_op.py:64-88, 104-106
  * and vfa/utils.py:50-59 (project).

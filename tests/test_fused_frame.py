@@ -308,3 +308,40 @@ def test_window_path_is_used_when_the_fused_kernel_is_off(monkeypatch):
     assert torch.equal(outs[(False, True)], outs[(False, False)])
     scale = outs[(False, False)].abs().max().item()
     torch.testing.assert_close(outs[(True, True)], outs[(False, False)], rtol=RTOL, atol=2 * ATOL_REL * scale)
+
+
+def test_producer_fusion_integral_is_bitwise_and_vfanet_agrees(monkeypatch):
+    """GroupNorm affine + ReLU applied inside the integral-image row scan.  (1) the kernel against
+    the unfused pair (relu(x * scale + shift) with two rounded fp32 operations, then `vfa_integral_image_f32`): BITWISE;
+    (2) a whole `VFANet` forward with the fusion on and off: the same maps within the path's tolerance (the statistics are
+    formed by other kernels than torch's GroupNorm)."""
+    from types import SimpleNamespace
+    from vfa_amd import ops, vfanet
+    from vfa_amd.synthetic import ring_cameras
+    from vfa_amd.utils import make_grid
+    dev = _dev()
+    gen = torch.Generator().manual_seed(9)
+    for n, C, H, W in ((2, 256, 23, 40), (1, 256, 45, 80), (3, 70, 9, 13)):
+        x = torch.randn(n, C, H, W, generator=gen).to(dev)
+        scale = (torch.rand(n, C, generator=gen) * 2 + 0.1).to(dev)
+        shift = (torch.randn(n, C, generator=gen) * 0.5).to(dev)
+        got = ops.affine_relu_integral_image(x, scale, shift)
+        lat = torch.relu(x * scale[:, :, None, None] + shift[:, :, None, None])
+        want = ops.integral_image(lat)
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), (n, C, H, W)
+    args = SimpleNamespace(data="MultiviewC", image_size=(720, 1280))
+    torch.manual_seed(4)
+    net = vfanet.VFANet(args, grid_height=160, cube_size=(18.75, 18.75, 160), mode="2D").to(dev).eval()
+    images = torch.rand(3, 3, 96, 160, generator=gen).to(dev)
+    calibs = ring_cameras(3, (1875.0, 1875.0, 0.0), 2700.0, 600.0, 900.0, (1280, 720)).to(dev)
+    grid = make_grid(world_size=(3750, 3750), cube_LW=[125, 150], dataset="MultiviewC")[None].to(dev)
+    outs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(vfanet, "FUSE_PRODUCER", fuse)
+        with torch.no_grad(), ops.KernelTimer() as kt:
+            outs.append(net.ortho_features(images, calibs, grid))
+        torch.cuda.synchronize()
+        assert ("vfa_affine_relu_integral_image_f32" in kt.summary()) == fuse
+    scale = outs[1].abs().max().item()
+    assert scale > 0
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-3, atol=1e-4 * scale)

@@ -27,6 +27,7 @@ _c_int, _c_float, _c_size_t, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 SIGNATURES = {
     "vfa_abi_version": [],
     "vfa_integral_image_f32": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
+    "vfa_affine_relu_integral_image_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_box_params_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _c_int,
                            _c_float, _c_float, _vp, _vp, _vp, _vp],
     "vfa_gather_f32": [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,

@@ -137,7 +137,7 @@ class PendingOrtho:
 
 
 def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange=(-1, 0.95), reduce_group=None,
-                    distributed=False):
+                    distributed=False, integrals=None):
     """The camera loop of ``VFANet.forward`` for the cameras held by this process.
 
     lat* (n,C,h,w) lateral maps of the local cameras, calibs (n,3,4), grid (1,L,W,3)
@@ -145,6 +145,8 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     With ``distributed=True`` the partial sums of all ranks are all-reduced before returning; with
     ``distributed="async"`` (inference) the all-reduce is only launched and a ``PendingOrtho`` is returned, so that
     the collective of frame i overlaps the projection of frame i+1.
+    ``integrals``: the three integral-image batches instead of the lateral maps (producer fusion, inference on the fused frame
+    path only; ``lat*`` may then be None).
     """
     length, width = grid.shape[-3], grid.shape[-2]
     n = calibs.shape[0]
@@ -152,7 +154,13 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     reserved = RESERVED_CUS if (bool(distributed) and dist.is_available() and dist.is_initialized()
                                 and dist.get_world_size(reduce_group) > 1) else 0
     work = ((vfa8, lat8), (vfa16, lat16), (vfa32, lat32))
-    if n > 0 and all(m.mfma_collapse_ok(lat) for m, lat in work):
+    if integrals is not None:
+        assert n > 0 and vfa_op.fused_frame_ok([vfa8, vfa16, vfa32], n) and not torch.is_grad_enabled(), \
+            "integral-image inputs need the fused inference path"
+        ortho = torch.empty((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
+        vfa_op.fused_frame([vfa8, vfa16, vfa32], None, calibs, grid, crange, out=ortho, reserved_cus=reserved,
+                           integrals=list(integrals))
+    elif n > 0 and all(m.mfma_collapse_ok(lat) for m, lat in work):
         # inference on single-layer grids: per scale, pooling then ONE MFMA kernel that forms collapse + bias + ReLU and
         # sums the views into the map (sum over views per scale, then over scales: the reference's sums re-associated,
         # inside the post-GEMM tolerance)

@@ -20,8 +20,10 @@ constexpr int kIntersectionOffset = 8; // INTERSECTION_OFFSET :7
 constexpr double kEps = 1e-8;        // EPSILON            :8 (a double literal in the reference)
 
 // "vertex 1 comes before vertex 2", vertices normalised around (0, 0): smallest on the positive x axis, growing anticlockwise
-// (sort_vert_kernel.cu:15-40; the reference falls off the end -- undefined -- when a y is exactly 0: false here)
-__device__ __forceinline__ bool before(float x1, float y1, float x2, float y2)
+// (sort_vert_kernel.cu:15-40; the reference falls off the end -- undefined -- when a y is exactly 0: false here).
+// Kept out of line: inlined twice into the selection loop, hipcc 7.2 at -O1 and above folds the second call to "false"
+// (every pick after the first stayed 0 on gfx950; -O0 and the out-of-line call agree with the CPU restatement).
+__device__ __noinline__ bool before(float x1, float y1, float x2, float y2)
 {
     if ((double)fabsf(x1 - x2) < kEps && (double)fabsf(y2 - y1) < kEps) return false;
     if (y1 > 0 && y2 < 0) return true;

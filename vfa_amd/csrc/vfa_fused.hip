@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     // tiles in front of the first live item are fully masked
     Item cur = seek(t_begin, 0, live_of(t_begin, 0));
     {
-        f32x16 none;
+        f32x16 none = {};
         if (!DIRECT)
             for (int t2 = t_begin; t2 < (cur.valid ? cur.tile : t_end); ++t2) write_tile(t2, none, false);
     }

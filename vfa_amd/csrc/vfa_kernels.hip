@@ -34,8 +34,14 @@ using namespace vfa_dev;
 // ------------------------------------------------------------------------------------------------
 constexpr int kRowChunk = 32;
 
+// AFFINE (producer fusion): the input is the lateral 1x1-conv output and the kernel applies the
+// GroupNorm affine + ReLU of reference vfanet.py:72-74 while scanning: f = relu(x * scale[v, c] + shift[v, c]), two
+// separately rounded fp32 operations, scale = gamma * rstd, shift = beta - mean * scale per (view, channel).  The lateral map
+// itself is never written.
+template <bool AFFINE>
 __global__ __launch_bounds__(kWave) void integral_rows_kernel(const float *__restrict__ feat,
-                                                              float *__restrict__ out, int C, int H, int W)
+                                                              float *__restrict__ out, int C, int H, int W,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift)
 {
     // tile[channel][x]: row stride 33 floats -> the per-lane scans (lane = channel) are bank-conflict free
     __shared__ __align__(16) float tile[kWave][kRowChunk + 1];
@@ -54,6 +60,14 @@ __global__ __launch_bounds__(kWave) void integral_rows_kernel(const float *__res
     // 16-byte paths need aligned rows (loads) and channel quads (stores)
     const bool vec_load = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0);
     const bool vec_store = (C % 4 == 0) && (nch == kWave) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const float sa = (AFFINE && active) ? scale[(size_t)v * C + c0 + lane] : 1.0f;
+    const float sb = (AFFINE && active) ? shift[(size_t)v * C + c0 + lane] : 0.0f;
+    auto act = [&](float x) {
+        if (!AFFINE) return x;
+        float t = x * sa;
+        t = t + sb;
+        return (t < 0.0f) ? 0.0f : t; // NaN stays NaN
+    };
     double acc = 0.0;
     for (int x0 = 0; x0 < W; x0 += kRowChunk) {
         const int nx = min(kRowChunk, W - x0);
@@ -73,12 +87,12 @@ __global__ __launch_bounds__(kWave) void integral_rows_kernel(const float *__res
         if (active) {
             if (vec_store) {
                 for (int k = 0; k < nx; ++k) { // scan in place; the stores follow as 16-byte accesses
-                    acc += (double)tile[lane][k];
+                    acc += (double)act(tile[lane][k]);
                     tile[lane][k] = (float)acc;
                 }
             } else {
                 for (int k = 0; k < nx; ++k) {
-                    acc += (double)tile[lane][k];
+                    acc += (double)act(tile[lane][k]);
                     dst[(size_t)(x0 + k + 1) * C + lane] = (float)acc;
                 }
             }
@@ -1682,13 +1696,18 @@ extern "C" {
 int vfa_abi_version(void) { return VFA_ABI_VERSION; }
 
 
-int vfa_integral_image_f32(const float *feature, float *integral, int n_views, int C, int Hf, int Wf, void *stream)
+static int integral_image_impl(const float *feature, const float *scale, const float *shift, float *integral, int n_views, int C,
+                               int Hf, int Wf, void *stream)
 {
     if (n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0) return VFA_ERR_BAD_ARGUMENT;
     if (n_views == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(integral_rows_kernel, dim3(Hf, (C + kWave - 1) / kWave, n_views), dim3(kWave), 0, s, feature,
-                       integral, C, Hf, Wf);
+    if (scale)
+        hipLaunchKernelGGL((integral_rows_kernel<true>), dim3(Hf, (C + kWave - 1) / kWave, n_views), dim3(kWave), 0, s, feature,
+                           integral, C, Hf, Wf, scale, shift);
+    else
+        hipLaunchKernelGGL((integral_rows_kernel<false>), dim3(Hf, (C + kWave - 1) / kWave, n_views), dim3(kWave), 0, s, feature,
+                           integral, C, Hf, Wf, scale, shift);
     int st = launch_status();
     if (st) return st;
     if (C % 4 == 0) {
@@ -1701,6 +1720,18 @@ int vfa_integral_image_f32(const float *feature, float *integral, int n_views, i
                            row_vecs, total);
     }
     return launch_status();
+}
+
+int vfa_integral_image_f32(const float *feature, float *integral, int n_views, int C, int Hf, int Wf, void *stream)
+{
+    return integral_image_impl(feature, nullptr, nullptr, integral, n_views, C, Hf, Wf, stream);
+}
+
+int vfa_affine_relu_integral_image_f32(const float *x, const float *scale, const float *shift, float *integral, int n_views, int C,
+                                       int Hf, int Wf, void *stream)
+{
+    if (!scale || !shift) return VFA_ERR_BAD_ARGUMENT;
+    return integral_image_impl(x, scale, shift, integral, n_views, C, Hf, Wf, stream);
 }
 
 int vfa_box_params_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off,

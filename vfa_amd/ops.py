@@ -71,6 +71,20 @@ def integral_image(features):
     return integral
 
 
+def affine_relu_integral_image(x, scale, shift):
+    """Integral images of relu(x * scale[:, :, None, None] + shift[:, :, None, None]) without materialising that map: the
+    GroupNorm affine + ReLU of the lateral branch fused into the row scan (reference vfanet.py:72-74 + vfa_op.py:110).
+    x (n,C,Hf,Wf), scale / shift (n,C) -> (n,Hf+2,Wf+2,C)."""
+    _lib.require_device(x, scale, shift)
+    x, scale, shift = _f32c(x), _f32c(scale), _f32c(shift)
+    n, C, Hf, Wf = x.shape
+    assert tuple(scale.shape) == (n, C) and tuple(shift.shape) == (n, C)
+    integral = torch.empty((n, Hf + 2, Wf + 2, C), dtype=torch.float32, device=x.device)
+    _launch("vfa_affine_relu_integral_image_f32", _lib.ptr(x), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(integral), n, C, Hf, Wf,
+            _lib.current_stream_handle(), tag=(n, C, Hf, Wf))
+    return integral
+
+
 def box_params(calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, feat_hw, crange=(-1, 0.95)):
     """-> box (n,nl,cells,4), area (n,nl,cells), visible (n,nl,cells) uint8 (reference vfa_op.py:64-106)."""
     _lib.require_device(calibs, grid_flat, z_layers, corner_off)

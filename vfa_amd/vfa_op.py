@@ -126,12 +126,15 @@ def fused_frame_ok(mods, n_views, mode="fused"):
                     and tuple(m.args.image_size) == tuple(m0.args.image_size) for m in mods))
 
 
-def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0):
+def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0, integrals=None):
     """All scales and all cameras of one frame: ``out (L*W, 256) (+)= sum_scale sum_view relu(collapse_scale(vox))``.
 
     mods / features: one ``VFA`` and one (n,256,Hf,Wf) lateral batch per scale.  Integral images (one launch pair per
     scale), then ``ops.frame_records`` (geometry once per frame) and ``ops.pool_collapse`` (everything else).  Inference
-    only (no autograd); needs ``fused_frame_ok``."""
+    only (no autograd); needs ``fused_frame_ok``.  ``integrals``: the zero-bordered channels-last integral images when the
+    caller already has them (producer fusion, ``VFANet.lateral_integrals``); ``features`` is then ignored."""
+    if integrals is not None:
+        features = [i.permute(0, 3, 1, 2)[:, :, 1:-1, 1:-1] for i in integrals]  # views: only their shapes are read below
     _lib.require_device(calibs, grid, *features)
     m0 = mods[0]
     conv_kind = _conv_kind(m0.args)
@@ -140,7 +143,8 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
     dev = features[0].device
     z_layers, corner_off = m0._kernel_geometry(dev)
     with torch.no_grad():
-        integrals = [ops.integral_image(f) for f in features]
+        if integrals is None:
+            integrals = [ops.integral_image(f) for f in features]
         ws = ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h),
                                [tuple(f.shape[-2:]) for f in features], weights=[m.layer_major_weight() for m in mods],
                                crange=crange)

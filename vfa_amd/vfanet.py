@@ -17,8 +17,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops, vfa_op
 from .aggregate import aggregate_views, camera_shard
 from .vfa_op import VFA
+
+# Producer fusion, inference on the fused frame path: the GroupNorm affine + ReLU of the lateral branch
+# is applied inside the integral-image row scan (`vfa_affine_relu_integral_image_f32`); the lateral maps are never written.
+FUSE_PRODUCER = os.environ.get("VFA_AMD_FUSE_PRODUCER", "1") == "1"
 
 # ``pretrained=True`` (the default of the reference's train.py:90): the reference downloads the torchvision ImageNet
 # checkpoint (resnet.py:155-159, 170-172).  There is no network on the MI355X boxes, so the file is looked up locally.
@@ -144,12 +149,33 @@ class VFANet(nn.Module):
         f8, f16, f32 = self.base(x)
         return (F.relu(self.bn8(self.lat8(f8))), F.relu(self.bn16(self.lat16(f16))), F.relu(self.bn32(self.lat32(f32))))
 
+    def lateral_integrals(self, images):
+        """images (n,3,iH,iW) -> the three zero-bordered channels-last integral images of the lateral maps, without
+        materialising those maps: 1x1 conv (MIOpen), GroupNorm statistics (two small reductions), then the affine + ReLU inside
+        the row scan of the integral image (reference vfanet.py:72-74 + vfa_op.py:110, 172-173)."""
+        x = (images - self.mean.view(3, 1, 1)) / self.std.view(3, 1, 1)
+        out = []
+        for feat, conv, gn in zip(self.base(x), (self.lat8, self.lat16, self.lat32), (self.bn8, self.bn16, self.bn32)):
+            y = conv(feat)
+            n, c = y.shape[:2]
+            var, mean = torch.var_mean(y.reshape(n, gn.num_groups, -1), dim=2, unbiased=False)          # (n, groups)
+            rstd = torch.rsqrt(var + gn.eps)
+            per = c // gn.num_groups
+            scale = gn.weight.view(1, c) * rstd.repeat_interleave(per, dim=1)                            # gamma * rstd
+            shift = gn.bias.view(1, c) - mean.repeat_interleave(per, dim=1) * scale                      # beta - mean * scale
+            out.append(ops.affine_relu_integral_image(y, scale, shift))
+        return out
+
     def ortho_features(self, images, calibs, grid, distributed=False):
         """The fused BEV map (1,256,L,W) entering the heads (reference vfanet.py:64-82, 131)."""
         if distributed:
             mine = camera_shard(images.shape[0])
             idx = torch.tensor(mine, dtype=torch.long, device=images.device)
             images, calibs = images[idx], calibs[idx]
+        if (FUSE_PRODUCER and not torch.is_grad_enabled() and images.is_cuda and images.shape[0]
+                and vfa_op.fused_frame_ok([self.vfa8, self.vfa16, self.vfa32], images.shape[0])):
+            return aggregate_views(self.vfa8, self.vfa16, self.vfa32, None, None, None, calibs, grid, (-1, 0.95),
+                                   distributed=distributed, integrals=self.lateral_integrals(images))
         lat8, lat16, lat32 = self.laterals(images) if images.shape[0] else (images.new_zeros(0, 256, 1, 1),) * 3
         return aggregate_views(self.vfa8, self.vfa16, self.vfa32, lat8, lat16, lat32, calibs, grid, (-1, 0.95),
                                distributed=distributed)
