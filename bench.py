@@ -35,6 +35,7 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (MI355X_MICROARCH.md); the 5 PF headline includes 2:1 sparsity
 PRIMARY = "multiviewc_200x200x1"
 C5 = "synthetic4k_512x512x32"
 
@@ -235,37 +236,81 @@ class _Null:
 
 
 # entry point -> the kernel that does the work, for the roofline label
-KERNEL_NAMES = {"vfa_project_gather_f32": {"tap_cache": "gather_cached_kernel", "direct": "gather_kernel<4, true>"}}
+KERNEL_NAMES = {"vfa_project_gather_f32": {"tap_cache": "gather_cached_kernel", "direct": "gather_kernel<4, true>"},
+                "vfa_pool_windows_f32": {"windows": "pool_windows_kernel"},
+                "vfa_pool_collapse_relu_sum_f32": {"fused": "pool_collapse_kernel"}}
+ROOFLINE_ENTRY_POINTS = tuple(KERNEL_NAMES)
+
+
+def committed_traffic(workload, kernel_substr):
+    """HBM bytes per dispatch from the committed PMC passes of this command (profiles/rNN_pmc_traffic.json), or None."""
+    for tag in ("r02", "r01"):
+        tpath = os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")
+        if workload == PRIMARY and os.path.exists(tpath):
+            for name, rec in json.load(open(tpath))["kernels"].items():
+                if kernel_substr in name:
+                    return rec["hbm_bytes_per_dispatch"], f"profiles/{tag}_pmc_traffic.json"
+    return None, None
+
+
+def traffic_note(src):
+    return (src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_to_traffic.py; "
+            "not measured in this run)") if src else None
+
+
+def roofline_fused(g, workload):
+    """Roofline of the fused pooling + collapse kernel (the bound becomes the matrix pipe).  One launch
+    covers every (view, scale) of the frame.  flops = the bf16 MFMA flops the kernel issues: each fp32 product of the
+    reference's sgemm is three bf16 products of an exact hi/lo split, so 3 * 2*M*K*N, priced against the dense bf16 peak;
+    the fp32 flops of the reference's product (2*M*K*N) against the fp32 matrix peak are reported beside it.  The HBM side
+    (integral images read once, BEV map written once, records read once) is reported as `hbm_*`."""
+    flops = bytes_alg = 0.0
+    for (nv, L, W, hws), rec in g["by_tag"].items():
+        per = len(hws) * nv * L * W * 2.0 * 256 * 256
+        flops += rec["launches"] * per
+        bytes_alg += rec["launches"] * (sum(nv * (h + 2) * (w + 2) * 256 * 4 for h, w in hws) + L * W * 256 * 4 +
+                                        L * W * 12 + nv * 48)
+    avg_s = g["ms"] / g["launches"] * 1e-3
+    per_launch = flops / g["launches"]
+    achieved = 3 * per_launch / avg_s / 1e12
+    traffic, src = committed_traffic(workload, "pool_collapse_kernel")
+    return {"bound": "mfma", "kernel": "vfa_pool_collapse_relu_sum_f32: pool_collapse_kernel<3> (+ its oversized-window "
+            "pass), one launch per frame: box pooling of 7 views x 3 scales -> bf16-split MFMA collapse -> bias + ReLU + "
+            "view/scale sum", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note(src),
+            "avg_launch_us": avg_s * 1e6, "mfma_flops_per_launch": 3 * per_launch,
+            "fp32_flops_per_launch": per_launch, "fp32_equivalent_tflops": per_launch / avg_s / 1e12,
+            "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": per_launch / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "hbm_algorithmic_bytes_per_launch": bytes_alg / g["launches"],
+            "hbm_achieved_gbs": bytes_alg / g["launches"] / avg_s / 1e9, "hbm_frac": bytes_alg / g["launches"] / avg_s / 1e9 / HBM_PEAK_GBS,
+            "launches": g["launches"]}
 
 
 def roofline_of(ks, ops, workload):
-    """Roofline of the pooling kernel (HBM-bound by SURVEY.md 8d): algorithmic bytes of one launch = integral images read
-    once + voxel features written once + grid + calibs; achieved = those bytes / mean launch time from HIP events
-    recorded on the launch stream inside the timed loop."""
-    g = ks.get("vfa_project_gather_f32", dict(launches=0, ms=0.0, by_tag={}))
+    """Roofline of the dominant kernel of the step.  Fused path: see `roofline_fused`.  Unfused paths: the pooling kernel
+    (HBM-bound by SURVEY.md 8d): algorithmic bytes of one launch = integral images read once + voxel features written once
+    + grid + calibs; achieved = those bytes / mean launch time from HIP events recorded on the launch stream inside the
+    timed loop."""
+    if ks.get("vfa_pool_collapse_relu_sum_f32", {}).get("launches"):
+        return roofline_fused(ks["vfa_pool_collapse_relu_sum_f32"], workload)
+    entry = "vfa_pool_windows_f32" if ks.get("vfa_pool_windows_f32", {}).get("launches") else "vfa_project_gather_f32"
+    g = ks.get(entry, dict(launches=0, ms=0.0, by_tag={}))
     if not g["launches"]:
         return None
     alg_bytes = 0
     for (nv, Ct, Hf, Wf, nlt, cells), rec in g["by_tag"].items():
         alg_bytes += rec["launches"] * (nv * Ct * Hf * Wf * 4 + nv * nlt * cells * Ct * 4 + cells * 12 + nv * 48)
-    chosen = sorted(set(ops._gather_choice.values())) or ["default"]
-    kname = KERNEL_NAMES["vfa_project_gather_f32"]
+    chosen = ["windows"] if entry == "vfa_pool_windows_f32" else (sorted(set(ops._gather_choice.values())) or ["default"])
+    kname = KERNEL_NAMES[entry]
     traffic, src = None, None
-    for tag in ("r02", "r01"):
-        tpath = os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")
-        if workload == PRIMARY and os.path.exists(tpath) and len(chosen) == 1 and chosen[0] in kname:
-            for name, rec in json.load(open(tpath))["kernels"].items():
-                if kname[chosen[0]] in name:
-                    traffic, src = rec["hbm_bytes_per_dispatch"], f"profiles/{tag}_pmc_traffic.json"
-            if traffic is not None:
-                break
+    if len(chosen) == 1 and chosen[0] in kname:
+        traffic, src = committed_traffic(workload, kname[chosen[0]])
     avg_ms = g["ms"] / g["launches"]
     achieved = alg_bytes / g["launches"] / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "vfa_project_gather_f32: " + "/".join(kname.get(c, c) for c in chosen) +
-            " (picked per shape on first use)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": (src + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                               "tools/pmc_to_traffic.py; not measured in this run)") if src else None,
+    return {"bound": "hbm", "kernel": entry + ": " + "/".join(kname.get(c, c) for c in chosen) +
+            (" (picked per shape on first use)" if entry == "vfa_project_gather_f32" else ""), "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": traffic_note(src),
             "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": alg_bytes / g["launches"],
             "launches": g["launches"]}
 
@@ -320,7 +365,7 @@ def main():
             leg.step()
         leg.drain()
         leg.fence()
-    kt = ops.KernelTimer(only=("vfa_project_gather_f32",))
+    kt = ops.KernelTimer(only=ROOFLINE_ENTRY_POINTS)
     dt = leg.timed(a.steps, kt)
     ks = kt.summary()
     roofline = roofline_of(ks, ops, a.workload)
@@ -372,7 +417,16 @@ def main():
         del c5
 
     ck = ks_all.get("vfa_collapse_relu_sum_f32")
-    if ck and ck["launches"]:
+    fk = ks_all.get("vfa_pool_collapse_relu_sum_f32")
+    if fk and fk["launches"]:
+        us = 1e3 * fk["ms"] / fk["launches"]
+        collapse_info = {"flops_per_step": gemm_flops, "backend": "fused into vfa_pool_collapse_relu_sum_f32 (pooled rows go "
+                         "from registers to LDS bf16 hi/lo planes to 3xbf16-split MFMA, fp32 accumulate; bias + ReLU + "
+                         "view/scale sum in the epilogue; the voxel features never reach HBM)", "avg_us": us,
+                         "fp32_equivalent_tflops": gemm_flops / (us * 1e-6) / 1e12,
+                         "bf16_mfma_tflops": 3 * gemm_flops / (us * 1e-6) / 1e12,
+                         "max_rel_error_vs_fp64": "~3e-6 of max|out| (tests/test_fused_frame.py), tolerance 1e-5"}
+    elif ck and ck["launches"]:
         collapse_info = {"flops_per_step": gemm_flops, "backend": "vfa_collapse_relu_sum_f32 (3xbf16-split MFMA, fp32 "
                          "accumulate, fused bias+ReLU+view sum)", "avg_us": 1e3 * ck["ms"] / ck["launches"],
                          "fp32_equivalent_tflops": gemm_flops / 3 / (ck["ms"] / ck["launches"] * 1e-3) / 1e12,

@@ -631,7 +631,8 @@ def test_collapse_relu_sum_rejects_other_shapes_and_handles_empty():
 
 @pytest.mark.parametrize("name", ["multiviewc_200x200x1", "wildtrack_480x1440x1"])
 def test_mfma_collapse_path_matches_library_path_and_float64(name, monkeypatch):
-    """Inference on single-layer grids runs pooling + `vfa_collapse_relu_sum_f32`; the same frame through the fp32
+    """Inference on single-layer grids runs the fused per-frame kernel (default) or pooling + `vfa_collapse_relu_sum_f32`
+    per scale; the same frame through the fp32
     library GEMM + epilogue kernels and through a float64 product of the (bitwise-pinned) voxel features must agree
     within the post-GEMM tolerance, at BASELINE sizes."""
     import vfa_amd
@@ -648,6 +649,12 @@ def test_mfma_collapse_path_matches_library_path_and_float64(name, monkeypatch):
     assert all(m.mfma_collapse_ok() for m in mods) is False  # parameters require grad outside no_grad
     with torch.no_grad():
         assert all(m.mfma_collapse_ok(l) for m, l in zip(mods, lats))
+        with ops.KernelTimer() as kt:
+            fused = vfa_amd.aggregate_views(*mods, *lats, wl["calibs"], wl["grid"])
+        torch.cuda.synchronize()
+        assert "vfa_pool_collapse_relu_sum_f32" in kt.summary()  # the default: one kernel per frame
+        monkeypatch.setattr(vfa_op, "FUSED_POOL", False)
+        monkeypatch.setattr(vfa_op, "WINDOW_POOL", False)
         with ops.KernelTimer() as kt:
             fast = vfa_amd.aggregate_views(*mods, *lats, wl["calibs"], wl["grid"])
         torch.cuda.synchronize()
@@ -670,7 +677,10 @@ def test_mfma_collapse_path_matches_library_path_and_float64(name, monkeypatch):
     L, W = wl["grid"].shape[1:3]
     f = fast[0].permute(1, 2, 0).reshape(L * W, 256)
     s = slow[0].permute(1, 2, 0).reshape(L * W, 256)
+    u = fused[0].permute(1, 2, 0).reshape(L * W, 256)
     torch.testing.assert_close(f, s, rtol=RTOL, atol=2 * ATOL_REL * scale)
+    torch.testing.assert_close(u, s, rtol=RTOL, atol=2 * ATOL_REL * scale)
+    torch.testing.assert_close(u[:cells].double(), want, rtol=RTOL, atol=ATOL_REL * scale)
     torch.testing.assert_close(f[:cells].double(), want, rtol=RTOL, atol=ATOL_REL * scale)
     torch.testing.assert_close(s[:cells].double(), want, rtol=RTOL, atol=ATOL_REL * scale)
 
