@@ -88,6 +88,14 @@ int vfa_integral_image_f32(const float *feature, float *integral, int n_views, i
 int vfa_affine_relu_integral_image_f32(const float *x, const float *scale, const float *shift, float *integral, int n_views, int C,
                                        int Hf, int Wf, void *stream);
 
+/* The integral images of all the feature maps of a frame (one per stride) in ONE launch pair: features[s] (n_views, C, H_s, W_s),
+ * integrals[s] (n_views, H_s + 2, W_s + 2, C), feat_hw = {H_0, W_0, H_1, W_1, ...} (host array), n_maps <= 4.  scales / shifts:
+ * both NULL (plain maps, vfa_integral_image_f32 of each) or both arrays of n_maps device pointers (n_views, C) (producer fusion,
+ * vfa_affine_relu_integral_image_f32 of each).  Results are bit-identical to the per-map entry points; the small maps share the
+ * launch of the large one instead of paying a launch pair each.   replaces the three vfa_op.py:110 calls of vfanet.py:76-78 */
+int vfa_integral_images_f32(const float *const *features, const float *const *scales, const float *const *shifts,
+                            float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream);
+
 /* Cube corners -> world units -> 3x4 projection -> normalise/clamp -> 2-D bounding box, area and
  * visibility of every (view, layer, cell).                      replaces vfa_op.py:64-88, 104-106
  * and vfa/utils.py:50-59 (project).

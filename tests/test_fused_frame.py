@@ -341,7 +341,35 @@ def test_producer_fusion_integral_is_bitwise_and_vfanet_agrees(monkeypatch):
         with torch.no_grad(), ops.KernelTimer() as kt:
             outs.append(net.ortho_features(images, calibs, grid))
         torch.cuda.synchronize()
-        assert ("vfa_affine_relu_integral_image_f32" in kt.summary()) == fuse
+        assert all(tag[-1] == fuse for tag in kt.summary()["vfa_integral_images_f32"]["by_tag"])  # affine variant or plain
     scale = outs[1].abs().max().item()
     assert scale > 0
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-3, atol=1e-4 * scale)
+
+
+@pytest.mark.parametrize("shapes,n,C", [(((90, 160), (45, 80), (23, 40)), 2, 256),   # the bench frame: tails of 0, 16 and 8 columns
+                                        (((7, 44), (3, 4)), 3, 128),                  # a 12-column tail, a one-chunk map
+                                        (((9, 13), (5, 8)), 2, 70),                   # odd shapes: the per-map kernels
+                                        (((12, 36),), 1, 64)])
+def test_batched_integral_images_are_bitwise_the_per_map_ones(shapes, n, C):
+    """`vfa_integral_images_f32` (all strides of a frame in one launch pair, loads one chunk ahead) against
+    `vfa_integral_image_f32` / `vfa_affine_relu_integral_image_f32` per map -- which the oracle pins: BITWISE, borders included,
+    with heavy-tailed inputs (sums that are inexact in double would expose any re-association)."""
+    from vfa_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(len(shapes) * 100 + C)
+    feats = []
+    for H, W in shapes:
+        f = torch.randn(n, C, H, W, generator=gen)
+        f = f * torch.exp(6 * torch.randn(n, C, H, W, generator=gen))  # magnitudes over ~15 decades
+        feats.append(f.to(dev))
+    got = ops.integral_images(feats)
+    for f, g in zip(feats, got):
+        want = ops.integral_image(f)
+        assert g.shape == want.shape and torch.equal(g.view(torch.int32), want.view(torch.int32)), tuple(f.shape)
+    scales = [(torch.rand(n, C, generator=gen) * 2 + 0.1).to(dev) for _ in shapes]
+    shifts = [(torch.randn(n, C, generator=gen) * 0.5).to(dev) for _ in shapes]
+    got = ops.integral_images(feats, scales, shifts)
+    for f, sc, sh, g in zip(feats, scales, shifts, got):
+        want = ops.affine_relu_integral_image(f, sc, sh)
+        assert torch.equal(g.view(torch.int32), want.view(torch.int32)), tuple(f.shape)

@@ -48,6 +48,7 @@ SIGNATURES = {
     "vfa_collapse_gemm_workspace_bytes": [_c_int, _c_int],
     "vfa_collapse_gemm_f32": [_vp, _vp, _vp, _vp, _c_size_t, _c_size_t, _c_int, _c_int, _c_int, _vp],
     "vfa_collapse_relu_sum_f32": [_vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
+    "vfa_integral_images_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp],
     "vfa_sort_vertices_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp],
     "vfa_bev_nms_f32": [_vp, _vp, _c_int, _c_int, _vp],
     "vfa_frame_workspace_bytes": [_c_int, _c_int, _c_int, _c_int],

@@ -1,0 +1,194 @@
+// vfa_integral.hip -- integral images of all the feature scales of a frame in one launch pair.
+//
+// Reference: vfa/model/vfa_op.py:110, 172-173 (features.cumsum(-1).cumsum(-2), once per scale and camera) and, with the
+// affine variant, vfa/model/vfanet.py:72-74 (GroupNorm affine + ReLU of the lateral branch) -- SURVEY.md section 8 a1 / f3.
+//
+// Arithmetic is ATen's CPU cumsum, operation for operation: a double accumulator per (row, channel) running LEFT TO RIGHT,
+// rounded to fp32 at every element; then a double accumulator per (column, channel) running TOP TO BOTTOM over those fp32
+// values, rounded at every element.  No partial sum is ever re-associated (a tree / look-back scan would round differently
+// whenever a double sum is inexact), so the result is bit-identical to the reference for any input.
+//
+// Why one launch pair per FRAME: the stride-16 and stride-32 maps are too small to fill 256 CUs (630 + 161 wave-rows); in
+// their own launches they cost ~30 us per scale of mostly launch latency and tail.  Batched, they ride along with the
+// stride-8 map.  Layout and borders as in vfa_kernels.hip (channels-last, one zero pixel all round).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vfa_hip.h"
+#include "vfa_geom.h"
+
+namespace {
+using namespace vfa_dev;
+
+constexpr int kMaxMaps = 4;
+constexpr int kChunk = 32;    // columns staged per step
+
+struct MapDesc {
+    const float *feat;   // (n_views, C, H, W)
+    float *out;          // (n_views, H + 2, W + 2, C)
+    const float *scale;  // (n_views, C) or NULL
+    const float *shift;
+    int H, W;
+    unsigned row_blocks; // H * (C / 64) * n_views
+    unsigned long long col_vecs; // n_views * (W + 2) * C / 4
+};
+struct MapArgs {
+    MapDesc m[kMaxMaps];
+    int n_maps, n_views, C;
+};
+
+// pass 1: one wave = 64 channels of one image row, 32-column chunks (the scheme of integral_rows_kernel in vfa_kernels.hip, which
+// measured faster than a variant with register scans and loads one chunk ahead: 8.4 KiB of LDS keep every wave-row of the
+// frame resident at once).  NCHW loads: 8 lanes x float4 = one 128-byte row piece of a channel; the tile is scanned in place
+// with lane = channel (pitch 33: conflict-free); channels-last stores: 16 lanes x float4 = the 256 B of a pixel.
+template <bool AFFINE>
+__global__ __launch_bounds__(kWave) void rows_batched_kernel(MapArgs a)
+{
+    __shared__ __align__(16) float tile[kWave][kChunk + 1];
+    const int lane = threadIdx.x;
+    unsigned b = blockIdx.x;
+    int mi = 0;
+    while (mi + 1 < a.n_maps && b >= a.m[mi].row_blocks) { b -= a.m[mi].row_blocks; ++mi; }
+    const MapDesc &m = a.m[mi];
+    const int H = m.H, W = m.W, C = a.C, cblocks = C / kWave;
+    const int y = (int)(b % (unsigned)H);
+    const unsigned rest = b / (unsigned)H;
+    const int c0 = (int)(rest % (unsigned)cblocks) * kWave, v = (int)(rest / (unsigned)cblocks);
+    const size_t plane = (size_t)H * W;
+    const float *src = m.feat + ((size_t)v * C + c0) * plane + (size_t)y * W;
+    float *dst = m.out + (((size_t)v * (H + 2) + (y + 1)) * (W + 2)) * C + c0; // padded row y + 1, padded column 0
+    dst[lane] = 0.0f;                       // left border
+    dst[(size_t)(W + 1) * C + lane] = 0.0f; // right border
+    float sa = 1.0f, sb = 0.0f;
+    if (AFFINE) {
+        sa = m.scale[(size_t)v * C + c0 + lane];
+        sb = m.shift[(size_t)v * C + c0 + lane];
+    }
+    auto act = [&](float x) {
+        if (!AFFINE) return x;
+        float t = x * sa;
+        t = t + sb;
+        return (t < 0.0f) ? 0.0f : t; // NaN stays NaN
+    };
+    const int q = lane & 7, cq = lane & 15;
+    double acc = 0.0;
+    for (int x0 = 0; x0 < W; x0 += kChunk) {
+        const int nx = min(kChunk, W - x0); // a multiple of 4
+        if (4 * q < nx) {
+            for (int r = lane >> 3; r < kWave; r += 8) {
+                const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)r * plane + x0 + 4 * q);
+                tile[r][4 * q + 0] = t.x; tile[r][4 * q + 1] = t.y; tile[r][4 * q + 2] = t.z; tile[r][4 * q + 3] = t.w;
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < nx; ++k) {
+            acc += (double)act(tile[lane][k]);
+            tile[lane][k] = (float)acc;
+        }
+        __syncthreads();
+        for (int k = lane >> 4; k < nx; k += 4) {
+            const float4 t = make_float4(tile[4 * cq + 0][k], tile[4 * cq + 1][k], tile[4 * cq + 2][k], tile[4 * cq + 3][k]);
+            *reinterpret_cast<float4 *>(dst + (size_t)(x0 + k + 1) * C + 4 * cq) = t;
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2: cumsum along H, in place, plus the zero top and bottom border rows.  One thread owns four channels of one padded
+// column of one view of one map; its loads do not depend on the running sum and are issued eight rows ahead.
+__global__ __launch_bounds__(256) void cols_batched_kernel(MapArgs a, unsigned long long total)
+{
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int mi = 0;
+    while (mi + 1 < a.n_maps && i >= a.m[mi].col_vecs) { i -= a.m[mi].col_vecs; ++mi; }
+    const MapDesc &m = a.m[mi];
+    const int H = m.H;
+    const size_t row_vecs = (size_t)(m.W + 2) * a.C / 4;
+    const size_t v = i / row_vecs, r = i % row_vecs;
+    float4 *p = reinterpret_cast<float4 *>(m.out) + v * (size_t)(H + 2) * row_vecs + r;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    p[0] = zero;
+    p[(size_t)(H + 1) * row_vecs] = zero;
+    p += row_vecs; // first interior row
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    auto step = [&](float4 &t) {
+        a0 += (double)t.x; t.x = (float)a0;
+        a1 += (double)t.y; t.y = (float)a1;
+        a2 += (double)t.z; t.z = (float)a2;
+        a3 += (double)t.w; t.w = (float)a3;
+    };
+    constexpr int U = 8;
+    int y = 0;
+    for (; y + U <= H; y += U) {
+        float4 t[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) t[k] = p[(size_t)(y + k) * row_vecs];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            step(t[k]);
+            p[(size_t)(y + k) * row_vecs] = t[k];
+        }
+    }
+    for (; y < H; ++y) {
+        float4 t = p[(size_t)y * row_vecs];
+        step(t);
+        p[(size_t)y * row_vecs] = t;
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+} // namespace
+
+extern "C" {
+
+int vfa_integral_images_f32(const float *const *features, const float *const *scales, const float *const *shifts,
+                            float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream)
+{
+    if (!features || !integrals || !feat_hw || n_views < 0 || C <= 0 || n_maps < 0) return VFA_ERR_BAD_ARGUMENT;
+    if ((scales == nullptr) != (shifts == nullptr)) return VFA_ERR_BAD_ARGUMENT;
+    for (int s = 0; s < n_maps; ++s) {
+        if (feat_hw[2 * s] <= 0 || feat_hw[2 * s + 1] <= 0 || !features[s] || !integrals[s]) return VFA_ERR_BAD_ARGUMENT;
+        if (scales && (!scales[s] || !shifts[s])) return VFA_ERR_BAD_ARGUMENT;
+    }
+    if (n_views == 0 || n_maps == 0) return 0;
+    bool fast = (C % kWave == 0) && n_maps <= kMaxMaps;
+    for (int s = 0; s < n_maps && fast; ++s)
+        fast = (feat_hw[2 * s + 1] % 4 == 0) && aligned16(features[s]) && aligned16(integrals[s]);
+    if (!fast) { // odd shapes: the per-map kernels of vfa_kernels.hip (same arithmetic)
+        for (int s = 0; s < n_maps; ++s) {
+            const int st = scales ? vfa_affine_relu_integral_image_f32(features[s], scales[s], shifts[s], integrals[s], n_views, C,
+                                                                        feat_hw[2 * s], feat_hw[2 * s + 1], stream)
+                                  : vfa_integral_image_f32(features[s], integrals[s], n_views, C, feat_hw[2 * s], feat_hw[2 * s + 1], stream);
+            if (st) return st;
+        }
+        return 0;
+    }
+    MapArgs a = {};
+    a.n_maps = n_maps; a.n_views = n_views; a.C = C;
+    unsigned long long row_blocks = 0, col_vecs = 0;
+    for (int s = 0; s < n_maps; ++s) {
+        MapDesc &m = a.m[s];
+        m.feat = features[s]; m.out = integrals[s];
+        m.scale = scales ? scales[s] : nullptr; m.shift = shifts ? shifts[s] : nullptr;
+        m.H = feat_hw[2 * s]; m.W = feat_hw[2 * s + 1];
+        const unsigned long long rb = (unsigned long long)m.H * (C / kWave) * n_views;
+        if (rb >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
+        m.row_blocks = (unsigned)rb;
+        m.col_vecs = (unsigned long long)n_views * (m.W + 2) * C / 4;
+        row_blocks += rb; col_vecs += m.col_vecs;
+    }
+    if (row_blocks >= (1ull << 31) || (col_vecs + 255) / 256 >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (scales)
+        hipLaunchKernelGGL((rows_batched_kernel<true>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
+    else
+        hipLaunchKernelGGL((rows_batched_kernel<false>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    hipLaunchKernelGGL(cols_batched_kernel, dim3((unsigned)((col_vecs + 255) / 256)), dim3(256), 0, st, a, col_vecs);
+    return (int)hipGetLastError();
+}
+
+} // extern "C"

@@ -85,6 +85,26 @@ def affine_relu_integral_image(x, scale, shift):
     return integral
 
 
+def integral_images(features, scales=None, shifts=None):
+    """The integral images of every feature map of a frame in one launch pair (``vfa_integral_images_f32``): features = one
+    (n,C,H_s,W_s) batch per stride -> one (n,H_s+2,W_s+2,C) image per stride, bit-identical to ``integral_image`` of each.
+    ``scales`` / ``shifts`` (one (n,C) tensor per map): the fused GroupNorm affine + ReLU of ``affine_relu_integral_image``."""
+    features = [_f32c(f) for f in features]
+    _lib.require_device(*features)
+    n, C = features[0].shape[:2]
+    assert all(f.shape[0] == n and f.shape[1] == C for f in features)
+    outs = [torch.empty((n, f.shape[2] + 2, f.shape[3] + 2, C), dtype=torch.float32, device=f.device) for f in features]
+    affine = scales is not None
+    if affine:
+        scales, shifts = [_f32c(t) for t in scales], [_f32c(t) for t in shifts]
+        assert all(tuple(t.shape) == (n, C) for t in scales + shifts)
+    hw = _lib.int_array([v for f in features for v in f.shape[2:]])
+    _launch("vfa_integral_images_f32", _lib.ptr_array(features), _lib.ptr_array(scales) if affine else None,
+            _lib.ptr_array(shifts) if affine else None, _lib.ptr_array(outs), n, C, len(features), hw,
+            _lib.current_stream_handle(), tag=(n, C, tuple(tuple(f.shape[2:]) for f in features), affine))
+    return outs
+
+
 def box_params(calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, feat_hw, crange=(-1, 0.95)):
     """-> box (n,nl,cells,4), area (n,nl,cells), visible (n,nl,cells) uint8 (reference vfa_op.py:64-106)."""
     _lib.require_device(calibs, grid_flat, z_layers, corner_off)

@@ -144,7 +144,7 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
     z_layers, corner_off = m0._kernel_geometry(dev)
     with torch.no_grad():
         if integrals is None:
-            integrals = [ops.integral_image(f) for f in features]
+            integrals = ops.integral_images(features)  # all strides in one launch pair
         ws = ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h),
                                [tuple(f.shape[-2:]) for f in features], weights=[m.layer_major_weight() for m in mods],
                                crange=crange)
@@ -171,8 +171,9 @@ def window_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accu
         ws = ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h),
                                [tuple(f.shape[-2:]) for f in features], weights=None, crange=crange)
         vox = torch.empty((n, length * width, 256), dtype=torch.float32, device=dev)
-        for k, (m, f) in enumerate(zip(mods, features)):
-            ops.pool_windows(ops.integral_image(f), ws, (length, width), len(mods), k, out=vox)
+        integrals = ops.integral_images(features)
+        for k, (m, integral) in enumerate(zip(mods, integrals)):
+            ops.pool_windows(integral, ws, (length, width), len(mods), k, out=vox)
             ops.collapse_relu_sum(vox, m.layer_major_weight(), m.collapse.bias, out=out, accumulate=accumulate or k > 0,
                                   terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
     return out

@@ -154,7 +154,7 @@ class VFANet(nn.Module):
         materialising those maps: 1x1 conv (MIOpen), GroupNorm statistics (two small reductions), then the affine + ReLU inside
         the row scan of the integral image (reference vfanet.py:72-74 + vfa_op.py:110, 172-173)."""
         x = (images - self.mean.view(3, 1, 1)) / self.std.view(3, 1, 1)
-        out = []
+        ys, scales, shifts = [], [], []
         for feat, conv, gn in zip(self.base(x), (self.lat8, self.lat16, self.lat32), (self.bn8, self.bn16, self.bn32)):
             y = conv(feat)
             n, c = y.shape[:2]
@@ -163,8 +163,8 @@ class VFANet(nn.Module):
             per = c // gn.num_groups
             scale = gn.weight.view(1, c) * rstd.repeat_interleave(per, dim=1)                            # gamma * rstd
             shift = gn.bias.view(1, c) - mean.repeat_interleave(per, dim=1) * scale                      # beta - mean * scale
-            out.append(ops.affine_relu_integral_image(y, scale, shift))
-        return out
+            ys.append(y), scales.append(scale), shifts.append(shift)
+        return ops.integral_images(ys, scales, shifts)
 
     def ortho_features(self, images, calibs, grid, distributed=False):
         """The fused BEV map (1,256,L,W) entering the heads (reference vfanet.py:64-82, 131)."""
