@@ -114,6 +114,17 @@ class _CollapseGemm(torch.autograd.Function):
         return g_vox, g_w, None
 
 
+SIDE_STREAM = os.environ.get("VFA_AMD_SIDE_STREAM", "1") == "1"
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
+
 def fused_frame_ok(mods, n_views, mode="fused"):
     """The per-frame-records inference paths (``mode`` "fused": one persistent kernel for everything behind the integral
     images; "window": LDS-window pooling kernel + MFMA collapse kernel per scale) cover these projector modules (one per
@@ -143,11 +154,19 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
     dev = features[0].device
     z_layers, corner_off = m0._kernel_geometry(dev)
     with torch.no_grad():
+        # geometry (camera + grid only) on a second HIP stream, beside the integral images (bandwidth-bound, feature maps only)
+        cur = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if SIDE_STREAM and integrals is None else cur
+        weights = [m.layer_major_weight() for m in mods]
+        ws = torch.empty(max(_lib.lib().vfa_frame_workspace_bytes(calibs.shape[0], length, width, len(mods)), 1),
+                         dtype=torch.uint8, device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h),
+                              [tuple(f.shape[-2:]) for f in features], weights=weights, crange=crange, workspace=ws)
         if integrals is None:
             integrals = ops.integral_images(features)  # all strides in one launch pair
-        ws = ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h),
-                               [tuple(f.shape[-2:]) for f in features], weights=[m.layer_major_weight() for m in mods],
-                               crange=crange)
+        cur.wait_stream(side)
         return ops.pool_collapse(integrals, [m.collapse.bias for m in mods], ws, (length, width), out=out,
                                  accumulate=accumulate, terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
 
