@@ -217,9 +217,11 @@ int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, voi
  *   integrals / biases = HOST arrays of n_scales device pointers ((n_views, Hf+2, Wf+2, 256) each / (256) or NULL);
  *   workspace = what vfa_frame_records_f32 filled for the same (n_views, L, W, n_scales, feat_hw). */
 size_t vfa_frame_workspace_bytes(int n_views, int L, int W, int n_scales);
-/* Where things are inside that workspace (tests and tools/ read the records back): offsets[5 k + {0..4}] = live-view masks,
- * direct-item masks, tile headers (32 B), box records (96 B), split weight of scale k; offsets[15] diagnostics, offsets[16]
- * total bytes; tiles = {tile rows, tile columns, tap-window capacity in slots}.  Tiles are 4 x 8 cells. */
+/* Where things are inside that workspace (tests and tools/ read the records back): offsets[23]: offsets[5 k + {0..4}] = live-view
+ * masks, direct-item masks, tile headers (32 B), box records (96 B), split weight of scale k; offsets[15] diagnostics, offsets[16]
+ * total bytes; offsets[17 + k] = masks of the direct items without a row slot, offsets[20] the direct-item counter,
+ * offsets[21] the pooled rows of the direct items (slot x 32 boxes x 256 fp32), offsets[22] = the number of row slots;
+ * tiles = {tile rows, tile columns, tap-window capacity in slots}.  Tiles are 4 x 8 cells. */
 int vfa_frame_workspace_layout(int n_views, int L, int W, int n_scales, size_t *offsets, int *tiles);
 int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
                           int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,

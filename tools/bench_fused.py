@@ -83,3 +83,8 @@ with torch.no_grad():
             for k, nm in enumerate(names):
                 print(f"      {nm:28s} {np.mean(d[:, k] / items):9.0f}")
             print(f"      {'sum':28s} {np.mean(d[:, :7].sum(1) / items):9.0f}")
+            tot = d[:, :7].sum(1)
+            print(f"    per-workgroup total cycles: min {tot.min():.3g}  mean {tot.mean():.3g}  p90 {np.percentile(tot, 90):.3g}  max {tot.max():.3g}"
+                  f"  (max / mean {tot.max() / tot.mean():.3f}); items per workgroup min {items.min():.0f} max {items.max():.0f}")
+            order = np.argsort(tot)[-5:]
+            print("    slowest workgroups (cycles, items, cycles/item):", [(int(tot[i]), int(items[i]), int(tot[i] / items[i])) for i in order])

@@ -40,7 +40,7 @@ constexpr int kSteps = kC / 16;                                     // k-steps o
 // record flags
 constexpr int kVis = 1, kCont = 1 << 8; // bits 1-2 DXC, bits 3-4 DYC; kCont: same tap set as the previous box of the 4-box chunk
 // tile header flags
-constexpr int kTileLive = 1, kTileDirect = 2;
+constexpr int kTileLive = 1, kTileDirect = 2, kTileRows = 4; // kTileRows: a direct item whose pooled rows the pre-pass leaves in the workspace (header word 2 = its slot there)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -54,6 +54,9 @@ struct RecordArgs {
     ScaleDims dims[kMaxScales];
     unsigned *live[kMaxScales];      // (n_tiles) bit v = view v has a visible box in the tile
     unsigned *direct[kMaxScales];    // (n_tiles) bit v = ... and the tile's tap window does not fit LDS (subset of live)
+    unsigned *overflow[kMaxScales];  // (n_tiles) bit v = ... and there was no row slot left for it (subset of direct)
+    unsigned *row_counter;           // direct items numbered so far (all scales)
+    unsigned rows_cap;               // row slots in the workspace
     unsigned char *hdrs[kMaxScales]; // (n_views, n_tiles, 32 B)
     unsigned char *recs[kMaxScales]; // (n_views, n_tiles, 32 boxes, 96 B)
 };
@@ -174,10 +177,16 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
             if (b == 0) {
                 uint4 *hdr = reinterpret_cast<uint4 *>(a.hdrs[s] + ((size_t)view * a.n_tiles + tile) * kHdrBytes);
                 const int inv = cwid > 0 ? (65536 + cwid - 1) / cwid : 0; // floor(s / cwid) == (s * inv) >> 16 for s < 128
-                hdr[0] = make_uint4((any_live ? kTileLive : 0) | (direct ? kTileDirect : 0), (unsigned)n_slots, (unsigned)cwid, (unsigned)inv);
-                hdr[1] = make_uint4((unsigned)x0, (unsigned)t0, (unsigned)top_rows, (unsigned)b0);
+                unsigned hflags = (any_live ? kTileLive : 0) | (direct ? kTileDirect : 0), word2 = (unsigned)cwid;
                 if (any_live) atomicOr(a.live[s] + tile, 1u << view);
-                if (any_live && direct) atomicOr(a.direct[s] + tile, 1u << view);
+                if (any_live && direct) {
+                    atomicOr(a.direct[s] + tile, 1u << view);
+                    const unsigned slot = atomicAdd(a.row_counter, 1u); // (the order is arbitrary: the slot only names scratch space)
+                    if (slot < a.rows_cap) { hflags |= kTileRows; word2 = slot; } // (a direct item has no use for the window width)
+                    else atomicOr(a.overflow[s] + tile, 1u << view);
+                }
+                hdr[0] = make_uint4(hflags, (unsigned)n_slots, word2, (unsigned)inv);
+                hdr[1] = make_uint4((unsigned)x0, (unsigned)t0, (unsigned)top_rows, (unsigned)b0);
             }
         }
         __syncthreads(); // the stage is reused by the next scale
@@ -254,7 +263,7 @@ struct FusedScale {
     const float *integral;          // (n_views, Hf+2, Wf+2, 256) zero-bordered channels-last
     const float *bias;              // (256) or NULL
     const uint4 *wfrag;             // split_weight_frag_kernel output
-    const unsigned *live, *direct;  // (n_tiles) each
+    const unsigned *live, *direct, *overflow; // (n_tiles) each
     const unsigned char *hdrs, *recs;
     int Hf, Wf;
 };
@@ -263,6 +272,9 @@ struct FusedArgs {
     int n_scales, n_views, L, W, tiles_w, n_tiles;
     float *out;                     // (L * W, 256)
     const int *chunk_start;         // (kChunks + 1) tile_chunks_kernel
+    const float *rows;              // pooled rows of the direct items (pool_rows_kernel): slot x 32 boxes x 256 channels
+    const unsigned *row_counter;    // direct items of the frame
+    int rows_cap;                   // row slots in the workspace
     int accumulate;
     int debug;                      // diagnostic build only: ablation mask (kDbg*), results are then meaningless
     unsigned long long *diag;       // diagnostic build only: per workgroup 8 cycle counters
@@ -325,6 +337,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     // Main launch: a contiguous range of tiles of equal COST for this workgroup (tile_chunks_kernel); neighbouring ranges
     // share an XCD (their tap windows overlap).  Direct-item launch: tiles dealt round-robin -- those items sit in clusters
     // in front of the cameras.
+    if (DIRECT && uniform_i((int)*a.row_counter) <= a.rows_cap) return; // every direct item of this frame got a row slot
     const int nblk = gridDim.x;
     const int lb = (int)xcd_contiguous(blockIdx.x, (nblk + 7) / 8);
     if (lb >= nblk) return;
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     auto live_all = [&](int tile, int scale) { return (unsigned)uniform_i((int)(a.sc[scale].live[tile] & view_mask)); };
     // the views of (tile, scale) this launch works on
     auto live_of = [&](int tile, int scale) {
-        const unsigned dm = a.sc[scale].direct[tile] & view_mask;
+        const unsigned dm = a.sc[scale].overflow[tile] & view_mask;
         return (unsigned)uniform_i((int)(DIRECT ? dm : (a.sc[scale].live[tile] & view_mask & ~dm)));
     };
     // first live item at or after (tile, scale) with view bits `rest`
@@ -368,10 +381,14 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             for (int s = 0; s < kMaxScales; ++s)
                 if (s < a.n_scales) extra += (float)(a.n_views - __popc(live_all(tile, s))) * relu_t(bias_of(s));
         }
-        float *ocol = a.out + wave * 32 + r;
+        // (opaque copies: the per-lane row offsets below are loop invariants the compiler would otherwise keep in VGPRs for the
+        // whole kernel, pushing other values into scratch)
+        int h2 = h, r2 = r;
+        asm volatile("" : "+v"(h2), "+v"(r2));
+        float *ocol = a.out + wave * 32 + r2;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h2;
             const int cl = tl * kTileL + (row >> 3), cw = tw * kTileW + (row & 7);
             if (cl < a.L && cw < a.W) {
                 float *o = ocol + (size_t)(cl * a.W + cw) * kC;
@@ -418,12 +435,28 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 
     const int grp = lane >> 4, cq = lane & 15;
     LRec rec; // record of THIS lane's box of the item to be pooled next
-    auto load_record = [&](const Item &it) {
+    // (a direct item of the main launch needs no record: the same registers prefetch its pooled row instead -- four float4,
+    // channels 64 q + 4 cq .. + 3 of box 4 wave + grp, left in the workspace by pool_rows_kernel)
+    auto load_record = [&](const Item &it, int it_flags, int it_slot) {
+        if (!DIRECT && (it_flags & kTileRows)) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.rows) + ((size_t)it_slot * kTileBoxes + 4 * wave + grp) * (kC / 4) + cq;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rec.v[q] = p[q * 16];
+            return;
+        }
         const uint4 *p = reinterpret_cast<const uint4 *>(a.sc[it.scale].recs + (((size_t)it.view * a.n_tiles + it.tile) * kTileBoxes + 4 * wave + grp) * kRecBytes);
 #pragma unroll
         for (int k = 0; k < 6; ++k) rec.v[k] = p[k];
     };
-    auto pool = [&](const Item &it) {
+    auto pool = [&](const Item &it, int it_flags, int it_word1) {
+        if (!DIRECT && (it_flags & kTileRows)) {
+            // a direct item of the main launch: its pooled rows came with `load_record`; only the bf16 split remains
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                store_quad(s_planes, 4 * wave + grp, q * 16 + cq,
+                           make_float4(__uint_as_float(rec.v[q].x), __uint_as_float(rec.v[q].y), __uint_as_float(rec.v[q].z), __uint_as_float(rec.v[q].w)));
+            return;
+        }
         const FusedScale &sc = a.sc[it.scale];
         const unsigned Wp = (unsigned)sc.Wf + 2u;
         const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)it.view * (sc.Hf + 2) * Wp * kSlotBytes;
@@ -511,8 +544,9 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     };
     i32x8 nh;
     header_of(cur, nh);
-    load_record(cur);
     header_wait(nh);
+    int cur_flags = nh[0], cur_word1 = nh[2], nxt_flags = 0, nxt_word1 = 0; // header words 0, 2 of the item being pooled / the next
+    load_record(cur, cur_flags, cur_word1);
     if (!(dbg & kDbgNoFills)) {
         begin_fills(cur, nh);
         rest_fills();
@@ -553,15 +587,16 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             bc = bias_of(cur.scale);
             w_scale = cur.scale;
         }
-        if (!(dbg & kDbgNoPool)) pool(cur);
+        if (!(dbg & kDbgNoPool)) pool(cur, cur_flags, cur_word1);
         tick(2);
         __syncthreads();                    // A tile complete; the tap window is free again
         tick(3);
         f_n = 0;
         if (nxt.valid) {
             header_wait(nh);
+            nxt_flags = nh[0]; nxt_word1 = nh[2];
             if (!(dbg & kDbgNoFills)) begin_fills(nxt, nh); // issued between the MFMAs below
-            load_record(nxt); // this lane's box of the next item: lands under the MFMAs
+            load_record(nxt, nxt_flags, nxt_word1); // this lane's box of the next item: lands under the MFMAs
         }
         if (nn.valid) header_of(nn, nh);
         tick(4);
@@ -570,11 +605,13 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
         if (!(dbg & kDbgNoMfma)) {
-            const unsigned char *pa = s_planes + frag_base;
+            int key2 = key, fb = frag_base; // (opaque: keeps the 16 swizzled fragment offsets out of long-lived registers)
+            asm volatile("" : "+v"(key2), "+v"(fb));
+            const unsigned char *pa = s_planes + fb;
 #pragma unroll
             for (int c = 0; c < kSteps / 2; ++c) {
                 one_fill(); // (wave-uniform branch; nothing to issue once the wave's share of the window is on its way)
-                const int off0 = ((2 * c) ^ (key >> 1)) << 5, off1 = ((2 * c + 1) ^ (key >> 1)) << 5;
+                const int off0 = ((2 * c) ^ (key2 >> 1)) << 5, off1 = ((2 * c + 1) ^ (key2 >> 1)) << 5;
                 const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(pa + off0);
                 const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(pa + off1);
                 const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off0);
@@ -604,6 +641,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         tick(6);
         if (DIAG) stamp[7] += 1;
         cur = nxt;
+        cur_flags = nxt_flags; cur_word1 = nxt_word1;
         nxt = nn;
     }
     flush();
@@ -869,11 +907,74 @@ __global__ __launch_bounds__(512) void pool_direct_kernel(PoolArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2a. pre-pass of the fused path: the direct items (tap window larger than LDS: boxes right in front of a camera) are pooled
+// here, at full occupancy and with every tap load of a box in flight at once, into fp32 rows in the workspace.  Inside the
+// persistent kernel those loads had nothing to hide behind (W takes half of the register file: 8 taps per round trip,
+// ~53 000 cycles per item).  Same arithmetic as the persistent kernel's own pooling (v * RN(1 / area)).
+// grid = (n_tiles x 4 quarters, n_scales); one wave = 4 boxes x 64 channels.
+// ------------------------------------------------------------------------------------------------
+struct RowsArgs {
+    const float *integral[kMaxScales];
+    const unsigned char *hdrs[kMaxScales], *recs[kMaxScales];
+    const unsigned *direct[kMaxScales];
+    int Hf[kMaxScales], Wf[kMaxScales];
+    float *rows;
+    int n_views, n_tiles;
+};
+__global__ __launch_bounds__(512) void pool_rows_kernel(RowsArgs a)
+{
+    const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, grp = lane >> 4, cq = lane & 15;
+    const int tile = blockIdx.x >> 2, q = blockIdx.x & 3, s = blockIdx.y;
+    unsigned mask = (unsigned)uniform_i((int)a.direct[s][tile]);
+    if (a.n_views < 32) mask &= (1u << a.n_views) - 1u;
+    const int b = 4 * wave + grp;
+    const int Wp = a.Wf[s] + 2;
+    while (mask) {
+        const int view = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        const int item = view * a.n_tiles + tile;
+        const unsigned *hd = reinterpret_cast<const unsigned *>(a.hdrs[s] + (size_t)item * kHdrBytes);
+        const int flags = uniform_i((int)hd[0]), slot = uniform_i((int)hd[2]);
+        if (!(flags & kTileRows)) continue; // no row slot left: the second launch of the persistent kernel takes it
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs[s] + ((size_t)item * kTileBoxes + b) * kRecBytes);
+        uint4 r[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r[k] = rp[k];
+        const float wt[16] = {__uint_as_float(r[0].x), __uint_as_float(r[0].y), __uint_as_float(r[0].z), __uint_as_float(r[0].w),
+                              __uint_as_float(r[1].x), __uint_as_float(r[1].y), __uint_as_float(r[1].z), __uint_as_float(r[1].w),
+                              __uint_as_float(r[2].x), __uint_as_float(r[2].y), __uint_as_float(r[2].z), __uint_as_float(r[2].w),
+                              __uint_as_float(r[3].x), __uint_as_float(r[3].y), __uint_as_float(r[3].z), __uint_as_float(r[3].w)};
+        const float rcp = __uint_as_float(r[4].x), masked = __uint_as_float(r[5].z);
+        const bool vis = (r[4].y & (unsigned)kVis) != 0u;
+        // records of a direct item hold pixel coordinates (+ 1: the zero border); a masked box reads pixel 0 and discards it
+        const unsigned rws[4] = {vis ? r[4].z & 0xffffu : 0u, vis ? r[4].z >> 16 : 0u, vis ? r[4].w & 0xffffu : 0u, vis ? r[4].w >> 16 : 0u};
+        const unsigned cls[4] = {vis ? r[5].x & 0xffffu : 0u, vis ? r[5].x >> 16 : 0u, vis ? r[5].y & 0xffffu : 0u, vis ? r[5].y >> 16 : 0u};
+        const char *img = reinterpret_cast<const char *>(a.integral[s]) + (size_t)view * (a.Hf[s] + 2) * Wp * kSlotBytes + q * 256 + cq * 16;
+        float4 t[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[i][j] = *reinterpret_cast<const float4 *>(img + (size_t)(rws[i] * Wp + cls[j]) * kSlotBytes);
+        const float4 lt = sample4(t[0][0], t[0][1], t[1][0], t[1][1], wt[0], wt[1], wt[2], wt[3]);
+        const float4 rb = sample4(t[2][2], t[2][3], t[3][2], t[3][3], wt[4], wt[5], wt[6], wt[7]);
+        const float4 rt = sample4(t[0][2], t[0][3], t[1][2], t[1][3], wt[8], wt[9], wt[10], wt[11]);
+        const float4 lb2 = sample4(t[2][0], t[2][1], t[3][0], t[3][1], wt[12], wt[13], wt[14], wt[15]);
+        float4 v = make_float4(lt.x + rb.x, lt.y + rb.y, lt.z + rb.z, lt.w + rb.w); // (((lt + rb) - rt) - lb) * RN(1 / area)
+        v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
+        v = make_float4(v.x - lb2.x, v.y - lb2.y, v.z - lb2.z, v.w - lb2.w);
+        float4 res = make_float4(v.x * rcp, v.y * rcp, v.z * rcp, v.w * rcp);
+        if (!vis) res = make_float4(masked, masked, masked, masked);
+        reinterpret_cast<float4 *>(a.rows)[((size_t)slot * kTileBoxes + b) * (kC / 4) + q * 16 + cq] = res;
+    }
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
-    size_t live[kMaxScales], direct[kMaxScales], hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], masks_bytes, chunks, diag, total;
-    int tiles_l, tiles_w, n_tiles;
+    size_t live[kMaxScales], direct[kMaxScales], overflow[kMaxScales], counter, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales],
+        masks_bytes, chunks, diag, rows, total;
+    int tiles_l, tiles_w, n_tiles, rows_cap;
 };
 inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
 {
@@ -886,7 +987,9 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
         const bool on = s < n_scales;
         w.live[s] = off;  off = align_up(off + (on ? (size_t)w.n_tiles * 4 : 0), 256);
         w.direct[s] = off; off = align_up(off + (on ? (size_t)w.n_tiles * 4 : 0), 256);
+        w.overflow[s] = off; off = align_up(off + (on ? (size_t)w.n_tiles * 4 : 0), 256);
     }
+    w.counter = off; off += 256; // direct items numbered so far
     w.masks_bytes = off;
     for (int s = 0; s < kMaxScales; ++s) {
         const bool on = s < n_scales;
@@ -898,6 +1001,15 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     off = align_up(off + (kChunks + 1) * sizeof(int), 256);
     w.diag = off;
     off = align_up(off + 512 * 8 * sizeof(unsigned long long), 256); // diagnostic build: 8 counters per workgroup
+    // pooled rows of the direct items: room for a quarter of all (view, tile, scale) items, at most 256 MiB; the rest (none on the
+    // BASELINE frames: 3 % of the items of the bench frame are direct) goes through the second launch
+    const size_t items = (size_t)n_views * w.n_tiles * n_scales;
+    size_t cap = items / 4 + 64;
+    if (cap > 8192) cap = 8192;
+    if (cap > items) cap = items;
+    w.rows_cap = (int)cap;
+    w.rows = off;
+    off = align_up(off + cap * kTileBoxes * kC * sizeof(float), 256);
     w.total = off;
     return w;
 }
@@ -925,6 +1037,10 @@ int vfa_frame_workspace_layout(int n_views, int L, int W, int n_scales, size_t *
     }
     offsets[15] = lay.diag;
     offsets[16] = lay.total;
+    for (int k = 0; k < kMaxScales; ++k) offsets[17 + k] = lay.overflow[k];
+    offsets[20] = lay.counter;
+    offsets[21] = lay.rows;
+    offsets[22] = (size_t)lay.rows_cap;
     tiles[0] = lay.tiles_l;
     tiles[1] = lay.tiles_w;
     tiles[2] = kMaxSlots;
@@ -953,12 +1069,15 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
         if (a.dims[k].Hf <= 0 || a.dims[k].Wf <= 0 || a.dims[k].Hf > 65533 || a.dims[k].Wf > 65533) return VFA_ERR_BAD_ARGUMENT;
         a.live[k] = reinterpret_cast<unsigned *>(ws + lay.live[k]);
         a.direct[k] = reinterpret_cast<unsigned *>(ws + lay.direct[k]);
+        a.overflow[k] = reinterpret_cast<unsigned *>(ws + lay.overflow[k]);
         a.hdrs[k] = ws + lay.hdrs[k];
         a.recs[k] = ws + lay.recs[k];
     }
     // a single entry point = few launches: one memset (all view masks), the records kernel (which also clears the spare
     // record behind each scale's table), the chunk boundaries, one weight-split launch
     {
+        a.row_counter = reinterpret_cast<unsigned *>(ws + lay.counter);
+        a.rows_cap = (unsigned)lay.rows_cap;
         const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s);
         if (e != hipSuccess) return (int)e;
     }
@@ -1046,6 +1165,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
         a.sc[k].wfrag = reinterpret_cast<const uint4 *>(ws + lay.wfrag[q]);
         a.sc[k].live = reinterpret_cast<const unsigned *>(ws + lay.live[q]);
         a.sc[k].direct = reinterpret_cast<const unsigned *>(ws + lay.direct[q]);
+        a.sc[k].overflow = reinterpret_cast<const unsigned *>(ws + lay.overflow[q]);
         a.sc[k].hdrs = ws + lay.hdrs[q];
         a.sc[k].recs = ws + lay.recs[q];
         a.sc[k].Hf = feat_hw[2 * q];
@@ -1068,7 +1188,22 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     int nblk = lay.n_tiles < n_cu ? lay.n_tiles : n_cu;
     nblk = (nblk + 7) / 8 * 8; // xcd_contiguous deals whole eighths; surplus blocks find an empty range and leave
     if (nblk > 512) nblk = 512;
-    if (debug & 64) { // diagnostic: only the second launch (direct items)
+    a.rows = reinterpret_cast<const float *>(ws + lay.rows);
+    a.row_counter = reinterpret_cast<const unsigned *>(ws + lay.counter);
+    a.rows_cap = lay.rows_cap;
+    if (!(debug & 64)) { // pre-pass: pooled rows of the direct items (a block leaves at once where its tile has none)
+        RowsArgs ra;
+        for (int k = 0; k < kMaxScales; ++k) {
+            ra.integral[k] = a.sc[k].integral; ra.hdrs[k] = a.sc[k].hdrs; ra.recs[k] = a.sc[k].recs; ra.direct[k] = a.sc[k].direct;
+            ra.Hf[k] = a.sc[k].Hf; ra.Wf[k] = a.sc[k].Wf;
+        }
+        ra.rows = reinterpret_cast<float *>(const_cast<unsigned char *>(ws) + lay.rows);
+        ra.n_views = n_views; ra.n_tiles = lay.n_tiles;
+        hipLaunchKernelGGL(pool_rows_kernel, dim3((unsigned)(lay.n_tiles * 4), n_scales), dim3(512), 0, s, ra);
+        const int st0 = (int)hipGetLastError();
+        if (st0) return st0;
+    }
+    if (debug & 64) { // diagnostic: only the second launch (direct items without a row slot)
         hipLaunchKernelGGL((pool_collapse_kernel<3, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
         return (int)hipGetLastError();
     }
