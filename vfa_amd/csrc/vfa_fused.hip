@@ -218,25 +218,32 @@ __global__ __launch_bounds__(256) void split_weight_frag_kernel(SplitArgs sa)
 }
 
 // Work balance of the persistent kernel: the cost of a tile is its number of live (view, scale) items, which varies with the
-// camera coverage.  chunk_start[c], c = 0..kChunks, cuts the tile sequence into kChunks pieces of equal cost (weight of a
-// tile = 1 + 4 x live items); a workgroup takes a contiguous run of chunks.  One workgroup, an LDS scan over per-thread sums.
+// camera coverage.  The tile sequence is cut into kChunks pieces of equal cost (weight of a tile = 1 + 4 x live items); a
+// workgroup takes a contiguous run of chunks.  A cut may fall INSIDE a tile: chunk c starts at the chunk_rank[c]-th live item of
+// tile chunk_start[c] (items in (scale, view) order; rank 0 = the tile's beginning) -- whole tiles only left the slowest
+// workgroup 19 % above the mean on the bench frame (4.9 tiles of ~18 items per workgroup).  A tile cut this way is finished by
+// the workgroup that holds its beginning, which gets the partial sums of the other one through the workspace (see `flush`).
+// One workgroup, an LDS scan over per-thread sums.
 constexpr int kChunks = 1024;
+constexpr int kMaxBlocks = 512; // workgroups of the persistent kernel
 __global__ __launch_bounds__(1024) void tile_chunks_kernel(const unsigned *live0, const unsigned *live1, const unsigned *live2,
-                                                           int n_scales, int n_tiles, unsigned view_mask, int *chunk_start)
+                                                           const unsigned *ovf0, const unsigned *ovf1, const unsigned *ovf2,
+                                                           int n_scales, int n_tiles, unsigned view_mask, int *chunk_start, int *chunk_rank)
 {
     __shared__ unsigned long long part[1024];
     const int tid = threadIdx.x;
     const int per = (n_tiles + 1023) / 1024, t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
-    auto weight = [&](int t) {
-        int items = __popc(live0[t] & view_mask);
-        if (n_scales > 1) items += __popc(live1[t] & view_mask);
-        if (n_scales > 2) items += __popc(live2[t] & view_mask);
-        return (unsigned long long)(1 + 4 * items);
+    auto items_of = [&](int t) {
+        // (the items of the main launch: live, minus the direct ones without a row slot)
+        int items = __popc(live0[t] & ~ovf0[t] & view_mask);
+        if (n_scales > 1) items += __popc(live1[t] & ~ovf1[t] & view_mask);
+        if (n_scales > 2) items += __popc(live2[t] & ~ovf2[t] & view_mask);
+        return items;
     };
     unsigned long long local = 0;
-    for (int t = t0; t < t1; ++t) local += weight(t);
+    for (int t = t0; t < t1; ++t) local += (unsigned long long)(1 + 4 * items_of(t));
     part[tid] = local;
-    for (int c = tid; c <= kChunks; c += 1024) chunk_start[c] = n_tiles;
+    for (int c = tid; c <= kChunks; c += 1024) { chunk_start[c] = n_tiles; chunk_rank[c] = 0; }
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) { // inclusive Hillis-Steele scan
         const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
@@ -246,13 +253,24 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(const unsigned *live0
     }
     const unsigned long long total = part[1023];
     unsigned long long before = part[tid] - local; // weight of all tiles in front of tile t
-    // chunk c starts at the first tile t with  before(t) * kChunks >= total * c
+    // chunk c starts at position p_c = ceil(total c / kChunks): inside the tile t with before(t) <= p_c < before(t) + weight(t)
     for (int t = t0; t < t1; ++t) {
-        // i.e. c <= before(t) K / total  and  c > before(t - 1) K / total
-        const unsigned long long hi = before * kChunks / total;
-        const long long lo = t == 0 ? 0 : (long long)((before - weight(t - 1)) * kChunks / total) + 1;
-        for (long long c = lo; c <= (long long)hi && c < kChunks; ++c) chunk_start[c] = t;
-        before += weight(t);
+        const int items = items_of(t);
+        const unsigned long long w = (unsigned long long)(1 + 4 * items);
+        long long c = before > 0 ? (long long)((before - 1) * kChunks / total) : 0; // p_c >= before  <=>  c > (before - 1) K / total
+        for (; c < kChunks; ++c) {
+            const unsigned long long pc = (total * (unsigned long long)c + kChunks - 1) / kChunks;
+            if (pc < before) continue;
+            if (pc >= before + w) break;
+            const int k = (int)((pc - before + 2) / 4); // the item nearest to the position
+            if (k >= items && items > 0) { // behind the last item: the next tile's beginning (written by its own thread if it
+                if (t + 1 < n_tiles && before + w > pc) { chunk_start[c] = t + 1; chunk_rank[c] = 0; } // ... lies in range)
+            } else {
+                chunk_start[c] = t;
+                chunk_rank[c] = k;
+            }
+        }
+        before += w;
     }
 }
 
@@ -271,7 +289,9 @@ struct FusedArgs {
     FusedScale sc[kMaxScales];
     int n_scales, n_views, L, W, tiles_w, n_tiles;
     float *out;                     // (L * W, 256)
-    const int *chunk_start;         // (kChunks + 1) tile_chunks_kernel
+    const int *chunk_start, *chunk_rank; // (kChunks + 1) each: tile_chunks_kernel
+    float *partial;                 // per workgroup 8 waves x 16 registers x 64 lanes: sums of a tile finished by another workgroup
+    unsigned *flags;                // per workgroup: partial sums published (zeroed by pool_rows_kernel before every launch)
     const float *rows;              // pooled rows of the direct items (pool_rows_kernel): slot x 32 boxes x 256 channels
     const unsigned *row_counter;    // direct items of the frame
     int rows_cap;                   // row slots in the workspace
@@ -323,7 +343,7 @@ __device__ __forceinline__ void store_quad(unsigned char *planes, int row, int c
     *reinterpret_cast<uint2 *>(planes + kPlane + off) = lo.u;
 }
 
-struct Item { int tile, scale, view; unsigned rest; bool valid; }; // rest: live views of (tile, scale) above `view`
+struct Item { int tile, scale, view; unsigned rest; bool valid; int rank; }; // rest: live views of (tile, scale) above `view`; rank: index among the tile's live items
 
 // DIRECT = false: every item whose tap window fits LDS (all but the tiles right in front of a camera); DIRECT = true: a second
 // launch for exactly the others -- taps read straight from the integral image, contribution ADDED to the map.
@@ -332,6 +352,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 {
     __shared__ float4 s_taps[kMaxSlots * 64];                       // 126 KiB: the tap window of the current item
     __shared__ __align__(16) unsigned char s_planes[2 * kPlane];    // 32 KiB: bf16 hi / lo planes of the 32 x 256 A tile
+    __shared__ uint4 s_hdr[2][16];                                  // tile headers of the next two items (32 B used of each 256)
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
 
     // Main launch: a contiguous range of tiles of equal COST for this workgroup (tile_chunks_kernel); neighbouring ranges
@@ -342,30 +363,44 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     const int lb = (int)xcd_contiguous(blockIdx.x, (nblk + 7) / 8);
     if (lb >= nblk) return;
     const int t_step = DIRECT ? nblk : 1;
-    const int t_begin = DIRECT ? lb : uniform_i(a.chunk_start[(int)((long long)kChunks * lb / nblk)]);
-    const int t_end = DIRECT ? a.n_tiles : uniform_i(a.chunk_start[(int)((long long)kChunks * (lb + 1) / nblk)]);
-    if (t_begin >= t_end) return;
+    // main launch: the items from the k_begin-th live item of tile t_begin up to (not including) the k_end-th of tile t_end
+    auto range_of = [&](int wg, int &tb, int &kb, int &te, int &ke) {
+        const int c0 = (int)((long long)kChunks * wg / nblk), c1 = (int)((long long)kChunks * (wg + 1) / nblk);
+        tb = uniform_i(a.chunk_start[c0]); kb = uniform_i(a.chunk_rank[c0]);
+        te = uniform_i(a.chunk_start[c1]); ke = uniform_i(a.chunk_rank[c1]);
+    };
+    int t_begin = lb, k_begin = 0, t_end = a.n_tiles, k_end = 0;
+    if (!DIRECT) range_of(lb, t_begin, k_begin, t_end, k_end);
+    if (t_begin > t_end || (t_begin == t_end && k_begin >= k_end)) return;
+    const int t_lim = (!DIRECT && k_end > 0) ? t_end + 1 : t_end; // tiles this workgroup looks at
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
 
-    auto live_all = [&](int tile, int scale) { return (unsigned)uniform_i((int)(a.sc[scale].live[tile] & view_mask)); };
-    // the views of (tile, scale) this launch works on
-    auto live_of = [&](int tile, int scale) {
-        const unsigned dm = a.sc[scale].overflow[tile] & view_mask;
-        return (unsigned)uniform_i((int)(DIRECT ? dm : (a.sc[scale].live[tile] & view_mask & ~dm)));
+    // view masks come by SCALAR loads (constant address space: the records kernel finished before this launch): a vector load
+    // here would queue behind the window DMA of the next item, which is in flight whenever the item sequence is advanced
+    auto mask_at = [&](const unsigned *p, int tile) {
+        return *reinterpret_cast<const __attribute__((address_space(4))) unsigned *>((size_t)(p + tile));
     };
-    // first live item at or after (tile, scale) with view bits `rest`
-    auto seek = [&](int tile, int scale, unsigned rest) {
+    auto live_all = [&](int tile, int scale) { return mask_at(a.sc[scale].live, tile) & view_mask; };
+    // the views of (tile, scale) this launch works on
+    // the views of (tile, scale) this launch works on (the ranks of the chunk cuts count exactly these)
+    auto live_of = [&](int tile, int scale) {
+        const unsigned dm = mask_at(a.sc[scale].overflow, tile) & view_mask;
+        return DIRECT ? dm : (mask_at(a.sc[scale].live, tile) & view_mask & ~dm);
+    };
+    // first item at or after (tile, scale) with view bits `rest`; `rank` = its index among the items of its tile
+    auto seek = [&](int tile, int scale, unsigned rest, int rank) {
         Item it;
-        it.valid = false; it.tile = tile; it.scale = scale; it.view = 0; it.rest = 0;
-        while (tile < t_end) {
+        it.valid = false; it.tile = tile; it.scale = scale; it.view = 0; it.rest = 0; it.rank = rank;
+        while (tile < t_lim) {
             if (rest) {
+                if (!DIRECT && tile == t_end && rank >= k_end) return it; // the next workgroup's part of the tile
                 it.view = __builtin_ctz(rest);
                 it.rest = rest & (rest - 1u);
-                it.tile = tile; it.scale = scale; it.valid = true;
+                it.tile = tile; it.scale = scale; it.rank = rank; it.valid = true;
                 return it;
             }
-            if (++scale == a.n_scales) { scale = 0; tile += t_step; }
-            if (tile < t_end) rest = live_of(tile, scale);
+            if (++scale == a.n_scales) { scale = 0; tile += t_step; rank = 0; }
+            if (tile < t_lim) rest = live_of(tile, scale);
         }
         return it;
     };
@@ -400,12 +435,24 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     };
 
     // LDS-DMA of the item's tap window: slot s = (window row, window column), 1 KiB per wave instruction
-    // tile headers travel in SGPRs: a scalar load issued one item ahead, waited for (lgkmcnt) where the header is used
-    auto header_of = [&](const Item &it, i32x8 &hd) {
-        const unsigned char *p = a.sc[it.scale].hdrs + ((size_t)it.view * a.n_tiles + it.tile) * kHdrBytes;
-        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(hd) : "s"(p));
+    // Tile headers end up in SGPRs, but travel by LDS-DMA like the tap window, two items ahead: one wave requests the 32 bytes
+    // (a 256-byte piece, the DMA granule) into one of two small LDS buffers; after the `vmcnt(0)` + barrier at the head of the
+    // loop every wave reads them back (a broadcast read) into scalar registers.  In flight the header costs no register at all.
+    // The two scalar forms both failed: an asm s_load is invisible to the register allocator, which spilled its destination
+    // registers before the data landed and restored garbage as soon as scalar pressure rose; a compiler-issued scalar load is
+    // waited for at the next lgkmcnt(0) -- scalar loads return out of order -- i.e. at once (+1 300 cycles per item).
+    auto header_of = [&](const Item &it, int buf) {
+        if (wave == 7) { // (the wave with the smallest share of the window DMA)
+            const unsigned char *p = a.sc[it.scale].hdrs + ((size_t)it.view * a.n_tiles + it.tile) * kHdrBytes + lane * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                             (__attribute__((address_space(3))) void *)(&s_hdr[buf][0]), 4, 0, 0);
+        }
     };
-    auto header_wait = [&](i32x8 &hd) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hd)); };
+    auto header_get = [&](i32x8 &hd, int buf) {
+        const uint4 h0 = s_hdr[buf][0], h1 = s_hdr[buf][1];
+        hd[0] = uniform_i((int)h0.x); hd[1] = uniform_i((int)h0.y); hd[2] = uniform_i((int)h0.z); hd[3] = uniform_i((int)h0.w);
+        hd[4] = uniform_i((int)h1.x); hd[5] = uniform_i((int)h1.y); hd[6] = uniform_i((int)h1.z); hd[7] = uniform_i((int)h1.w);
+    };
     // The window is brought in by LDS-DMA, 1 KiB (one slot) per wave instruction, slot s = (window row, window column).  The
     // instructions are issued ONE AT A TIME between groups of MFMAs: eight waves issuing their whole share at once queue up
     // behind the texture addresser for ~1000 cycles and enter the MFMA phase skewed by as much.
@@ -526,7 +573,18 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     const int frag_base = r * kRowBytes + ((h ^ (key & 1)) << 4);
 
     // tiles in front of the first live item are fully masked
-    Item cur = seek(t_begin, 0, live_of(t_begin, 0));
+    Item cur;
+    if (DIRECT || k_begin == 0) {
+        cur = seek(t_begin, 0, live_of(t_begin, 0), 0);
+    } else { // the first k_begin live items of the tile are the previous workgroup's
+        int sc0 = 0, left = k_begin;
+        unsigned rest0 = live_of(t_begin, 0);
+        while (left > 0 && (rest0 || sc0 + 1 < a.n_scales)) {
+            if (rest0) { rest0 &= rest0 - 1u; --left; }
+            else rest0 = live_of(t_begin, ++sc0);
+        }
+        cur = seek(t_begin, sc0, rest0, k_begin);
+    }
     {
         f32x16 none = {};
         if (!DIRECT)
@@ -543,16 +601,19 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         }
     };
     i32x8 nh;
-    header_of(cur, nh);
-    header_wait(nh);
+    int hbuf = 0; // LDS buffer holding the header of `nxt`
+    header_of(cur, 1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    header_get(nh, 1);
     int cur_flags = nh[0], cur_word1 = nh[2], nxt_flags = 0, nxt_word1 = 0; // header words 0, 2 of the item being pooled / the next
     load_record(cur, cur_flags, cur_word1);
     if (!(dbg & kDbgNoFills)) {
         begin_fills(cur, nh);
         rest_fills();
     }
-    Item nxt = seek(cur.tile, cur.scale, cur.rest);
-    if (nxt.valid) header_of(nxt, nh);
+    Item nxt = seek(cur.tile, cur.scale, cur.rest, cur.rank + 1);
+    if (nxt.valid) header_of(nxt, hbuf);
     int w_scale = -1;
     float bc = 0.0f;
     f32x16 sum;
@@ -562,7 +623,38 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     int pend_tile = -1, pend_next = 0;
     auto flush = [&]() {
         if (pend_tile < 0) return;
-        write_tile(pend_tile, sum, true);
+        if (!DIRECT) {
+            // A tile cut between two workgroups is stored by the one that holds its beginning.  The other one (always the next
+            // in line: it STARTS with that tile, so its part is ready early in its run) leaves its partial sums in the
+            // workspace and raises a flag; agent-scope accesses, the two may sit on different XCDs.  The waits form a chain
+            // towards higher workgroup indices, never a cycle, and every workgroup that does not wait runs to its end.
+            if (pend_tile == t_end) { // (only reached with k_end > 0): somebody continues this tile
+                int j = lb + 1;
+                for (;; ++j) { // the next workgroup with a non-empty range (empty ones exist only on tiny frames)
+                    int tb, kb, te, ke;
+                    range_of(j, tb, kb, te, ke);
+                    if (tb < te || (tb == te && kb < ke)) break;
+                }
+                while (__hip_atomic_load(a.flags + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
+                const float *pp = a.partial + ((size_t)j * 8 + wave) * 16 * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum[i] += __hip_atomic_load(pp + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (pend_tile == t_begin && k_begin > 0) { // the previous workgroup holds the beginning of this tile
+                float *pp = a.partial + ((size_t)lb * 8 + wave) * 16 * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) __hip_atomic_store(pp + i * 64, sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                __syncthreads();
+                int lb2 = lb;
+                asm volatile("" : "+s"(lb2)); // (keeps the flag's address out of the long-lived scalar registers)
+                if (tid == 0) __hip_atomic_store(a.flags + lb2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                write_tile(pend_tile, sum, true);
+            }
+        } else {
+            write_tile(pend_tile, sum, true);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
         if (!DIRECT)
@@ -576,10 +668,11 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     while (cur.valid) {
         Item nn;
         nn.valid = false;
-        if (nxt.valid) nn = seek(nxt.tile, nxt.scale, nxt.rest);
+        if (nxt.valid) nn = seek(nxt.tile, nxt.scale, nxt.rest, nxt.rank + 1);
         tick(0);
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's share of the tap window has landed
         __syncthreads();                    // ... and everybody else's
+        if (nxt.valid) header_get(nh, hbuf); // (the header of the next item landed with that wait)
         tick(1);
         flush();
         if (cur.scale != w_scale) { // W and bias of this scale: land while the boxes are pooled
@@ -593,12 +686,12 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         tick(3);
         f_n = 0;
         if (nxt.valid) {
-            header_wait(nh);
             nxt_flags = nh[0]; nxt_word1 = nh[2];
             if (!(dbg & kDbgNoFills)) begin_fills(nxt, nh); // issued between the MFMAs below
             load_record(nxt, nxt_flags, nxt_word1); // this lane's box of the next item: lands under the MFMAs
         }
-        if (nn.valid) header_of(nn, nh);
+        hbuf ^= 1;
+        if (nn.valid) header_of(nn, hbuf);
         tick(4);
 
         f32x16 acc;
@@ -920,12 +1013,14 @@ struct RowsArgs {
     const unsigned *direct[kMaxScales];
     int Hf[kMaxScales], Wf[kMaxScales];
     float *rows;
+    unsigned *flags; // hand-off flags of the persistent kernel (kMaxBlocks), cleared here: this launch precedes it every time
     int n_views, n_tiles;
 };
 __global__ __launch_bounds__(512) void pool_rows_kernel(RowsArgs a)
 {
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, grp = lane >> 4, cq = lane & 15;
     const int tile = blockIdx.x >> 2, q = blockIdx.x & 3, s = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < kMaxBlocks) a.flags[tid] = 0u;
     unsigned mask = (unsigned)uniform_i((int)a.direct[s][tile]);
     if (a.n_views < 32) mask &= (1u << a.n_views) - 1u;
     const int b = 4 * wave + grp;
@@ -973,7 +1068,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
     size_t live[kMaxScales], direct[kMaxScales], overflow[kMaxScales], counter, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales],
-        masks_bytes, chunks, diag, rows, total;
+        masks_bytes, chunks, ranks, diag, rows, partial, flags, total;
     int tiles_l, tiles_w, n_tiles, rows_cap;
 };
 inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
@@ -999,6 +1094,12 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     }
     w.chunks = off;
     off = align_up(off + (kChunks + 1) * sizeof(int), 256);
+    w.ranks = off;
+    off = align_up(off + (kChunks + 1) * sizeof(int), 256);
+    w.flags = off; // hand-off of tiles cut between two workgroups of the persistent kernel: a flag and 32 KiB of partial sums each
+    off = align_up(off + kMaxBlocks * sizeof(unsigned), 256);
+    w.partial = off;
+    off = align_up(off + (size_t)kMaxBlocks * 8 * 16 * 64 * sizeof(float), 256);
     w.diag = off;
     off = align_up(off + 512 * 8 * sizeof(unsigned long long), 256); // diagnostic build: 8 counters per workgroup
     // pooled rows of the direct items: room for a quarter of all (view, tile, scale) items, at most 256 MiB; the rest (none on the
@@ -1086,7 +1187,7 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
     int st = (int)hipGetLastError();
     if (st) return st;
     hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, s, a.live[0], a.live[n_scales > 1 ? 1 : 0], a.live[n_scales > 2 ? 2 : 0],
-                       n_scales, lay.n_tiles, n_views >= 32 ? 0xffffffffu : ((1u << n_views) - 1u), reinterpret_cast<int *>(ws + lay.chunks));
+                       a.overflow[0], a.overflow[n_scales > 1 ? 1 : 0], a.overflow[n_scales > 2 ? 2 : 0], n_scales, lay.n_tiles, n_views >= 32 ? 0xffffffffu : ((1u << n_views) - 1u), reinterpret_cast<int *>(ws + lay.chunks), reinterpret_cast<int *>(ws + lay.ranks));
     st = (int)hipGetLastError();
     if (st) return st;
     if (weights) {
@@ -1175,6 +1276,9 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     a.n_scales = n_scales; a.n_views = n_views; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles;
     a.out = out; a.accumulate = accumulate;
     a.chunk_start = reinterpret_cast<const int *>(ws + lay.chunks);
+    a.chunk_rank = reinterpret_cast<const int *>(ws + lay.ranks);
+    a.partial = reinterpret_cast<float *>(const_cast<unsigned char *>(ws) + lay.partial);
+    a.flags = reinterpret_cast<unsigned *>(const_cast<unsigned char *>(ws) + lay.flags);
     a.debug = debug;
     a.diag = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(ws) + lay.diag);
     int n_cu = 256;
@@ -1187,7 +1291,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     if (reserved_cus > 0 && n_cu - reserved_cus >= 8) n_cu -= reserved_cus;
     int nblk = lay.n_tiles < n_cu ? lay.n_tiles : n_cu;
     nblk = (nblk + 7) / 8 * 8; // xcd_contiguous deals whole eighths; surplus blocks find an empty range and leave
-    if (nblk > 512) nblk = 512;
+    if (nblk > kMaxBlocks) nblk = kMaxBlocks;
     a.rows = reinterpret_cast<const float *>(ws + lay.rows);
     a.row_counter = reinterpret_cast<const unsigned *>(ws + lay.counter);
     a.rows_cap = lay.rows_cap;
@@ -1199,6 +1303,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
         }
         ra.rows = reinterpret_cast<float *>(const_cast<unsigned char *>(ws) + lay.rows);
         ra.n_views = n_views; ra.n_tiles = lay.n_tiles;
+        ra.flags = a.flags;
         hipLaunchKernelGGL(pool_rows_kernel, dim3((unsigned)(lay.n_tiles * 4), n_scales), dim3(512), 0, s, ra);
         const int st0 = (int)hipGetLastError();
         if (st0) return st0;
