@@ -274,9 +274,10 @@ def roofline_fused(g, workload):
     per_launch = flops / g["launches"]
     achieved = 3 * per_launch / avg_s / 1e12
     traffic, src = committed_traffic(workload, "pool_collapse_kernel")
-    return {"bound": "mfma", "kernel": "vfa_pool_collapse_relu_sum_f32: pool_collapse_kernel<3> (+ its oversized-window "
-            "pass), one launch per frame: box pooling of 7 views x 3 scales -> bf16-split MFMA collapse -> bias + ReLU + "
-            "view/scale sum", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+    return {"bound": "mfma", "kernel": "vfa_pool_collapse_relu_sum_f32: pool_collapse_kernel<3, false, false> (persistent, one launch per "
+            "frame: box pooling of 7 views x 3 scales from LDS tap windows -> bf16-split MFMA collapse -> bias + ReLU + view/scale "
+            "sum) behind its pre-pass pool_rows_kernel (the 3 % of items whose window exceeds LDS); the HIP events bracket the "
+            "entry point, i.e. both kernels", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note(src),
             "avg_launch_us": avg_s * 1e6, "mfma_flops_per_launch": 3 * per_launch,
             "fp32_flops_per_launch": per_launch, "fp32_equivalent_tflops": per_launch / avg_s / 1e12,
