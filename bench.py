@@ -273,7 +273,7 @@ def roofline_fused(g, workload):
     avg_s = g["ms"] / g["launches"] * 1e-3
     per_launch = flops / g["launches"]
     achieved = 3 * per_launch / avg_s / 1e12
-    traffic, src = committed_traffic(workload, "pool_collapse_kernel")
+    traffic, src = committed_traffic(workload, "pool_collapse_kernel<3, false, false>")
     return {"bound": "mfma", "kernel": "vfa_pool_collapse_relu_sum_f32: pool_collapse_kernel<3, false, false> (persistent, one launch per "
             "frame: box pooling of 7 views x 3 scales from LDS tap windows -> bf16-split MFMA collapse -> bias + ReLU + view/scale "
             "sum) behind its pre-pass pool_rows_kernel (the 3 % of items whose window exceeds LDS); the HIP events bracket the "
