@@ -57,6 +57,7 @@ struct RecordArgs {
     unsigned *overflow[kMaxScales];  // (n_tiles) bit v = ... and there was no row slot left for it (subset of direct)
     unsigned *row_counter;           // direct items numbered so far (all scales)
     unsigned rows_cap;               // row slots in the workspace
+    unsigned *row_list;              // (rows_cap) slot -> scale << 30 | view << 25 | tile
     unsigned char *hdrs[kMaxScales]; // (n_views, n_tiles, 32 B)
     unsigned char *recs[kMaxScales]; // (n_views, n_tiles, 32 boxes, 96 B)
 };
@@ -182,7 +183,10 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
                 if (any_live && direct) {
                     atomicOr(a.direct[s] + tile, 1u << view);
                     const unsigned slot = atomicAdd(a.row_counter, 1u); // (the order is arbitrary: the slot only names scratch space)
-                    if (slot < a.rows_cap) { hflags |= kTileRows; word2 = slot; } // (a direct item has no use for the window width)
+                    if (slot < a.rows_cap) { // (a direct item has no use for the window width)
+                        hflags |= kTileRows; word2 = slot;
+                        a.row_list[slot] = ((unsigned)s << 30) | ((unsigned)view << 25) | (unsigned)tile;
+                    }
                     else atomicOr(a.overflow[s] + tile, 1u << view);
                 }
                 hdr[0] = make_uint4(hflags, (unsigned)n_slots, word2, (unsigned)inv);
@@ -1005,33 +1009,32 @@ __global__ __launch_bounds__(512) void pool_direct_kernel(PoolArgs a)
 // here, at full occupancy and with every tap load of a box in flight at once, into fp32 rows in the workspace.  Inside the
 // persistent kernel those loads had nothing to hide behind (W takes half of the register file: 8 taps per round trip,
 // ~53 000 cycles per item).  Same arithmetic as the persistent kernel's own pooling (v * RN(1 / area)).
-// grid = (n_tiles x 4 quarters, n_scales); one wave = 4 boxes x 64 channels.
+// A fixed grid walks the list of direct items the geometry pass appended to (a grid over all tiles spent its 27 us launching
+// 15 000 workgroups, 95 % of which had nothing to do); one wave = 4 boxes x 64 channels.
 // ------------------------------------------------------------------------------------------------
 struct RowsArgs {
     const float *integral[kMaxScales];
-    const unsigned char *hdrs[kMaxScales], *recs[kMaxScales];
-    const unsigned *direct[kMaxScales];
+    const unsigned char *recs[kMaxScales];
     int Hf[kMaxScales], Wf[kMaxScales];
+    const unsigned *row_list;    // slot -> scale << 30 | view << 25 | tile (frame_records_kernel)
+    const unsigned *row_counter; // direct items of the frame
     float *rows;
     unsigned *flags; // hand-off flags of the persistent kernel (kMaxBlocks), cleared here: this launch precedes it every time
-    int n_views, n_tiles;
+    int n_tiles, rows_cap;
 };
 __global__ __launch_bounds__(512) void pool_rows_kernel(RowsArgs a)
 {
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, grp = lane >> 4, cq = lane & 15;
-    const int tile = blockIdx.x >> 2, q = blockIdx.x & 3, s = blockIdx.y;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < kMaxBlocks) a.flags[tid] = 0u;
-    unsigned mask = (unsigned)uniform_i((int)a.direct[s][tile]);
-    if (a.n_views < 32) mask &= (1u << a.n_views) - 1u;
+    if (blockIdx.x == 0 && tid < kMaxBlocks) a.flags[tid] = 0u;
+    const int count = min(uniform_i((int)*a.row_counter), a.rows_cap);
     const int b = 4 * wave + grp;
-    const int Wp = a.Wf[s] + 2;
-    while (mask) {
-        const int view = __builtin_ctz(mask);
-        mask &= mask - 1u;
+    // unit = (direct item, 64-channel quarter); the items come from the list the geometry pass appended to
+    for (int u = blockIdx.x; u < 4 * count; u += gridDim.x) {
+        const int slot = u >> 2, q = u & 3;
+        const unsigned e = (unsigned)uniform_i((int)a.row_list[slot]);
+        const int s = (int)(e >> 30), view = (int)((e >> 25) & 31u), tile = (int)(e & 0x1ffffffu);
+        const int Wp = a.Wf[s] + 2;
         const int item = view * a.n_tiles + tile;
-        const unsigned *hd = reinterpret_cast<const unsigned *>(a.hdrs[s] + (size_t)item * kHdrBytes);
-        const int flags = uniform_i((int)hd[0]), slot = uniform_i((int)hd[2]);
-        if (!(flags & kTileRows)) continue; // no row slot left: the second launch of the persistent kernel takes it
         const uint4 *rp = reinterpret_cast<const uint4 *>(a.recs[s] + ((size_t)item * kTileBoxes + b) * kRecBytes);
         uint4 r[6];
 #pragma unroll
@@ -1068,7 +1071,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
     size_t live[kMaxScales], direct[kMaxScales], overflow[kMaxScales], counter, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales],
-        masks_bytes, chunks, ranks, diag, rows, partial, flags, total;
+        masks_bytes, chunks, ranks, diag, rows, row_list, partial, flags, total;
     int tiles_l, tiles_w, n_tiles, rows_cap;
 };
 inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
@@ -1109,6 +1112,8 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     if (cap > 8192) cap = 8192;
     if (cap > items) cap = items;
     w.rows_cap = (int)cap;
+    w.row_list = off;
+    off = align_up(off + cap * sizeof(unsigned), 256);
     w.rows = off;
     off = align_up(off + cap * kTileBoxes * kC * sizeof(float), 256);
     w.total = off;
@@ -1157,7 +1162,7 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
     if (n_views > 32) return VFA_ERR_UNSUPPORTED; // live-view masks are 32 bits wide
     const WorkspaceLayout lay = layout_of(n_views, L, W, n_scales);
     if (lay.n_tiles == 0 || n_views == 0) return 0;
-    if ((long long)n_views * lay.n_tiles >= (1ll << 31) - 2) return VFA_ERR_UNSUPPORTED;
+    if ((long long)n_views * lay.n_tiles >= (1ll << 31) - 2 || lay.n_tiles >= (1 << 25)) return VFA_ERR_UNSUPPORTED; // (row_list packs the tile in 25 bits)
     if (!workspace || workspace_bytes < lay.total) return VFA_ERR_BAD_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
@@ -1179,6 +1184,7 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
     {
         a.row_counter = reinterpret_cast<unsigned *>(ws + lay.counter);
         a.rows_cap = (unsigned)lay.rows_cap;
+        a.row_list = reinterpret_cast<unsigned *>(ws + lay.row_list);
         const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s);
         if (e != hipSuccess) return (int)e;
     }
@@ -1298,13 +1304,15 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     if (!(debug & 64)) { // pre-pass: pooled rows of the direct items (a block leaves at once where its tile has none)
         RowsArgs ra;
         for (int k = 0; k < kMaxScales; ++k) {
-            ra.integral[k] = a.sc[k].integral; ra.hdrs[k] = a.sc[k].hdrs; ra.recs[k] = a.sc[k].recs; ra.direct[k] = a.sc[k].direct;
+            ra.integral[k] = a.sc[k].integral; ra.recs[k] = a.sc[k].recs;
             ra.Hf[k] = a.sc[k].Hf; ra.Wf[k] = a.sc[k].Wf;
         }
+        ra.row_list = reinterpret_cast<const unsigned *>(ws + lay.row_list);
+        ra.row_counter = a.row_counter;
         ra.rows = reinterpret_cast<float *>(const_cast<unsigned char *>(ws) + lay.rows);
-        ra.n_views = n_views; ra.n_tiles = lay.n_tiles;
+        ra.n_tiles = lay.n_tiles; ra.rows_cap = lay.rows_cap;
         ra.flags = a.flags;
-        hipLaunchKernelGGL(pool_rows_kernel, dim3((unsigned)(lay.n_tiles * 4), n_scales), dim3(512), 0, s, ra);
+        hipLaunchKernelGGL(pool_rows_kernel, dim3(1024), dim3(512), 0, s, ra);
         const int st0 = (int)hipGetLastError();
         if (st0) return st0;
     }
