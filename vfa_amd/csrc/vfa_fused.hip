@@ -748,9 +748,12 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         if (nn.valid) header_of(nn, hbuf);
         tick(4);
 
-        f32x16 acc;
+        // two accumulator chains (even / odd k-steps): a dependent 32x32x16 MFMA issues only ~84 cycles after its predecessor,
+        // so one chain per wave leaves the matrix pipe a quarter idle even with two waves per SIMD; the second chain costs 16
+        // VGPRs that are free in this phase (the pooling temporaries are dead)
+        f32x16 acc, acc2;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int i = 0; i < 16; ++i) { acc[i] = 0.0f; acc2[i] = 0.0f; }
         if (!(dbg & kDbgNoMfma)) {
             int key2 = key, fb = frag_base; // (opaque: keeps the 16 swizzled fragment offsets out of long-lived registers)
             asm volatile("" : "+v"(key2), "+v"(fb));
@@ -765,20 +768,20 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                 const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off1);
                 // the four hi products first: they cover the latency of the lo reads
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].lo, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].lo, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].lo, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].hi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].hi, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].hi, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, w[2 * c].hi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].hi, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].hi, acc2, 0, 0, 0);
                 if (TERMS >= 4) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, w[2 * c].lo, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].lo, acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].lo, acc2, 0, 0, 0);
                 }
             }
         }
         rest_fills(); // windows of more than 64 slots
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[i] + bc); // vfa_op.py:124; vfanet.py:79, 82
+        for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t((acc[i] + acc2[i]) + bc); // vfa_op.py:124; vfanet.py:79, 82
         tick(5);
 
         if (!nxt.valid || nxt.tile != cur.tile) {
