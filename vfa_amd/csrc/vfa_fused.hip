@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         // VGPRs that are free in this phase (the pooling temporaries are dead)
         f32x16 acc, acc2;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[i] = 0.0f; acc2[i] = 0.0f; }
+        for (int i = 0; i < 16; ++i) { acc[i] = bc; acc2[i] = 0.0f; } // (the bias rides in the first chain)
         if (!(dbg & kDbgNoMfma)) {
             int key2 = key, fb = frag_base; // (opaque: keeps the 16 swizzled fragment offsets out of long-lived registers)
             asm volatile("" : "+v"(key2), "+v"(fb));
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         }
         rest_fills(); // windows of more than 64 slots
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t((acc[i] + acc2[i]) + bc); // vfa_op.py:124; vfanet.py:79, 82
+        for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[i] + acc2[i]); // vfa_op.py:124; vfanet.py:79, 82
         tick(5);
 
         if (!nxt.valid || nxt.tile != cur.tile) {
