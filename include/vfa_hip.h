@@ -217,6 +217,10 @@ int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, voi
  *   integrals / biases = HOST arrays of n_scales device pointers ((n_views, Hf+2, Wf+2, 256) each / (256) or NULL);
  *   workspace = what vfa_frame_records_f32 filled for the same (n_views, L, W, n_scales, feat_hw). */
 size_t vfa_frame_workspace_bytes(int n_views, int L, int W, int n_scales);
+/* (That is the recommended size.  The last region holds the pooled rows of the direct items -- tiles whose tap window exceeds LDS
+ * -- 32 KiB per slot; any size from offsets[21] of vfa_frame_workspace_layout upwards is accepted by the three entry points
+ * below, which derive the number of row slots from the size they are given: pass the SAME size to all of them.  Direct items
+ * without a slot take a slower second launch.) */
 /* Where things are inside that workspace (tests and tools/ read the records back): offsets[23]: offsets[5 k + {0..4}] = live-view
  * masks, direct-item masks, tile headers (32 B), box records (96 B), split weight of scale k; offsets[15] diagnostics, offsets[16]
  * total bytes; offsets[17 + k] = masks of the direct items without a row slot, offsets[20] the direct-item counter,

@@ -373,3 +373,41 @@ def test_batched_integral_images_are_bitwise_the_per_map_ones(shapes, n, C):
     for f, sc, sh, g in zip(feats, scales, shifts, got):
         want = ops.affine_relu_integral_image(f, sc, sh)
         assert torch.equal(g.view(torch.int32), want.view(torch.int32)), tuple(f.shape)
+
+
+@pytest.mark.parametrize("row_slots", [0, 5])
+def test_direct_items_without_a_row_slot_take_the_second_launch(row_slots):
+    """The workspace may be smaller than recommended: direct items (tap window larger than LDS) that find no pooled-row slot are
+    left to the second launch of the persistent kernel.  A camera inside the field (many direct items), with all / some / none of
+    them in row slots: the same map within the path's tolerance, and the scene really has direct items."""
+    import vfa_amd
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import look_at_camera
+    from vfa_amd.utils import make_grid
+    dev = _dev()
+    image_size = (720, 1280)
+    calibs = torch.tensor(np.stack([look_at_camera((1500.0, 1700.0, 250.0), (2600.0, 2300.0, 0.0), 700.0, (1280, 720)),
+                                    look_at_camera((300.0, 300.0, 200.0), (1800.0, 1900.0, 0.0), 500.0, (1280, 720))]),
+                          dtype=torch.float32).to(dev)
+    grid = make_grid(world_size=(3750, 3750), cube_LW=[150.0, 150.0], dataset="MultiviewC").to(dev)
+    L, W = grid.shape[:2]
+    args = SimpleNamespace(data="MultiviewC", image_size=image_size)
+    gen = torch.Generator().manual_seed(11)
+    lats = [torch.relu(torch.randn(2, 256, h, w, generator=gen)).to(dev) for h, w in ((90, 160), (45, 80), (23, 40))]
+    torch.manual_seed(5)
+    mods = [vfa_amd.VFA(256, grid_height=300, cube_size=(150.0, 150.0, 300), args=args).to(dev) for _ in range(3)]
+    zl, co = mods[0]._kernel_geometry(dev)
+    integrals = ops.integral_images(lats)
+    outs = {}
+    for slots in (None, row_slots):
+        ws = ops.frame_records(calibs, grid, zl, co, _lib.CONV_KIND["MultiviewC"], image_size[::-1], [tuple(l.shape[-2:]) for l in lats],
+                               weights=[m.layer_major_weight() for m in mods], row_slots=slots)
+        with torch.no_grad():
+            outs[slots] = ops.pool_collapse(integrals, [m.collapse.bias for m in mods], ws, (L, W))
+        torch.cuda.synchronize()
+        lay = ops.frame_workspace_layout(2, L, W, 3)
+        n_direct = int(ws[lay["counter"]:lay["counter"] + 4].cpu().numpy().view(np.uint32)[0])
+        assert n_direct > 5, "the scene should have direct items"
+        assert ws.numel() == (lay["total"] if slots is None else lay["rows"] + slots * 32 * 1024)
+    scale = outs[None].abs().max().item()
+    torch.testing.assert_close(outs[row_slots], outs[None], rtol=RTOL, atol=2 * ATOL_REL * scale)

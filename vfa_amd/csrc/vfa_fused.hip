@@ -1173,6 +1173,15 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     return w;
 }
 
+// row slots that fit a workspace of `bytes` (the rows are the last region; fewer slots only send more direct items to the
+// second launch of the persistent kernel)
+inline int rows_cap_of(const WorkspaceLayout &lay, size_t bytes)
+{
+    if (bytes <= lay.rows) return 0;
+    const size_t fit = (bytes - lay.rows) / ((size_t)kTileBoxes * kC * sizeof(float));
+    return fit < (size_t)lay.rows_cap ? (int)fit : lay.rows_cap;
+}
+
 } // namespace
 
 extern "C" {
@@ -1216,7 +1225,7 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
     const WorkspaceLayout lay = layout_of(n_views, L, W, n_scales);
     if (lay.n_tiles == 0 || n_views == 0) return 0;
     if ((long long)n_views * lay.n_tiles >= (1ll << 31) - 2 || lay.n_tiles >= (1 << 25)) return VFA_ERR_UNSUPPORTED; // (row_list packs the tile in 25 bits)
-    if (!workspace || workspace_bytes < lay.total) return VFA_ERR_BAD_ARGUMENT;
+    if (!workspace || workspace_bytes < lay.rows) return VFA_ERR_BAD_ARGUMENT; // (everything in front of the row slots is mandatory)
     hipStream_t s = (hipStream_t)stream;
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
     RecordArgs a;
@@ -1236,7 +1245,7 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
     // record behind each scale's table), the chunk boundaries, one weight-split launch
     {
         a.row_counter = reinterpret_cast<unsigned *>(ws + lay.counter);
-        a.rows_cap = (unsigned)lay.rows_cap;
+        a.rows_cap = (unsigned)rows_cap_of(lay, workspace_bytes);
         a.row_list = reinterpret_cast<unsigned *>(ws + lay.row_list);
         const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s);
         if (e != hipSuccess) return (int)e;
@@ -1271,7 +1280,7 @@ int vfa_pool_windows_f32(const float *integral, const void *workspace, size_t wo
     if (n_views > 32) return VFA_ERR_UNSUPPORTED;
     const WorkspaceLayout lay = layout_of(n_views, L, W, n_scales);
     if (lay.n_tiles == 0 || n_views == 0) return 0;
-    if (!workspace || workspace_bytes < lay.total || !integral || !vox) return VFA_ERR_BAD_ARGUMENT;
+    if (!workspace || workspace_bytes < lay.rows || !integral || !vox) return VFA_ERR_BAD_ARGUMENT;
     const unsigned char *ws = reinterpret_cast<const unsigned char *>(workspace);
     PoolArgs a;
     a.integral = integral; a.hdrs = ws + lay.hdrs[scale]; a.recs = ws + lay.recs[scale]; a.vox = vox;
@@ -1315,8 +1324,9 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
         if (!accumulate) return (int)hipMemsetAsync(out, 0, (size_t)L * W * kC * sizeof(float), s);
         return 0;
     }
-    if (!workspace || workspace_bytes < lay.total) return VFA_ERR_BAD_ARGUMENT;
+    if (!workspace || workspace_bytes < lay.rows) return VFA_ERR_BAD_ARGUMENT;
     const unsigned char *ws = reinterpret_cast<const unsigned char *>(workspace);
+    const int rows_cap = rows_cap_of(lay, workspace_bytes); // (the same figure the records call derived from the same size)
     FusedArgs a;
     for (int k = 0; k < kMaxScales; ++k) {
         const int q = k < n_scales ? k : 0;
@@ -1353,7 +1363,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     if (nblk > kMaxBlocks) nblk = kMaxBlocks;
     a.rows = reinterpret_cast<const float *>(ws + lay.rows);
     a.row_counter = reinterpret_cast<const unsigned *>(ws + lay.counter);
-    a.rows_cap = lay.rows_cap;
+    a.rows_cap = rows_cap;
     if (!(debug & 64)) { // pre-pass: pooled rows of the direct items (a block leaves at once where its tile has none)
         RowsArgs ra;
         for (int k = 0; k < kMaxScales; ++k) {
@@ -1363,7 +1373,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
         ra.row_list = reinterpret_cast<const unsigned *>(ws + lay.row_list);
         ra.row_counter = a.row_counter;
         ra.rows = reinterpret_cast<float *>(const_cast<unsigned char *>(ws) + lay.rows);
-        ra.n_tiles = lay.n_tiles; ra.rows_cap = lay.rows_cap;
+        ra.n_tiles = lay.n_tiles; ra.rows_cap = rows_cap;
         ra.flags = a.flags;
         hipLaunchKernelGGL(pool_rows_kernel, dim3(1024), dim3(512), 0, s, ra);
         const int st0 = (int)hipGetLastError();

@@ -346,7 +346,7 @@ def collapse_gemm(vox2d, weight, out=None, terms=0, reserved_cus=0):
 
 
 def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_hws, weights=None, crange=(-1, 0.95),
-                  workspace=None):
+                  workspace=None, row_slots=None):
     """Geometry of one frame for the fused inference kernel (``pool_collapse``): box records of every (view, cell) for each
     feature scale + the split collapse weights -> workspace tensor (reference vfa_op.py:64-106, set-up of :112-115).
 
@@ -361,6 +361,10 @@ def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_
         raise _lib.VFAHipError("frame_records / pool_collapse cover single-layer grids (nl = 1) only")
     ns = len(feat_hws)
     need = _lib.lib().vfa_frame_workspace_bytes(n, L, W, ns)
+    if row_slots is not None:  # a smaller workspace: fewer pooled-row slots for direct items (the rest takes the second launch)
+        lay = frame_workspace_layout(n, L, W, ns)
+        need = lay["rows"] + min(int(row_slots), lay["rows_cap"]) * 32 * 256 * 4
+        workspace = None
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=calibs.device)
     hw = _lib.int_array([v for f in feat_hws for v in f])
