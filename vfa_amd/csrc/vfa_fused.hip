@@ -835,11 +835,13 @@ __global__ __launch_bounds__(512, 2) void pool_windows_kernel(PoolArgs a)
     const int Wp = a.Wf + 2;
     const size_t img_stride = (size_t)(a.Hf + 2) * Wp * kSlotBytes;
 
+    // (a compiler-issued scalar load: an asm s_load is invisible to the register allocator, which may spill the destination
+    // registers before the data lands -- see the persistent kernel above)
     auto header_of = [&](long long u, i32x8 &hd) {
         const unsigned char *p = a.hdrs + (size_t)(u >> 2) * kHdrBytes;
-        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(hd) : "s"(p));
+        hd = *reinterpret_cast<const __attribute__((address_space(4))) i32x8 *>((size_t)p);
     };
-    auto header_wait = [&](i32x8 &hd) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(hd)); };
+    auto header_wait = [&](i32x8 &) {};
     // position of a unit, advanced by counting (the CU has ONE scalar unit: divisions per unit and wave made the kernel
     // scalar-bound)
     struct Pos { int item, q, view, tl, tw; };
