@@ -964,22 +964,23 @@ struct ScalarWeights { f32x16 w; f32x4 t; };  // BoxRec::w: 16 tap weights | are
 struct ScalarHeader { i32x8 a; i32x4 b; };    // BoxRec::h: flags, view, run_len, masked, col[4] | row[4]
 static_assert(offsetof(BoxRec, w) == 48 && sizeof(BoxHdr) == 48 && sizeof(BoxWeights) == 80, "record layout");
 
+// (Compiler-issued scalar loads through the constant address space.  The first form, `s_load` in inline asm with the wait a
+// step later, is invisible to the register allocator: with scalar registers spilled in between it would save the destination
+// before the data lands and restore garbage -- which is what happened to the fused kernel of round 2.)
 __device__ __forceinline__ void sload_weights(ScalarWeights &o, const BoxRec *p)
 {
-    asm volatile("s_load_dwordx16 %0, %2, 0x30\n\ts_load_dwordx4 %1, %2, 0x70" : "=&s"(o.w), "=&s"(o.t) : "s"(p));
+    const char *b = reinterpret_cast<const char *>(p);
+    o.w = *reinterpret_cast<const __attribute__((address_space(4))) f32x16 *>((size_t)(b + 0x30));
+    o.t = *reinterpret_cast<const __attribute__((address_space(4))) f32x4 *>((size_t)(b + 0x70));
 }
-__device__ __forceinline__ void swait_weights(ScalarWeights &o)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(o.w), "+s"(o.t));
-}
+__device__ __forceinline__ void swait_weights(ScalarWeights &) {}
 __device__ __forceinline__ void sload_header(ScalarHeader &o, const BoxRec *p)
 {
-    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=&s"(o.a), "=&s"(o.b) : "s"(p));
+    const char *b = reinterpret_cast<const char *>(p);
+    o.a = *reinterpret_cast<const __attribute__((address_space(4))) i32x8 *>((size_t)b);
+    o.b = *reinterpret_cast<const __attribute__((address_space(4))) i32x4 *>((size_t)(b + 0x20));
 }
-__device__ __forceinline__ void swait_header(ScalarHeader &o)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(o.a), "+s"(o.b));
-}
+__device__ __forceinline__ void swait_header(ScalarHeader &) {}
 __device__ __forceinline__ BoxWeights unpack(const ScalarWeights &s)
 {
     BoxWeights w;
