@@ -23,6 +23,7 @@ measured the same way with fewer steps -- the configuration on which >= 6x at 8 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -213,13 +214,20 @@ class Leg:
         self.drain()
         self.fence()
         ctx = timer if timer is not None else _Null()
-        with ctx:
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                self.step()
-            self.drain()
-            self.fence()
-            dt = time.perf_counter() - t0
+        # (no cyclic-GC pause inside the timed region: a generation-2 collection stalls the launching thread for 30-60 ms,
+        # longer than the work queued ahead of it -- seen as a 2 x outlier of a 100-step leg about once in six runs)
+        gc.collect()
+        gc.disable()
+        try:
+            with ctx:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    self.step()
+                self.drain()
+                self.fence()
+                dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if self.world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
