@@ -221,11 +221,12 @@ size_t vfa_frame_workspace_bytes(int n_views, int L, int W, int n_scales);
  * -- 32 KiB per slot; any size from offsets[21] of vfa_frame_workspace_layout upwards is accepted by the three entry points
  * below, which derive the number of row slots from the size they are given: pass the SAME size to all of them.  Direct items
  * without a slot take a slower second launch.) */
-/* Where things are inside that workspace (tests and tools/ read the records back): offsets[23]: offsets[5 k + {0..4}] = live-view
+/* Where things are inside that workspace (tests and tools/ read the records back): offsets[25]: offsets[5 k + {0..4}] = live-view
  * masks, direct-item masks, tile headers (32 B), box records (96 B), split weight of scale k; offsets[15] diagnostics, offsets[16]
  * total bytes; offsets[17 + k] = masks of the direct items without a row slot, offsets[20] the direct-item counter,
- * offsets[21] the pooled rows of the direct items (slot x 32 boxes x 256 fp32), offsets[22] = the number of row slots;
- * tiles = {tile rows, tile columns, tap-window capacity in slots}.  Tiles are 4 x 8 cells. */
+ * offsets[21] the pooled rows of the direct items (slot x 32 boxes x 256 fp32), offsets[22] = the number of row slots,
+ * offsets[23] / [24] the work cuts (tile, rank of the first item inside it), tiles[3] + 1 of them;
+ * tiles[4] = {tile rows, tile columns, tap-window capacity in slots, number of work pieces}.  Tiles are 4 x 8 cells. */
 int vfa_frame_workspace_layout(int n_views, int L, int W, int n_scales, size_t *offsets, int *tiles);
 int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
                           int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,

@@ -411,3 +411,44 @@ def test_direct_items_without_a_row_slot_take_the_second_launch(row_slots):
         assert ws.numel() == (lay["total"] if slots is None else lay["rows"] + slots * 32 * 1024)
     scale = outs[None].abs().max().item()
     torch.testing.assert_close(outs[row_slots], outs[None], rtol=RTOL, atol=2 * ATOL_REL * scale)
+
+
+@pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 7, None), ("multiviewc_200x200x1", 2, (21, 40)), ("multiviewc_200x200x1", 1, (3, 5))])
+def test_work_cuts_cover_every_item_once(name, n_cam, crop):
+    """`tile_chunks_kernel`: the n_chunks + 1 cuts (tile, rank) of the item sequence are monotonic, start at (0, 0), end at (n_tiles, 0),
+    never point behind the last item of a tile, and the pieces between them carry equal numbers of items (+- one tile's
+    granule is NOT allowed any more: cuts fall inside tiles)."""
+    import vfa_amd
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload(name, channels=256, seed=0, n_cam=n_cam)
+    grid = wl["grid"] if crop is None else wl["grid"][:, 40:40 + crop[0], 30:30 + crop[1]].contiguous()
+    L, W = grid.shape[1:3]
+    mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+    zl, co = mod._kernel_geometry(dev)
+    sizes = [tuple(s) for s in wl["feat_sizes"]]
+    ws = ops.frame_records(wl["calibs"].to(dev), grid.to(dev), zl, co, _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1], sizes)
+    host = ws.cpu().numpy()
+    lay = ops.frame_workspace_layout(n_cam, L, W, 3)
+    nt = lay["tiles_l"] * lay["tiles_w"]
+    items = np.zeros(nt, np.int64)
+    for s in range(3):
+        live = host[lay["live"][s]:lay["live"][s] + nt * 4].view(np.uint32)
+        ovf = host[lay["overflow"][s]:lay["overflow"][s] + nt * 4].view(np.uint32)
+        items += np.array([bin(int(a) & ~int(b)).count("1") for a, b in zip(live, ovf)])
+    K = lay["n_chunks"]
+    cs = host[lay["chunks"]:lay["chunks"] + (K + 1) * 4].view(np.int32).astype(np.int64)
+    cr = host[lay["ranks"]:lay["ranks"] + (K + 1) * 4].view(np.int32).astype(np.int64)
+    assert (cs[0], cr[0]) == (0, 0) and (cs[-1], cr[-1]) == (nt, 0)
+    pos = cs * 4096 + cr
+    assert (np.diff(pos) >= 0).all(), "cuts must be monotonic"
+    inside = cs < nt
+    assert (cr[inside] <= np.maximum(items[cs[inside]] - 1, 0)).all(), "a cut may not point behind the last item of its tile"
+    before = np.concatenate([[0], np.cumsum(items)])
+    upto = before[np.minimum(cs, nt)] + cr          # items in front of each cut
+    assert upto[-1] == items.sum()
+    for wgs in (256, 248, 240, 8):                  # pieces of a launch with that many workgroups (240: 16 CUs left to RCCL)
+        cut = upto[(np.arange(wgs + 1) * K) // wgs]
+        per = np.diff(cut)
+        assert per.sum() == items.sum() and per.max() - per.min() <= max(3, int(0.03 * per.mean()) + 3), (per.min(), per.max())

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void split_weight_frag_kernel(SplitArgs sa)
 // workgroup 19 % above the mean on the bench frame (4.9 tiles of ~18 items per workgroup).  A tile cut this way is finished by
 // the workgroup that holds its beginning, which gets the partial sums of the other one through the workspace (see `flush`).
 // One workgroup, an LDS scan over per-thread sums.
-constexpr int kChunks = 1024;
+constexpr int kChunks = 8192; // (fine enough that a launch with any number of workgroups gets pieces within 3 % of each other)
 constexpr int kMaxBlocks = 512; // workgroups of the persistent kernel
 __global__ __launch_bounds__(1024) void tile_chunks_kernel(const unsigned *live0, const unsigned *live1, const unsigned *live2,
                                                            const unsigned *ovf0, const unsigned *ovf1, const unsigned *ovf2,
@@ -1211,9 +1211,12 @@ int vfa_frame_workspace_layout(int n_views, int L, int W, int n_scales, size_t *
     offsets[20] = lay.counter;
     offsets[21] = lay.rows;
     offsets[22] = (size_t)lay.rows_cap;
+    offsets[23] = lay.chunks;
+    offsets[24] = lay.ranks;
     tiles[0] = lay.tiles_l;
     tiles[1] = lay.tiles_w;
     tiles[2] = kMaxSlots;
+    tiles[3] = kChunks;
     return 0;
 }
 

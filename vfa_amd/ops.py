@@ -421,12 +421,13 @@ def frame_workspace_layout(n_views, L, W, n_scales):
     ``hdrs``, ``recs``, ``wfrag``, ``overflow`` and ``diag``, ``total``, ``counter``, ``rows``, ``rows_cap``, ``tiles_l``,
     ``tiles_w``, ``max_slots``."""
     import ctypes
-    off = (ctypes.c_size_t * 23)()
-    tiles = (ctypes.c_int * 3)()
+    off = (ctypes.c_size_t * 25)()
+    tiles = (ctypes.c_int * 4)()
     _lib.call("vfa_frame_workspace_layout", int(n_views), int(L), int(W), int(n_scales), off, tiles)
     names = ("live", "direct", "hdrs", "recs", "wfrag")
     out = {nm: [int(off[5 * k + i]) for k in range(n_scales)] for i, nm in enumerate(names)}
     out["overflow"] = [int(off[17 + k]) for k in range(n_scales)]
     out.update(diag=int(off[15]), total=int(off[16]), counter=int(off[20]), rows=int(off[21]), rows_cap=int(off[22]),
-               tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]))
+               chunks=int(off[23]), ranks=int(off[24]),
+               tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]))
     return out
