@@ -2,9 +2,12 @@
 
 ``sort_vertices``: a sequential numpy / Python restatement of the reference's CUDA kernel
 (``/root/reference/vfa/evaluation/pyeval/cuda_op/sort_vert_kernel.cu:15-134``), polygon by polygon, with the kernel's operand
-types (float32 products, double constants).  PARITY UNPINNED: the reference kernel is CUDA-only and its extension cannot be built
-in this image (it needs nvcc and ATen's CUDA headers), and the reference ships no test vectors for it; the restatement was read
-against the source line by line and the tests compare the HIP kernel with it on generated rectangle-intersection polygons.
+types (float32 products, double constants).  The reference kernel is CUDA-only and its extension cannot be built in this image
+(it needs nvcc and ATen's CUDA headers), and the reference ships no test vectors for it, so the restatement is PINNED AT THE
+KERNEL'S CALL SITE instead: tests/golden/make_golden.py --iou runs the reference's rotated-box IoU (IoU.py:139-221, its own
+torch code on CPU) with this function standing in for the extension, and every overlap area equals an independent float64
+polygon clipper's (tests/golden/iou_pairs.npz, tests/test_eval_ops.py).  Bit-level agreement with the CUDA binary on inputs that
+pipeline never produces (random vertex clouds) remains unpinned.
 
 ``bev_nms``: numpy restatement of ``ObjectEncoder.nms(torch.sigmoid(h))`` (``vfa/data/encoder.py:230-232``), pinned by the decode
 fixtures generated from the reference (tests/golden/decode_*.npz).

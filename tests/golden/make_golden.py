@@ -260,12 +260,112 @@ def main_decode():
         print(f"{fname}: {len(out['conf'])} detections above 0.4, nms peaks {int((nms > 0).sum())}")
 
 
+def _clip_area(c1, c2):
+    """Independent truth for the overlap of two convex quadrilaterals: Sutherland-Hodgman clipping + shoelace in float64.
+    Shares nothing with the reference's candidate-vertex / angular-sort scheme."""
+    def ccw(poly):
+        a = sum(poly[i][0] * poly[(i + 1) % len(poly)][1] - poly[i][1] * poly[(i + 1) % len(poly)][0] for i in range(len(poly)))
+        return poly if a > 0 else poly[::-1]
+    subject, clip = ccw([tuple(map(float, p)) for p in c1]), ccw([tuple(map(float, p)) for p in c2])
+    for i in range(len(clip)):
+        a, b = clip[i], clip[(i + 1) % len(clip)]
+        side = lambda p: (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])
+        out = []
+        for j in range(len(subject)):
+            p, q = subject[j], subject[(j + 1) % len(subject)]
+            sp, sq = side(p), side(q)
+            if sp >= 0:
+                out.append(p)
+            if (sp > 0 and sq < 0) or (sp < 0 and sq > 0):
+                t = sp / (sp - sq)
+                out.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+        subject = out
+        if not subject:
+            return 0.0
+    return abs(sum(subject[i][0] * subject[(i + 1) % len(subject)][1] - subject[i][1] * subject[(i + 1) % len(subject)][0]
+                   for i in range(len(subject)))) / 2
+
+
+def main_iou():
+    """Pins the ``sort_vertices`` restatement through the reference's only call site of the kernel, the rotated-box IoU
+    (vfa/evaluation/pyeval/IoU.py:139-198).  The reference's CUDA extension module ``sort_vertices`` cannot be built here
+    (nvcc), so it is the ONE piece stood in for -- by oracle/eval_oracle.sort_vertices, the thing under test; every other step
+    (boxes2corners, boxes_intersection, box1_in_box2, build_vertices, the mean normalisation, calculate_area, IoUs2D) is the
+    reference's own torch code, run on CPU.  If the restatement ordered the vertices differently from what the reference's
+    pipeline needs, the shoelace area it feeds would not be the overlap: the script checks every case against an independent
+    float64 polygon clipper and stores vertices, masks, the index lists and both areas."""
+    from oracle import eval_oracle
+    captured = []
+    stub = types.ModuleType("sort_vertices")
+
+    def sort_vertices_forward(vertices, mask, num_valid):
+        idx = eval_oracle.sort_vertices(vertices.numpy(), mask.numpy(), num_valid.numpy())
+        captured.append((vertices.numpy().copy(), mask.numpy().copy(), num_valid.numpy().copy(), idx.copy()))
+        return torch.from_numpy(idx)
+    stub.sort_vertices_forward = sort_vertices_forward
+    sys.modules["sort_vertices"] = stub
+    from vfa.evaluation.pyeval import IoU as ref_iou
+
+    rng = np.random.default_rng(61)
+    pairs, kinds = [], []
+
+    def add(kind, b1, b2):
+        pairs.append((np.asarray(b1, np.float32), np.asarray(b2, np.float32)))
+        kinds.append(kind)
+    for _ in range(192):      # generic rotated pairs, most of them overlapping
+        b1 = [rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.5, 3), rng.uniform(0.5, 3), rng.uniform(-np.pi, np.pi)]
+        b2 = [rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.5, 3), rng.uniform(0.5, 3), rng.uniform(-np.pi, np.pi)]
+        add("random", b1, b2)
+    for _ in range(16):       # identical boxes: 8 valid corners, the kernel's duplicate rule (sort_vert_kernel.cu:110-129)
+        b = [rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.5, 3), rng.uniform(0.5, 3), rng.uniform(0.1, 1.4)]
+        add("identical", b, b)
+    for _ in range(16):       # one box strictly inside the other: 4 valid corners, no intersections
+        b = [rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(2, 3), rng.uniform(2, 3), rng.uniform(0.1, 1.4)]
+        add("contained", b, [b[0] + 0.1, b[1] - 0.1, 0.6, 0.5, rng.uniform(-np.pi, np.pi)])
+    for _ in range(16):       # far apart: no valid vertex at all (num_valid = 0, everything padding)
+        b = [rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.5, 1), rng.uniform(0.5, 1), rng.uniform(-np.pi, np.pi)]
+        add("disjoint", b, [b[0] + 5, b[1] + 5, 1, 1, rng.uniform(-np.pi, np.pi)])
+    for _ in range(16):       # MultiviewC-sized cows in centimetres (the evaluation's real magnitudes)
+        b1 = [rng.uniform(500, 3400), rng.uniform(500, 3400), rng.uniform(180, 260), rng.uniform(60, 110), rng.uniform(-np.pi, np.pi)]
+        b2 = [b1[0] + rng.uniform(-60, 60), b1[1] + rng.uniform(-60, 60), rng.uniform(180, 260), rng.uniform(60, 110),
+              b1[4] + rng.uniform(-0.5, 0.5)]
+        add("cows_cm", b1, b2)
+
+    rows = []
+    for kind, (b1, b2) in zip(kinds, pairs):
+        t1, t2 = torch.from_numpy(b1).view(1, 1, 5), torch.from_numpy(b2).view(1, 1, 5)
+        with np.errstate(all="ignore"):
+            iou, c1, c2, union = ref_iou.IoUs2D(t1, t2)
+        verts, mask, nv, idx = captured[-1]
+        # the un-normalised vertices calculate_area reads (IoU.py:189-191)
+        inters, mi = ref_iou.boxes_intersection(c1, c2)
+        raw, _ = ref_iou.build_vertices(c1, c2, inters, ref_iou.box1_in_box2(c1, c2), ref_iou.box1_in_box2(c2, c1), mi)
+        overlap = float(b1[2] * b1[3] + b2[2] * b2[3] - float(union))
+        truth = _clip_area(c1[0, 0].numpy().astype(np.float64), c2[0, 0].numpy().astype(np.float64))
+        rows.append((kind, b1, b2, verts[0, 0], mask[0, 0], int(nv[0, 0]), idx[0, 0], raw[0, 0].numpy(), overlap, truth, float(iou)))
+    scale = np.array([max(r[1][2] * r[1][3], r[2][2] * r[2][3]) for r in rows])
+    err = np.abs(np.array([r[8] for r in rows]) - np.array([r[9] for r in rows])) / scale
+    for kind in sorted(set(kinds)):
+        sel = np.array([k == kind for k in kinds])
+        print(f"iou_pairs {kind:10s}: {sel.sum():3d} pairs, max |overlap - clipped| / box area = {err[sel].max():.2e}, "
+              f"vertex counts {sorted(set(r[5] for r, s in zip(rows, sel) if s))}")
+    np.savez_compressed(os.path.join(HERE, "iou_pairs.npz"), kind=np.array(kinds), box1=np.stack([r[1] for r in rows]),
+                        box2=np.stack([r[2] for r in rows]), vertices=np.stack([r[3] for r in rows]),
+                        mask=np.stack([r[4] for r in rows]), num_valid=np.array([r[5] for r in rows], np.int32),
+                        idx=np.stack([r[6] for r in rows]).astype(np.int32), raw_vertices=np.stack([r[7] for r in rows]),
+                        overlap=np.array([r[8] for r in rows]), clipped=np.array([r[9] for r in rows]),
+                        iou=np.array([r[10] for r in rows]), rel_err=err)
+
+
 if __name__ == "__main__":
     if "--decode" in sys.argv:
         main_decode()
     elif "--nl1" in sys.argv:
         main_nl1()
+    elif "--iou" in sys.argv:
+        main_iou()
     else:
         main()
         main_nl1()
         main_decode()
+        main_iou()

@@ -77,6 +77,40 @@ def test_sort_vertices_oracle_orders_anticlockwise():
     assert seen >= 20
 
 
+def _iou_fixture():
+    d = np.load(golden_path("iou_pairs.npz"))
+    n = len(d["num_valid"])
+    return d, d["vertices"].reshape(1, n, 24, 2), d["mask"].reshape(1, n, 24), d["num_valid"].reshape(1, n)
+
+
+def _overlap_from(idx, raw):
+    """The reference's ``calculate_area`` (IoU.py:176-192) on its un-normalised vertices: open shoelace over the 9 indices (the
+    padding index points at a zeroed intersection, so its terms vanish), float32 like the reference."""
+    sel = np.take_along_axis(raw, idx[..., None].astype(np.int64).repeat(2, -1), axis=1)
+    tot = (sel[:, :-1, 0] * sel[:, 1:, 1] - sel[:, :-1, 1] * sel[:, 1:, 0]).sum(1, dtype=np.float32)
+    return np.abs(tot) / 2
+
+
+def _check_overlaps(d, idx):
+    area = np.maximum(d["box1"][:, 2] * d["box1"][:, 3], d["box2"][:, 2] * d["box2"][:, 3])
+    got = _overlap_from(idx, d["raw_vertices"])
+    np.testing.assert_allclose(got, d["overlap"], rtol=0, atol=1e-6 * area.max())       # what the reference pipeline returned
+    assert (np.abs(got - d["clipped"]) <= 1e-4 * area).all()                            # ... and the true overlap
+    assert {0, 3, 4, 5, 6, 7, 8} <= set(d["num_valid"].tolist())
+
+
+def test_sort_vertices_oracle_is_pinned_by_the_reference_iou_pipeline():
+    """tests/golden/iou_pairs.npz: the reference's rotated-box IoU (IoU.py:139-198, its torch code run on CPU) on 256 box pairs
+    with the restatement standing in for the one CUDA-only call; the overlap areas that come out equal an independent float64
+    polygon clipper's (checked at generation time and again here), so the restatement orders vertices the way the reference's
+    only consumer of the kernel requires -- including the 8-corner identical-box rule and the all-padding cases."""
+    from oracle import eval_oracle
+    d, v, m, nv = _iou_fixture()
+    idx = eval_oracle.sort_vertices(v, m, nv)[0]
+    assert np.array_equal(idx, d["idx"])
+    _check_overlaps(d, idx)
+
+
 def test_bev_nms_oracle_matches_reference_fixture():
     from oracle import eval_oracle
     for name in ("decode_mc.npz", "decode_wt.npz", "decode_mx.npz"):

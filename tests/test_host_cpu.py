@@ -56,6 +56,20 @@ def test_reference_named_alias_package_resolves_to_the_build():
                 "assert l.__file__.startswith('/root/reference') and a.VFA is vfa_amd.VFA; print('ok')")
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/")
         assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+        # the reference's IoU module binds its CUDA-only op to the HIP one through compat/sort_vertices.py, unedited
+        code = ("import vfa.evaluation.pyeval.IoU as i, vfa_amd.eval_ops as e;"
+                "assert i.__file__.startswith('/root/reference') and i.sort_v.__self__.__name__ == 'SortVertices';"
+                "import sort_vertices as s; assert s.sort_vertices_forward is e.sort_vertices; print('ok')")
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/")
+        assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_extension_module_alias_exports_the_reference_entry_point():
+    """``import sort_vertices`` (reference cuda_op/cuda_ext.py:4) with compat/ on the path is the HIP op."""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(REPO, "compat"), REPO]))
+    code = "import sort_vertices as s, vfa_amd.eval_ops as e; assert s.sort_vertices_forward is e.sort_vertices; print('ok')"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/")
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
 
 
 # ------------------------------------------------------------------------------------------------
