@@ -68,9 +68,9 @@ int vfa_abi_version(void);
  *              boundary.  Results are unchanged. */
 #define VFA_FLAG_TERMS_MASK 0xf
 #define VFA_FLAG_RESERVED_CUS(n) (((n) & 0xff) << 8)
-/* vfa_pool_collapse_relu_sum_f32 only, DIAGNOSTIC: bits 16-23 select a profiling build of the kernel (phase ablations,
+/* vfa_pool_collapse_relu_sum_f32 only, DIAGNOSTIC: bits 16-27 select a profiling build of the kernel (phase ablations,
  * in-kernel cycle stamps written behind the records in the workspace); its results are meaningless.  tools/ use it. */
-#define VFA_FLAG_DEBUG(mask) (((mask) & 0xff) << 16)
+#define VFA_FLAG_DEBUG(mask) (((mask) & 0xfff) << 16)
 /* `flags` of vfa_project_gather_backward_f32: bit 0 = accumulate into grad_integral (otherwise it is zeroed first);
  * VFA_VOX_KERNEL_DIRECT selects the per-box atomic kernel instead of the LDS-privatised one (C = 256). */
 #define VFA_BWD_ACCUMULATE 1

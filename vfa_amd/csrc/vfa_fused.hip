@@ -31,7 +31,8 @@ constexpr int kC = 256;                                             // channels 
 constexpr int kRecBytes = 96, kHdrBytes = 32;
 constexpr int kMaxScales = 3;
 constexpr int kSlotBytes = kC * 4;                                  // one tap = 256 fp32
-constexpr int kMaxSlots = 126;                                      // LDS tap window of a (tile, view, scale)
+constexpr int kMaxSlots = 123;                                      // LDS tap window of a (tile, view, scale)
+constexpr int kRecSlots = 3;                                        // + the 32 box records of the item (3 KiB) behind it
 constexpr int kThreads = 512;
 constexpr int kRowBytes = 2 * kC;                                   // one bf16 plane row; 16-byte chunks XOR-swizzled with (row & 15)
 constexpr int kPlane = kTileBoxes * kRowBytes;                      // 16 KiB
@@ -304,7 +305,7 @@ struct FusedArgs {
     unsigned long long *diag;       // diagnostic build only: per workgroup 8 cycle counters
 };
 // diagnostic ablations (VFA_FLAG_DEBUG(mask), pool_collapse_kernel<TERMS, true> only)
-constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgStamps = 128; // (64: only the direct-item launch)
+constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgOneW = 8, kDbgNoRecords = 16, kDbgStamps = 128; // (64: only the direct-item launch)
 
 struct Frag { bf16x8 hi, lo; };
 
@@ -368,7 +369,7 @@ struct Item { int tile, scale, view; unsigned rest; bool valid; int rank; }; // 
 template <int TERMS, bool DIAG, bool DIRECT>
 __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 {
-    __shared__ float4 s_taps[kMaxSlots * 64];                       // 126 KiB: the tap window of the current item
+    __shared__ float4 s_taps[(kMaxSlots + kRecSlots) * 64];         // 126 KiB: the tap window of the current item + its box records
     __shared__ __align__(16) unsigned char s_planes[2 * kPlane];    // 32 KiB: bf16 hi / lo planes of the 32 x 256 A tile
     __shared__ uint4 s_hdr[2][16];                                  // tile headers of the next two items (32 B used of each 256)
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -474,57 +475,78 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     // The window is brought in by LDS-DMA, 1 KiB (one slot) per wave instruction, slot s = (window row, window column).  The
     // instructions are issued ONE AT A TIME between groups of MFMAs: eight waves issuing their whole share at once queue up
     // behind the texture addresser for ~1000 cycles and enter the MFMA phase skewed by as much.
-    int f_slot = 0, f_n = 0, f_cw = 1, f_inv = 0, f_x0 = 0, f_t0 = 0, f_top = 0, f_b0 = 0, f_wp = 0;
+    // The source offsets of a wave's fills (slots wave, wave + 8, ...: at most 16) are computed ONCE per item, lane j that of
+    // fill j, with a handful of vector instructions; the MFMA loop then reads them back with v_readlane: 5 instructions per
+    // fill where the closed form took ~20 dependent scalar ones, in a wave that issues in order, in front of its next MFMA.
+    int f_slot = 0, f_n = 0;
+    unsigned f_off = 0; // lane j: byte offset of this wave's j-th slot inside the view's padded integral image (< 4 GiB)
     const char *f_img = nullptr;
     auto begin_fills = [&](const Item &it, const i32x8 &hd) {
         const FusedScale &sc = a.sc[it.scale];
-        f_n = (DIRECT || (hd[0] & kTileDirect)) ? 0 : hd[1];
-        f_cw = hd[2]; f_inv = hd[3]; f_x0 = hd[4]; f_t0 = hd[5]; f_top = hd[6]; f_b0 = hd[7];
-        f_wp = sc.Wf + 2;
-        f_img = reinterpret_cast<const char *>(sc.integral) + (size_t)it.view * (sc.Hf + 2) * f_wp * kSlotBytes;
         f_slot = wave;
-    };
-    auto one_fill = [&]() {
-        if (f_slot < f_n) {
-            const int wr = (f_slot * f_inv) >> 16, wc = f_slot - wr * f_cw;
-            const int y = wr < f_top ? f_t0 + wr : f_b0 + (wr - f_top), x = f_x0 + wc;
-            const char *src = f_img + ((size_t)(y + 1) * f_wp + (x + 1)) * kSlotBytes + lane * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(s_taps + f_slot * 64), 16, 0, 0);
-            f_slot += kThreads / 64;
+        const int slot = wave + (kThreads / 64) * (lane & 15);
+        if (!DIRECT && (hd[0] & kTileRows)) {
+            // a direct item with a row slot: its "window" is its 32 pooled rows (pool_rows_kernel), slot b = row of box b
+            f_n = kTileBoxes;
+            f_off = (unsigned)slot * kSlotBytes;
+            f_img = reinterpret_cast<const char *>(a.rows) + (size_t)hd[2] * kTileBoxes * kSlotBytes;
+            return;
         }
+        f_n = (DIRECT || (hd[0] & kTileDirect)) ? 0 : hd[1];
+        const int cw = hd[2], inv = hd[3], x0 = hd[4], t0 = hd[5], top = hd[6], b0 = hd[7], wp = sc.Wf + 2;
+        const int wr = (slot * inv) >> 16, wc = slot - wr * cw;
+        const int y = wr < top ? t0 + wr : b0 + (wr - top), x = x0 + wc;
+        f_off = (unsigned)((y + 1) * wp + (x + 1)) * kSlotBytes;
+        f_img = reinterpret_cast<const char *>(sc.integral) + (size_t)it.view * (sc.Hf + 2) * wp * kSlotBytes;
     };
-    auto rest_fills = [&]() {
-        while (f_slot < f_n) one_fill();
+    auto fill_at = [&](int j) { // (j: wave-uniform)
+        const char *src = f_img + (size_t)(unsigned)__builtin_amdgcn_readlane((int)f_off, j) + lane * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(s_taps + f_slot * 64), 16, 0, 0);
+        f_slot += kThreads / 64;
+    };
+    auto one_fill = [&](int j) { // the j-th fill of this wave (j a compile-time constant where the loop is unrolled)
+        if (f_slot < f_n) fill_at(j);
+    };
+    auto rest_fills = [&]() { // every fill that is left
+        while (f_slot < f_n) fill_at((f_slot - wave) / (kThreads / 64));
     };
 
     const int grp = lane >> 4, cq = lane & 15;
-    LRec rec; // record of THIS lane's box of the item to be pooled next
-    // (a direct item of the main launch needs no record: the same registers prefetch its pooled row instead -- four float4,
-    // channels 64 q + 4 cq .. + 3 of box 4 wave + grp, left in the workspace by pool_rows_kernel)
+    LRec rec; // record of THIS lane's box (direct-item launch: loaded one item ahead; main launch: read from LDS when pooling)
+    // Main launch: the 32 box records of an item (3 KiB, contiguous) travel by LDS-DMA like its window, into the three slots
+    // behind it -- three wave instructions per item, nothing held in registers across the MFMA phase.  As per-lane global loads
+    // into registers that live across the loop they made the compiler wait for them (`vmcnt(0)`) right where they were issued:
+    // a full memory latency per item in front of the MFMA phase.
     auto load_record = [&](const Item &it, int it_flags, int it_slot) {
-        if (!DIRECT && (it_flags & kTileRows)) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(a.rows) + ((size_t)it_slot * kTileBoxes + 4 * wave + grp) * (kC / 4) + cq;
+        if constexpr (DIRECT) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(a.sc[it.scale].recs + (((size_t)it.view * a.n_tiles + it.tile) * kTileBoxes + 4 * wave + grp) * kRecBytes);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rec.v[q] = p[q * 16];
-            return;
+            for (int k = 0; k < 6; ++k) rec.v[k] = p[k];
+        } else if (!(it_flags & kTileRows) && wave >= 8 - kRecSlots) { // (the waves with the smallest share of the window)
+            const int k = wave - (8 - kRecSlots);
+            const unsigned char *p = a.sc[it.scale].recs + ((size_t)it.view * a.n_tiles + it.tile) * kTileBoxes * kRecBytes + k * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                             (__attribute__((address_space(3))) void *)(s_taps + (kMaxSlots + k) * 64), 16, 0, 0);
         }
-        const uint4 *p = reinterpret_cast<const uint4 *>(a.sc[it.scale].recs + (((size_t)it.view * a.n_tiles + it.tile) * kTileBoxes + 4 * wave + grp) * kRecBytes);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) rec.v[k] = p[k];
     };
     auto pool = [&](const Item &it, int it_flags, int it_word1) {
         if (!DIRECT && (it_flags & kTileRows)) {
-            // a direct item of the main launch: its pooled rows came with `load_record`; only the bf16 split remains
+            // a direct item of the main launch: its pooled rows arrived as its window (slot b = row of box b); only the bf16
+            // split remains
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                store_quad(s_planes, 4 * wave + grp, q * 16 + cq,
-                           make_float4(__uint_as_float(rec.v[q].x), __uint_as_float(rec.v[q].y), __uint_as_float(rec.v[q].z), __uint_as_float(rec.v[q].w)));
+                store_quad(s_planes, 4 * wave + grp, q * 16 + cq, s_taps[(4 * wave + grp) * 64 + q * 16 + cq]);
             return;
         }
         const FusedScale &sc = a.sc[it.scale];
         const unsigned Wp = (unsigned)sc.Wf + 2u;
         const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)it.view * (sc.Hf + 2) * Wp * kSlotBytes;
+        if constexpr (!DIRECT) { // this lane's box record, out of the slots behind the window (a broadcast read per 16-lane group)
+            const uint4 *rp = reinterpret_cast<const uint4 *>(s_taps + kMaxSlots * 64) + (4 * wave + grp) * (kRecBytes / 16);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rec.v[k] = rp[k];
+        }
         const float wt[16] = {__uint_as_float(rec.v[0].x), __uint_as_float(rec.v[0].y), __uint_as_float(rec.v[0].z), __uint_as_float(rec.v[0].w),
                               __uint_as_float(rec.v[1].x), __uint_as_float(rec.v[1].y), __uint_as_float(rec.v[1].z), __uint_as_float(rec.v[1].w),
                               __uint_as_float(rec.v[2].x), __uint_as_float(rec.v[2].y), __uint_as_float(rec.v[2].z), __uint_as_float(rec.v[2].w),
@@ -725,77 +747,86 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         if (nxt.valid) nn = seek(nxt.tile, nxt.scale, nxt.rest, nxt.rank + 1);
         tick(0);
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): this wave's share of the tap window has landed
+        tick(1);
         __syncthreads();                    // ... and everybody else's
         if (nxt.valid) header_get(nh, hbuf); // (the header of the next item landed with that wait)
-        tick(1);
+        tick(2);
         flush();
-        if (cur.scale != w_scale) { // W and bias of this scale: land while the boxes are pooled
+        if (cur.scale != w_scale && !((dbg & kDbgOneW) && w_scale >= 0)) { // W and bias of this scale: land while the boxes are pooled
             load_weights(cur.scale);
             bc = bias_of(cur.scale);
             w_scale = cur.scale;
         }
         if (!(dbg & kDbgNoPool)) pool(cur, cur_flags, cur_word1);
-        tick(2);
-        __syncthreads();                    // A tile complete; the tap window is free again
         tick(3);
+        // W, the bias and the tile stores of `flush` were issued a pooling pass ago.  Waiting for them HERE, explicitly, is
+        // what keeps the compiler from doing it in front of the first MFMA, behind the DMA instructions issued below: its
+        // in-order vmcnt would then cover those too -- a full memory round trip per item before the MFMA phase.
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();                    // A tile complete; the tap window is free again
+        tick(4);
         f_n = 0;
         if (nxt.valid) {
             nxt_flags = nh[0]; nxt_word1 = nh[2];
             if (!(dbg & kDbgNoFills)) begin_fills(nxt, nh); // issued between the MFMAs below
-            load_record(nxt, nxt_flags, nxt_word1); // this lane's box of the next item: lands under the MFMAs
+            if (!(dbg & kDbgNoRecords)) load_record(nxt, nxt_flags, nxt_word1); // this lane's box of the next item: lands under the MFMAs
         }
         hbuf ^= 1;
         if (nn.valid) header_of(nn, hbuf);
-        tick(4);
+        tick(5);
 
-        // two accumulator chains (even / odd k-steps): a dependent 32x32x16 MFMA issues only ~84 cycles after its predecessor,
-        // so one chain per wave leaves the matrix pipe a quarter idle even with two waves per SIMD; the second chain costs 16
-        // VGPRs that are free in this phase (the pooling temporaries are dead)
-        f32x16 acc, acc2;
+        // ONE accumulator chain: back-to-back dependent v_mfma_f32_32x32x16_bf16 issue at the pipe rate (32 cycles), so extra
+        // chains buy nothing and their registers are better spent on running the A fragments ahead of the MFMAs
+        f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[i] = bc; acc2[i] = 0.0f; } // (the bias rides in the first chain)
+        for (int i = 0; i < 16; ++i) acc[i] = bc; // (the bias rides in the accumulator)
         if (!(dbg & kDbgNoMfma)) {
             int key2 = key, fb = frag_base; // (opaque: keeps the 16 swizzled fragment offsets out of long-lived registers)
             asm volatile("" : "+v"(key2), "+v"(fb));
             const unsigned char *pa = s_planes + fb;
+            auto frags = [&](int k, bf16x8 &hh, bf16x8 &ll) {
+                const int off = (k ^ (key2 >> 1)) << 5;
+                hh = *reinterpret_cast<const bf16x8 *>(pa + off);
+                ll = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off);
+            };
+            // the A fragments run two k-steps ahead of the MFMAs (LDS reads return in order: `lgkmcnt(4)` = everything but
+            // the two youngest pairs has arrived; left alone the compiler drains the queue, reads just issued included)
+            bf16x8 fh[3], fl[3];
+            frags(0, fh[0], fl[0]);
+            frags(1, fh[1], fl[1]);
 #pragma unroll
-            for (int c = 0; c < kSteps / 2; ++c) {
-                one_fill(); // (wave-uniform branch; nothing to issue once the wave's share of the window is on its way)
-                const int off0 = ((2 * c) ^ (key2 >> 1)) << 5, off1 = ((2 * c + 1) ^ (key2 >> 1)) << 5;
-                const bf16x8 h0 = *reinterpret_cast<const bf16x8 *>(pa + off0);
-                const bf16x8 h1 = *reinterpret_cast<const bf16x8 *>(pa + off1);
-                const bf16x8 l0 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off0);
-                const bf16x8 l1 = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off1);
-                // the four hi products first: they cover the latency of the lo reads
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].lo, acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].lo, acc2, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, w[2 * c].hi, acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, w[2 * c + 1].hi, acc2, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, w[2 * c].hi, acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].hi, acc2, 0, 0, 0);
-                if (TERMS >= 4) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, w[2 * c].lo, acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, w[2 * c + 1].lo, acc2, 0, 0, 0);
+            for (int k = 0; k < kSteps; ++k) {
+                if ((k & 1) == 0) one_fill(k >> 1); // (wave-uniform branch; nothing to issue once the wave's share is on its way)
+                if (k + 2 < kSteps) {
+                    frags(k + 2, fh[(k + 2) % 3], fl[(k + 2) % 3]);
+                    __builtin_amdgcn_s_waitcnt(0xc47f); // lgkmcnt(4)
+                } else if (k + 1 < kSteps) {
+                    __builtin_amdgcn_s_waitcnt(0xc27f); // lgkmcnt(2)
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[k % 3], w[k].lo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[k % 3], w[k].hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[k % 3], w[k].hi, acc, 0, 0, 0);
+                if (TERMS >= 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[k % 3], w[k].lo, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         rest_fills(); // windows of more than 64 slots
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[i] + acc2[i]); // vfa_op.py:124; vfanet.py:79, 82
-        tick(5);
+        for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[i]); // vfa_op.py:124; vfanet.py:79, 82
+        tick(6);
 
         if (!nxt.valid || nxt.tile != cur.tile) {
             pend_tile = cur.tile;
             pend_next = nxt.valid ? nxt.tile : t_end;
         }
-        tick(6);
         if (DIAG) stamp[7] += 1;
         cur = nxt;
         cur_flags = nxt_flags; cur_word1 = nxt_word1;
         nxt = nn;
     }
     flush();
-    if (DIAG && (dbg & kDbgStamps) && a.diag && tid == 0)
+    if (DIAG && (dbg & kDbgStamps) && a.diag && tid == ((dbg >> 8) & 7) * 64) // (bits 8..10: the wave that reports)
         for (int k = 0; k < 8; ++k) a.diag[(size_t)blockIdx.x * 8 + k] = stamp[k];
 }
 
@@ -1316,8 +1347,8 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
                                    size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales, const int *feat_hw,
                                    int accumulate, int flags, void *stream)
 {
-    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xff;
-    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xffff00)) return VFA_ERR_BAD_ARGUMENT;
+    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xfff;
+    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales || !feat_hw || !integrals ||
         (terms != 0 && terms != 3 && terms != 4))
         return VFA_ERR_BAD_ARGUMENT;

@@ -398,7 +398,7 @@ def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=Fa
     hw = _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)])
     _launch("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array(biases), _lib.ptr(workspace),
             workspace.numel(), _lib.ptr(out), n, L, W, ns, hw, 1 if accumulate else 0,
-            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xff) << 16),  # debug: diagnostic build, tools/ only
+            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16),  # debug: diagnostic build, tools/ only
             _lib.current_stream_handle(), tag=(n, L, W, tuple((i.shape[1] - 2, i.shape[2] - 2) for i in integrals)))
     return out
 
