@@ -461,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     // registers before the data landed and restored garbage as soon as scalar pressure rose; a compiler-issued scalar load is
     // waited for at the next lgkmcnt(0) -- scalar loads return out of order -- i.e. at once (+1 300 cycles per item).
     auto header_of = [&](const Item &it, int buf) {
-        if (wave == 7) { // (the wave with the smallest share of the window DMA)
+        if (wave == 0) { // (an older wave: see begin_fills)
             const unsigned char *p = a.sc[it.scale].hdrs + ((size_t)it.view * a.n_tiles + it.tile) * kHdrBytes + lane * 4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                              (__attribute__((address_space(3))) void *)(&s_hdr[buf][0]), 4, 0, 0);
@@ -475,16 +475,22 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     // The window is brought in by LDS-DMA, 1 KiB (one slot) per wave instruction, slot s = (window row, window column).  The
     // instructions are issued ONE AT A TIME between groups of MFMAs: eight waves issuing their whole share at once queue up
     // behind the texture addresser for ~1000 cycles and enter the MFMA phase skewed by as much.
-    // The source offsets of a wave's fills (slots wave, wave + 8, ...: at most 16) are computed ONCE per item, lane j that of
+    // The source offsets of a wave's fills (slots wave, wave + 4, ...: at most 32) are computed ONCE per item, lane j that of
     // fill j, with a handful of vector instructions; the MFMA loop then reads them back with v_readlane: 5 instructions per
     // fill where the closed form took ~20 dependent scalar ones, in a wave that issues in order, in front of its next MFMA.
+    constexpr int kFillWaves = 4; // waves 0-3 bring the window in (see begin_fills)
     int f_slot = 0, f_n = 0;
     unsigned f_off = 0; // lane j: byte offset of this wave's j-th slot inside the view's padded integral image (< 4 GiB)
     const char *f_img = nullptr;
     auto begin_fills = [&](const Item &it, const i32x8 &hd) {
-        const FusedScale &sc = a.sc[it.scale];
+        // Only the OLDER wave of every SIMD (waves 0-3) issues DMA: the arbiter favours it, it leaves the MFMA phase ~1 000
+        // cycles before its partner, and the scalar address arithmetic of this stage -- identical in every wave, on the CU's one
+        // scalar unit -- is then done by four waves instead of eight.
         f_slot = wave;
-        const int slot = wave + (kThreads / 64) * (lane & 15);
+        f_n = 0;
+        if (wave >= kFillWaves) return;
+        const FusedScale &sc = a.sc[it.scale];
+        const int slot = wave + kFillWaves * (lane & 31);
         if (!DIRECT && (hd[0] & kTileRows)) {
             // a direct item with a row slot: its "window" is its 32 pooled rows (pool_rows_kernel), slot b = row of box b
             f_n = kTileBoxes;
@@ -503,13 +509,13 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         const char *src = f_img + (size_t)(unsigned)__builtin_amdgcn_readlane((int)f_off, j) + lane * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                          (__attribute__((address_space(3))) void *)(s_taps + f_slot * 64), 16, 0, 0);
-        f_slot += kThreads / 64;
+        f_slot += kFillWaves;
     };
     auto one_fill = [&](int j) { // the j-th fill of this wave (j a compile-time constant where the loop is unrolled)
         if (f_slot < f_n) fill_at(j);
     };
     auto rest_fills = [&]() { // every fill that is left
-        while (f_slot < f_n) fill_at((f_slot - wave) / (kThreads / 64));
+        while (f_slot < f_n) fill_at((f_slot - wave) / kFillWaves);
     };
 
     const int grp = lane >> 4, cq = lane & 15;
@@ -523,8 +529,8 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             const uint4 *p = reinterpret_cast<const uint4 *>(a.sc[it.scale].recs + (((size_t)it.view * a.n_tiles + it.tile) * kTileBoxes + 4 * wave + grp) * kRecBytes);
 #pragma unroll
             for (int k = 0; k < 6; ++k) rec.v[k] = p[k];
-        } else if (!(it_flags & kTileRows) && wave >= 8 - kRecSlots) { // (the waves with the smallest share of the window)
-            const int k = wave - (8 - kRecSlots);
+        } else if (!(it_flags & kTileRows) && wave >= 1 && wave <= kRecSlots) { // (older waves: see begin_fills)
+            const int k = wave - 1;
             const unsigned char *p = a.sc[it.scale].recs + ((size_t)it.view * a.n_tiles + it.tile) * kTileBoxes * kRecBytes + k * 1024 + lane * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                              (__attribute__((address_space(3))) void *)(s_taps + (kMaxSlots + k) * 64), 16, 0, 0);
@@ -796,7 +802,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             frags(1, fh[1], fl[1]);
 #pragma unroll
             for (int k = 0; k < kSteps; ++k) {
-                if ((k & 1) == 0) one_fill(k >> 1); // (wave-uniform branch; nothing to issue once the wave's share is on its way)
+                one_fill(k); // (wave-uniform branch; nothing to issue once the wave's share is on its way)
                 if (k + 2 < kSteps) {
                     frags(k + 2, fh[(k + 2) % 3], fl[(k + 2) % 3]);
                     __builtin_amdgcn_s_waitcnt(0xc47f); // lgkmcnt(4)
