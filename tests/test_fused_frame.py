@@ -416,8 +416,9 @@ def test_direct_items_without_a_row_slot_take_the_second_launch(row_slots):
 @pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 7, None), ("multiviewc_200x200x1", 2, (21, 40)), ("multiviewc_200x200x1", 1, (3, 5))])
 def test_work_cuts_cover_every_item_once(name, n_cam, crop):
     """`tile_chunks_kernel`: the n_chunks + 1 cuts (tile, rank) of the item sequence are monotonic, start at (0, 0), end at (n_tiles, 0),
-    never point behind the last item of a tile, and the pieces between them carry equal numbers of items (+- one tile's
-    granule is NOT allowed any more: cuts fall inside tiles)."""
+    never point behind the last item of a tile, and the pieces between them carry equal estimated COST (the kernel's cost model,
+    restated here: an item 330 + its window slots, a row item 280, + 110 for the first item of a (tile, scale), + 380 for the first
+    of a tile, a tile without items 16) to within one item: cuts fall inside tiles."""
     import vfa_amd
     from vfa_amd import _lib, ops
     from vfa_amd.synthetic import make_workload
@@ -433,10 +434,20 @@ def test_work_cuts_cover_every_item_once(name, n_cam, crop):
     lay = ops.frame_workspace_layout(n_cam, L, W, 3)
     nt = lay["tiles_l"] * lay["tiles_w"]
     items = np.zeros(nt, np.int64)
+    weights = [[] for _ in range(nt)]               # per tile: the cost of its items in kernel order
     for s in range(3):
         live = host[lay["live"][s]:lay["live"][s] + nt * 4].view(np.uint32)
         ovf = host[lay["overflow"][s]:lay["overflow"][s] + nt * 4].view(np.uint32)
+        hdr = host[lay["hdrs"][s]:lay["hdrs"][s] + n_cam * nt * 32].view(np.uint32).reshape(n_cam, nt, 8)
         items += np.array([bin(int(a) & ~int(b)).count("1") for a, b in zip(live, ovf)])
+        for t in range(nt):
+            first = True
+            for v in range(n_cam):
+                if (int(live[t]) & ~int(ovf[t])) >> v & 1:
+                    h = hdr[v, t]
+                    w = 280 if h[0] & 4 else 330 + int(h[1])
+                    weights[t].append(w + (110 if first else 0) + (380 if not weights[t] else 0))
+                    first = False
     K = lay["n_chunks"]
     cs = host[lay["chunks"]:lay["chunks"] + (K + 1) * 4].view(np.int32).astype(np.int64)
     cr = host[lay["ranks"]:lay["ranks"] + (K + 1) * 4].view(np.int32).astype(np.int64)
@@ -448,7 +459,13 @@ def test_work_cuts_cover_every_item_once(name, n_cam, crop):
     before = np.concatenate([[0], np.cumsum(items)])
     upto = before[np.minimum(cs, nt)] + cr          # items in front of each cut
     assert upto[-1] == items.sum()
+    cost_before = np.concatenate([[0], np.cumsum([sum(w) if w else 16 for w in weights])])
+    inner = [np.concatenate([[0], np.cumsum(w)]) for w in weights]
+    cost_upto = np.array([cost_before[t] + (inner[t][r] if t < nt else 0) for t, r in zip(np.minimum(cs, nt), cr)])
+    biggest = max(max(w) for w in weights if w)
     for wgs in (256, 248, 240, 8):                  # pieces of a launch with that many workgroups (240: 16 CUs left to RCCL)
-        cut = upto[(np.arange(wgs + 1) * K) // wgs]
-        per = np.diff(cut)
-        assert per.sum() == items.sum() and per.max() - per.min() <= max(3, int(0.03 * per.mean()) + 3), (per.min(), per.max())
+        idx = (np.arange(wgs + 1) * K) // wgs
+        per = np.diff(upto[idx])
+        assert per.sum() == items.sum()
+        cost = np.diff(cost_upto[idx])
+        assert cost.max() - cost.min() <= biggest + 0.03 * cost.mean(), (cost.min(), cost.max(), biggest)

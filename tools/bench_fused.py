@@ -86,5 +86,39 @@ with torch.no_grad():
             tot = d[:, :7].sum(1)
             print(f"    per-workgroup total cycles: min {tot.min():.3g}  mean {tot.mean():.3g}  p90 {np.percentile(tot, 90):.3g}  max {tot.max():.3g}"
                   f"  (max / mean {tot.max() / tot.mean():.3f}); items per workgroup min {items.min():.0f} max {items.max():.0f}")
+            if mask == 128 and len(d) == 256:
+                # what the per-workgroup time depends on: items, their window slots, row items, scale changes, tiles (least squares)
+                nblk, K = 256, lay["n_chunks"]
+                cs = host[lay["chunks"]:lay["chunks"] + 4 * (K + 1)].view(np.int32)
+                cr = host[lay["ranks"]:lay["ranks"] + 4 * (K + 1)].view(np.int32)
+                hdrs = [host[lay["hdrs"][s]:lay["hdrs"][s] + n * tiles * 32].view(np.uint32).reshape(n, tiles, 8) for s in range(3)]
+                ovf = [host[lay["overflow"][s]:lay["overflow"][s] + 4 * tiles].view(np.uint32) for s in range(3)]
+                seq = []  # (tile, scale, view, slots, rows) in kernel order
+                for t in range(tiles):
+                    for s in range(3):
+                        for v in range(n):
+                            h = hdrs[s][v, t]
+                            if (h[0] & 1) and not ((ovf[s][t] >> v) & 1):
+                                seq.append((t, s, v, 0 if (h[0] & 2) else int(h[1]), 1 if (h[0] & 4) else 0))
+                seq = np.array(seq)
+                first = np.searchsorted(seq[:, 0], np.arange(tiles + 1))
+                feats = []
+                for wg in range(nblk):
+                    c0, c1 = K * wg // nblk, K * (wg + 1) // nblk
+                    i0, i1 = first[min(cs[c0], tiles)] + cr[c0], first[min(cs[c1], tiles)] + cr[c1]
+                    part = seq[i0:i1]
+                    changes = 1 + int(np.count_nonzero(np.diff(part[:, 0] * 4 + part[:, 1]))) if len(part) else 0
+                    feats.append((len(part), part[:, 3].sum(), part[:, 4].sum(), changes, len(np.unique(part[:, 0])), 1.0))
+                feats = np.array(feats, dtype=np.float64)
+                # diag rows are indexed by blockIdx.x; the kernel maps it to a range index XCD-contiguously
+                per = (nblk + 7) // 8
+                lb = np.array([(b % 8) * per + b // 8 for b in range(nblk)])
+                y = np.zeros(nblk)
+                full = ws[diag_off:diag_off + 256 * 64].cpu().numpy().view(np.uint64).reshape(256, 8).astype(np.float64)
+                y[lb] = full[:, :7].sum(1)
+                coef, *_ = np.linalg.lstsq(feats, y, rcond=None)
+                res = y - feats @ coef
+                print(f"    cycles ~ {coef[0]:.0f} x items + {coef[1]:.1f} x slots + {coef[2]:.0f} x row items + {coef[3]:.0f} x scale changes"
+                      f" + {coef[4]:.0f} x tiles + {coef[5]:.0f};  residual std {res.std():.3g} of mean {y.mean():.3g} (raw std {y.std():.3g})")
             order = np.argsort(tot)[-5:]
             print("    slowest workgroups (cycles, items, cycles/item):", [(int(tot[i]), int(items[i]), int(tot[i] / items[i])) for i in order])

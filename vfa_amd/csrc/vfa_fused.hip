@@ -32,6 +32,8 @@ constexpr int kRecBytes = 96, kHdrBytes = 32;
 constexpr int kMaxScales = 3;
 constexpr int kSlotBytes = kC * 4;                                  // one tap = 256 fp32
 constexpr int kMaxSlots = 123;                                      // LDS tap window of a (tile, view, scale)
+// cost estimate of an item of the persistent kernel in units of 32 cycles (tile_chunks_kernel): base + 1 per window slot
+constexpr unsigned kItemCost = 330, kRowItemCost = 280;
 constexpr int kRecSlots = 3;                                        // + the 32 box records of the item (3 KiB) behind it
 constexpr int kThreads = 512;
 constexpr int kRowBytes = 2 * kC;                                   // one bf16 plane row; 16-byte chunks XOR-swizzled with (row & 15)
@@ -61,6 +63,8 @@ struct RecordArgs {
     unsigned *row_list;              // (rows_cap) slot -> scale << 30 | view << 25 | tile
     unsigned char *hdrs[kMaxScales]; // (n_views, n_tiles, 32 B)
     unsigned char *recs[kMaxScales]; // (n_views, n_tiles, 32 boxes, 96 B)
+    unsigned short *item_w;          // (n_tiles, kMaxScales, views_pad): cost estimate of every item, 0 = none (tile_chunks_kernel)
+    int views_pad;                   // n_views rounded up to 8
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
@@ -190,6 +194,9 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
                     }
                     else atomicOr(a.overflow[s] + tile, 1u << view);
                 }
+                const bool main_item = any_live && !(direct && !(hflags & kTileRows));
+                a.item_w[((size_t)tile * kMaxScales + s) * a.views_pad + view] =
+                    (unsigned short)(!main_item ? 0u : (direct ? kRowItemCost : kItemCost + (unsigned)n_slots));
                 hdr[0] = make_uint4(hflags, (unsigned)n_slots, word2, (unsigned)inv);
                 hdr[1] = make_uint4((unsigned)x0, (unsigned)t0, (unsigned)top_rows, (unsigned)b0);
             }
@@ -222,33 +229,62 @@ __global__ __launch_bounds__(256) void split_weight_frag_kernel(SplitArgs sa)
     out[((size_t)(wave * kSteps + s) * 2 + 1) * 64 + lane] = lo.u;
 }
 
-// Work balance of the persistent kernel: the cost of a tile is its number of live (view, scale) items, which varies with the
-// camera coverage.  The tile sequence is cut into kChunks pieces of equal cost (weight of a tile = 1 + 4 x live items); a
-// workgroup takes a contiguous run of chunks.  A cut may fall INSIDE a tile: chunk c starts at the chunk_rank[c]-th live item of
-// tile chunk_start[c] (items in (scale, view) order; rank 0 = the tile's beginning) -- whole tiles only left the slowest
-// workgroup 19 % above the mean on the bench frame (4.9 tiles of ~18 items per workgroup).  A tile cut this way is finished by
-// the workgroup that holds its beginning, which gets the partial sums of the other one through the workspace (see `flush`).
-// One workgroup, an LDS scan over per-thread sums.
+// Work balance of the persistent kernel: the item sequence (tile, scale, view) is cut into kChunks pieces of equal estimated COST;
+// a workgroup takes a contiguous run of chunks.  Cost model, fitted to the per-workgroup cycle counts of the diagnostic build on
+// the bench frame (tools/bench_fused.py; unit = 32 cycles): an item 330 + 1 per slot of its tap window (a row item -50), + 110
+// for the first item of a (tile, scale) (W and bias are reloaded), + 380 per tile (the tile store and its masked-item term);
+// a tile without items 16.  A cut may fall INSIDE a tile: chunk c starts at the chunk_rank[c]-th live item of tile
+// chunk_start[c] (items in (scale, view) order; rank 0 = the tile's beginning) -- whole tiles only left the slowest workgroup 19 %
+// above the mean on the bench frame (4.9 tiles of ~18 items per workgroup), equal item counts 7 %.  A tile cut this way is
+// finished by the workgroup that holds its beginning, which gets the partial sums of the other one through the workspace (see
+// `flush`).  One workgroup, an LDS scan over per-thread sums.
 constexpr int kChunks = 8192; // (fine enough that a launch with any number of workgroups gets pieces within 3 % of each other)
 constexpr int kMaxBlocks = 512; // workgroups of the persistent kernel
-__global__ __launch_bounds__(1024) void tile_chunks_kernel(const unsigned *live0, const unsigned *live1, const unsigned *live2,
-                                                           const unsigned *ovf0, const unsigned *ovf1, const unsigned *ovf2,
-                                                           int n_scales, int n_tiles, unsigned view_mask, int *chunk_start, int *chunk_rank)
+struct ChunkArgs {
+    const unsigned *live[kMaxScales], *overflow[kMaxScales];
+    const unsigned short *item_w; // (n_tiles, kMaxScales, views_pad): written by frame_records_kernel
+    int n_scales, n_tiles, n_views, views_pad;
+    int *chunk_start, *chunk_rank;
+};
+__global__ __launch_bounds__(1024) void tile_chunks_kernel(ChunkArgs a)
 {
     __shared__ unsigned long long part[1024];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, n_tiles = a.n_tiles;
+    const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
     const int per = (n_tiles + 1023) / 1024, t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
-    auto items_of = [&](int t) {
-        // (the items of the main launch: live, minus the direct ones without a row slot)
-        int items = __popc(live0[t] & ~ovf0[t] & view_mask);
-        if (n_scales > 1) items += __popc(live1[t] & ~ovf1[t] & view_mask);
-        if (n_scales > 2) items += __popc(live2[t] & ~ovf2[t] & view_mask);
-        return items;
+    constexpr unsigned kScale = 110, kTile = 380, kEmpty = 16;
+    // walks the items of tile t in kernel order; `visit(k, w0, w1)`: item k covers the positions [w0, w1) of the tile's weight.
+    // The weights of eight views come with one 16-byte load.
+    auto walk = [&](int t, auto &&visit) -> unsigned {
+        unsigned w = 0;
+        int k = 0;
+        for (int s = 0; s < a.n_scales; ++s) {
+            const unsigned m = a.live[s][t] & ~a.overflow[s][t] & view_mask; // (the items of the main launch)
+            bool first = true;
+            for (int g = 0; g * 8 < a.n_views; ++g) {
+                unsigned mg = (m >> (8 * g)) & 0xffu;
+                if (!mg) continue;
+                const uint4 q = *reinterpret_cast<const uint4 *>(a.item_w + ((size_t)t * kMaxScales + s) * a.views_pad + 8 * g);
+                const unsigned long long lo = (unsigned long long)q.x | ((unsigned long long)q.y << 32), hi = (unsigned long long)q.z | ((unsigned long long)q.w << 32);
+                while (mg) {
+                    const int v = __builtin_ctz(mg);
+                    mg &= mg - 1u;
+                    unsigned wi = (unsigned)(((v < 4 ? lo : hi) >> (16 * (v & 3))) & 0xffffull);
+                    if (first) wi += kScale;
+                    if (k == 0) wi += kTile;
+                    first = false;
+                    visit(k, w, w + wi);
+                    w += wi;
+                    ++k;
+                }
+            }
+        }
+        return k == 0 ? kEmpty : w;
     };
     unsigned long long local = 0;
-    for (int t = t0; t < t1; ++t) local += (unsigned long long)(1 + 4 * items_of(t));
+    for (int t = t0; t < t1; ++t) local += walk(t, [](int, unsigned, unsigned) {});
     part[tid] = local;
-    for (int c = tid; c <= kChunks; c += 1024) { chunk_start[c] = n_tiles; chunk_rank[c] = 0; }
+    for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_tiles; a.chunk_rank[c] = 0; }
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) { // inclusive Hillis-Steele scan
         const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
@@ -258,21 +294,34 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(const unsigned *live0
     }
     const unsigned long long total = part[1023];
     unsigned long long before = part[tid] - local; // weight of all tiles in front of tile t
-    // chunk c starts at position p_c = ceil(total c / kChunks): inside the tile t with before(t) <= p_c < before(t) + weight(t)
+    // chunk c starts at position p_c = ceil(total c / kChunks): at the item of tile t whose weight interval holds p_c - before(t)
+    // (a position inside an item's interval rounds to the nearer end; the end of the last item = the next tile's beginning).
+    // The cuts of a tile are found in ONE walk: they come in increasing position.
     for (int t = t0; t < t1; ++t) {
-        const int items = items_of(t);
-        const unsigned long long w = (unsigned long long)(1 + 4 * items);
-        long long c = before > 0 ? (long long)((before - 1) * kChunks / total) : 0; // p_c >= before  <=>  c > (before - 1) K / total
-        for (; c < kChunks; ++c) {
-            const unsigned long long pc = (total * (unsigned long long)c + kChunks - 1) / kChunks;
-            if (pc < before) continue;
-            if (pc >= before + w) break;
-            const int k = (int)((pc - before + 2) / 4); // the item nearest to the position
-            if (k >= items && items > 0) { // behind the last item: the next tile's beginning (written by its own thread if it
-                if (t + 1 < n_tiles && before + w > pc) { chunk_start[c] = t + 1; chunk_rank[c] = 0; } // ... lies in range)
-            } else {
-                chunk_start[c] = t;
-                chunk_rank[c] = k;
+        const unsigned long long tb = before;
+        long long c = tb > 0 ? (long long)((tb - 1) * kChunks / total) : 0; // p_c >= before  <=>  c > (before - 1) K / total
+        auto pos_of = [&](long long cc) { return (total * (unsigned long long)cc + kChunks - 1) / kChunks; };
+        while (c < kChunks && pos_of(c) < tb) ++c;
+        int n_items = 0;
+        const unsigned w = walk(t, [&](int kk, unsigned w0, unsigned w1) {
+            n_items = kk + 1;
+            while (c < kChunks) {
+                const unsigned long long pc = pos_of(c);
+                if (pc >= tb + w1) break;
+                // (pc >= tb + w0: the cuts in front of this item were taken by its predecessors)
+                const unsigned pos = (unsigned)(pc - tb);
+                const int k = (pos - w0) * 2 < (w1 - w0) ? kk : kk + 1;
+                a.chunk_start[c] = t; a.chunk_rank[c] = k; // (k == number of items: fixed below)
+                ++c;
+            }
+        });
+        if (n_items == 0) {
+            for (; c < kChunks && pos_of(c) < tb + w; ++c) { a.chunk_start[c] = t; a.chunk_rank[c] = 0; }
+        } else {
+            // cuts that rounded to the end of the last item are the next tile's beginning (these are the last cuts of the tile)
+            for (long long cc = c - 1; cc >= 0 && a.chunk_start[cc] == t && a.chunk_rank[cc] >= n_items; --cc) {
+                a.chunk_start[cc] = t + 1 < n_tiles ? t + 1 : n_tiles;
+                a.chunk_rank[cc] = 0;
             }
         }
         before += w;
@@ -425,6 +474,11 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     };
 
     auto bias_of = [&](int scale) { return a.sc[scale].bias ? a.sc[scale].bias[wave * 32 + r] : 0.0f; };
+    // relu(bias) of this lane's column for every scale: what a fully masked (view, scale) item adds to a cell.  Kept in registers:
+    // loading the three biases inside `write_tile` put three dependent memory round trips in front of every tile store.
+    float rbias[kMaxScales];
+#pragma unroll
+    for (int s2 = 0; s2 < kMaxScales; ++s2) rbias[s2] = s2 < a.n_scales ? relu_t(bias_of(s2)) : 0.0f;
 
     // output rows of a tile: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 MFMA block, column r
     auto write_tile = [&](int tile, const f32x16 &sum, bool have_sum) {
@@ -433,7 +487,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         if (!DIRECT) {
 #pragma unroll
             for (int s = 0; s < kMaxScales; ++s)
-                if (s < a.n_scales) extra += (float)(a.n_views - __popc(live_all(tile, s))) * relu_t(bias_of(s));
+                if (s < a.n_scales) extra += (float)(a.n_views - __popc(live_all(tile, s))) * rbias[s];
         }
         // (opaque copies: the per-lane row offsets below are loop invariants the compiler would otherwise keep in VGPRs for the
         // whole kernel, pushing other values into scratch)
@@ -1163,8 +1217,8 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
     size_t live[kMaxScales], direct[kMaxScales], overflow[kMaxScales], counter, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales],
-        masks_bytes, chunks, ranks, diag, rows, row_list, partial, flags, total;
-    int tiles_l, tiles_w, n_tiles, rows_cap;
+        masks_bytes, chunks, ranks, diag, rows, row_list, partial, flags, item_w, total;
+    int tiles_l, tiles_w, n_tiles, rows_cap, views_pad;
 };
 inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
 {
@@ -1206,6 +1260,9 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     w.rows_cap = (int)cap;
     w.row_list = off;
     off = align_up(off + cap * sizeof(unsigned), 256);
+    w.views_pad = (n_views + 7) / 8 * 8; // cost estimates of the items, per tile (tile_chunks_kernel)
+    w.item_w = off;
+    off = align_up(off + (size_t)w.n_tiles * kMaxScales * w.views_pad * sizeof(unsigned short) + 16, 256);
     w.rows = off;
     off = align_up(off + cap * kTileBoxes * kC * sizeof(float), 256);
     w.total = off;
@@ -1289,6 +1346,8 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
         a.row_counter = reinterpret_cast<unsigned *>(ws + lay.counter);
         a.rows_cap = (unsigned)rows_cap_of(lay, workspace_bytes);
         a.row_list = reinterpret_cast<unsigned *>(ws + lay.row_list);
+        a.item_w = reinterpret_cast<unsigned short *>(ws + lay.item_w);
+        a.views_pad = lay.views_pad;
         const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s);
         if (e != hipSuccess) return (int)e;
     }
@@ -1296,8 +1355,18 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
     hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(kWave), 0, s, a);
     int st = (int)hipGetLastError();
     if (st) return st;
-    hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, s, a.live[0], a.live[n_scales > 1 ? 1 : 0], a.live[n_scales > 2 ? 2 : 0],
-                       a.overflow[0], a.overflow[n_scales > 1 ? 1 : 0], a.overflow[n_scales > 2 ? 2 : 0], n_scales, lay.n_tiles, n_views >= 32 ? 0xffffffffu : ((1u << n_views) - 1u), reinterpret_cast<int *>(ws + lay.chunks), reinterpret_cast<int *>(ws + lay.ranks));
+    {
+        ChunkArgs ca;
+        for (int k = 0; k < kMaxScales; ++k) {
+            const int q = k < n_scales ? k : 0;
+            ca.live[k] = a.live[q]; ca.overflow[k] = a.overflow[q];
+        }
+        ca.n_scales = n_scales; ca.n_tiles = lay.n_tiles; ca.n_views = n_views; ca.views_pad = lay.views_pad;
+        ca.item_w = reinterpret_cast<const unsigned short *>(ws + lay.item_w);
+        ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
+        ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);
+        hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, s, ca);
+    }
     st = (int)hipGetLastError();
     if (st) return st;
     if (weights) {
