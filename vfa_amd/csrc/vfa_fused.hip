@@ -246,25 +246,48 @@ struct ChunkArgs {
     int n_scales, n_tiles, n_views, views_pad;
     int *chunk_start, *chunk_rank;
 };
+template <int G> struct TileItemsT { unsigned m[kMaxScales]; uint4 q[kMaxScales][G]; }; // item masks and their cost estimates (8 views per uint4)
+// G = 1: up to 8 views, the first two tiles of a thread cached in registers; G = 4: up to 32 views, tiles re-read for the second walk
+template <int G>
 __global__ __launch_bounds__(1024) void tile_chunks_kernel(ChunkArgs a)
 {
+    using TileItems = TileItemsT<G>;
+    constexpr bool kCache = G == 1;
     __shared__ unsigned long long part[1024];
     const int tid = threadIdx.x, n_tiles = a.n_tiles;
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
     const int per = (n_tiles + 1023) / 1024, t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
     constexpr unsigned kScale = 110, kTile = 380, kEmpty = 16;
-    // walks the items of tile t in kernel order; `visit(k, w0, w1)`: item k covers the positions [w0, w1) of the tile's weight.
-    // The weights of eight views come with one 16-byte load.
-    auto walk = [&](int t, auto &&visit) -> unsigned {
+    // This kernel runs beside the bandwidth-bound integral-image kernels, where every dependent memory round trip costs
+    // microseconds: everything a tile needs is requested at once and -- for the first two tiles of a thread, i.e. all of
+    // them up to 2048 tiles -- kept in registers for the second walk.
+    auto load_tile = [&](int t) {
+        TileItems ti;
+#pragma unroll
+        for (int s = 0; s < kMaxScales; ++s) {
+            unsigned lv = 0, ov = 0;
+            if (s < a.n_scales) { lv = a.live[s][t]; ov = a.overflow[s][t]; }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                ti.q[s][g] = make_uint4(0u, 0u, 0u, 0u);
+                if (s < a.n_scales && g * 8 < a.n_views)
+                    ti.q[s][g] = *reinterpret_cast<const uint4 *>(a.item_w + ((size_t)t * kMaxScales + s) * a.views_pad + 8 * g);
+            }
+            ti.m[s] = lv & ~ov & view_mask; // (the items of the main launch: live, minus the direct ones without a row slot)
+        }
+        return ti;
+    };
+    // walks the items of a tile in kernel order; `visit(k, w0, w1)`: item k covers the positions [w0, w1) of the tile's weight
+    auto walk = [&](const TileItems &ti, auto &&visit) -> unsigned {
         unsigned w = 0;
         int k = 0;
-        for (int s = 0; s < a.n_scales; ++s) {
-            const unsigned m = a.live[s][t] & ~a.overflow[s][t] & view_mask; // (the items of the main launch)
+#pragma unroll
+        for (int s = 0; s < kMaxScales; ++s) {
             bool first = true;
-            for (int g = 0; g * 8 < a.n_views; ++g) {
-                unsigned mg = (m >> (8 * g)) & 0xffu;
-                if (!mg) continue;
-                const uint4 q = *reinterpret_cast<const uint4 *>(a.item_w + ((size_t)t * kMaxScales + s) * a.views_pad + 8 * g);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                unsigned mg = (ti.m[s] >> (8 * g)) & 0xffu;
+                const uint4 q = ti.q[s][g];
                 const unsigned long long lo = (unsigned long long)q.x | ((unsigned long long)q.y << 32), hi = (unsigned long long)q.z | ((unsigned long long)q.w << 32);
                 while (mg) {
                     const int v = __builtin_ctz(mg);
@@ -281,10 +304,14 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(ChunkArgs a)
         }
         return k == 0 ? kEmpty : w;
     };
+    TileItems c0 = {}, c1 = {};
+    if (kCache && t0 < t1) c0 = load_tile(t0);
+    if (kCache && t0 + 1 < t1) c1 = load_tile(t0 + 1);
+    auto tile_of = [&](int t) { return (kCache && t == t0) ? c0 : (kCache && t == t0 + 1) ? c1 : load_tile(t); };
     unsigned long long local = 0;
-    for (int t = t0; t < t1; ++t) local += walk(t, [](int, unsigned, unsigned) {});
+    for (int t = t0; t < t1; ++t) local += walk(tile_of(t), [](int, unsigned, unsigned) {});
     part[tid] = local;
-    for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_tiles; a.chunk_rank[c] = 0; }
+    for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_tiles; a.chunk_rank[c] = 0; } // (positions beyond the last tile)
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) { // inclusive Hillis-Steele scan
         const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
@@ -294,36 +321,31 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(ChunkArgs a)
     }
     const unsigned long long total = part[1023];
     unsigned long long before = part[tid] - local; // weight of all tiles in front of tile t
+    auto pos_of = [&](long long cc) { return (total * (unsigned long long)cc + kChunks - 1) / kChunks; };
     // chunk c starts at position p_c = ceil(total c / kChunks): at the item of tile t whose weight interval holds p_c - before(t)
     // (a position inside an item's interval rounds to the nearer end; the end of the last item = the next tile's beginning).
-    // The cuts of a tile are found in ONE walk: they come in increasing position.
+    // The cuts of a tile are found in ONE walk: they come in increasing position.  A chunk index falls into one
+    // tile's interval at most (stores of different threads never meet).
     for (int t = t0; t < t1; ++t) {
         const unsigned long long tb = before;
         long long c = tb > 0 ? (long long)((tb - 1) * kChunks / total) : 0; // p_c >= before  <=>  c > (before - 1) K / total
-        auto pos_of = [&](long long cc) { return (total * (unsigned long long)cc + kChunks - 1) / kChunks; };
         while (c < kChunks && pos_of(c) < tb) ++c;
+        const TileItems ti = tile_of(t);
         int n_items = 0;
-        const unsigned w = walk(t, [&](int kk, unsigned w0, unsigned w1) {
-            n_items = kk + 1;
+        walk(ti, [&](int kk, unsigned, unsigned) { n_items = kk + 1; });
+        const unsigned w = walk(ti, [&](int kk, unsigned w0, unsigned w1) {
             while (c < kChunks) {
                 const unsigned long long pc = pos_of(c);
                 if (pc >= tb + w1) break;
                 // (pc >= tb + w0: the cuts in front of this item were taken by its predecessors)
-                const unsigned pos = (unsigned)(pc - tb);
-                const int k = (pos - w0) * 2 < (w1 - w0) ? kk : kk + 1;
-                a.chunk_start[c] = t; a.chunk_rank[c] = k; // (k == number of items: fixed below)
+                const int k = ((unsigned)(pc - tb) - w0) * 2 < (w1 - w0) ? kk : kk + 1;
+                if (k >= n_items) { a.chunk_start[c] = t + 1 < n_tiles ? t + 1 : n_tiles; a.chunk_rank[c] = 0; } // = the next tile's beginning
+                else { a.chunk_start[c] = t; a.chunk_rank[c] = k; }
                 ++c;
             }
         });
-        if (n_items == 0) {
+        if (n_items == 0)
             for (; c < kChunks && pos_of(c) < tb + w; ++c) { a.chunk_start[c] = t; a.chunk_rank[c] = 0; }
-        } else {
-            // cuts that rounded to the end of the last item are the next tile's beginning (these are the last cuts of the tile)
-            for (long long cc = c - 1; cc >= 0 && a.chunk_start[cc] == t && a.chunk_rank[cc] >= n_items; --cc) {
-                a.chunk_start[cc] = t + 1 < n_tiles ? t + 1 : n_tiles;
-                a.chunk_rank[cc] = 0;
-            }
-        }
         before += w;
     }
 }
@@ -1365,7 +1387,8 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
         ca.item_w = reinterpret_cast<const unsigned short *>(ws + lay.item_w);
         ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
         ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);
-        hipLaunchKernelGGL(tile_chunks_kernel, dim3(1), dim3(1024), 0, s, ca);
+        if (n_views <= 8) hipLaunchKernelGGL(tile_chunks_kernel<1>, dim3(1), dim3(1024), 0, s, ca);
+        else hipLaunchKernelGGL(tile_chunks_kernel<4>, dim3(1), dim3(1024), 0, s, ca);
     }
     st = (int)hipGetLastError();
     if (st) return st;

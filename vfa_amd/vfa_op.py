@@ -121,7 +121,7 @@ _side_streams = {}
 def _side_stream(dev):
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=dev)
+        _side_streams[key] = torch.cuda.Stream(device=dev, priority=-1)  # its small kernels go in front of the queued integral-image blocks
     return _side_streams[key]
 
 
