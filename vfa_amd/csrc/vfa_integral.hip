@@ -100,6 +100,8 @@ __global__ __launch_bounds__(256) void cols_batched_kernel(MapArgs a, unsigned l
 {
     unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
+    // columns are taken in the REVERSE of the order the row pass wrote them: what it wrote last is still in the memory-side cache
+    i = total - 1 - i;
     int mi = 0;
     while (mi + 1 < a.n_maps && i >= a.m[mi].col_vecs) { i -= a.m[mi].col_vecs; ++mi; }
     const MapDesc &m = a.m[mi];
