@@ -865,14 +865,16 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         if (!(dbg & kDbgNoMfma)) {
             int key2 = key, fb = frag_base; // (opaque: keeps the 16 swizzled fragment offsets out of long-lived registers)
             asm volatile("" : "+v"(key2), "+v"(fb));
-            const unsigned char *pa = s_planes + fb;
+            // The A fragments run two k-steps ahead of the MFMAs.  Their LDS reads and the waits for them are written in
+            // assembly: LDS reads return in order, so `lgkmcnt(4)` = everything but the two youngest pairs has arrived, but
+            // whenever the compiler's own bookkeeping needs a wait here it emits `lgkmcnt(0)` -- a drain that includes the
+            // reads just issued -- in 5 of the 14 steps (with or without the explicit counted waits next to it).  The reads
+            // are invisible to it this way; the `sched_barrier`s keep its MFMAs behind the hand-written waits.
+            const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)s_planes + (unsigned)fb;
             auto frags = [&](int k, bf16x8 &hh, bf16x8 &ll) {
-                const int off = (k ^ (key2 >> 1)) << 5;
-                hh = *reinterpret_cast<const bf16x8 *>(pa + off);
-                ll = *reinterpret_cast<const bf16x8 *>(pa + kPlane + off);
+                const unsigned addr = pa + (unsigned)((k ^ (key2 >> 1)) << 5);
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(hh), "=&v"(ll) : "v"(addr), "n"(kPlane));
             };
-            // the A fragments run two k-steps ahead of the MFMAs (LDS reads return in order: `lgkmcnt(4)` = everything but
-            // the two youngest pairs has arrived; left alone the compiler drains the queue, reads just issued included)
             bf16x8 fh[3], fl[3];
             frags(0, fh[0], fl[0]);
             frags(1, fh[1], fl[1]);
@@ -881,9 +883,11 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                 one_fill(k); // (wave-uniform branch; nothing to issue once the wave's share is on its way)
                 if (k + 2 < kSteps) {
                     frags(k + 2, fh[(k + 2) % 3], fl[(k + 2) % 3]);
-                    __builtin_amdgcn_s_waitcnt(0xc47f); // lgkmcnt(4)
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fh[k % 3]), "+v"(fl[k % 3]));
                 } else if (k + 1 < kSteps) {
-                    __builtin_amdgcn_s_waitcnt(0xc27f); // lgkmcnt(2)
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[k % 3]), "+v"(fl[k % 3]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[k % 3]), "+v"(fl[k % 3]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[k % 3], w[k].lo, acc, 0, 0, 0);
