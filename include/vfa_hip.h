@@ -71,6 +71,11 @@ int vfa_abi_version(void);
 /* vfa_pool_collapse_relu_sum_f32 only, DIAGNOSTIC: bits 16-27 select a profiling build of the kernel (phase ablations,
  * in-kernel cycle stamps written behind the records in the workspace); its results are meaningless.  tools/ use it. */
 #define VFA_FLAG_DEBUG(mask) (((mask) & 0xfff) << 16)
+/* vfa_pool_collapse_relu_sum_f32 only: the entry point in two calls -- first ROWS_ONLY (the pre-pass over the direct items: needs
+ * the box records of the frame, not its work cuts), later SKIP_ROWS (everything else).  Lets a caller that computes the geometry
+ * on a second stream wait for vfa_frame_boxes_f32 before the first call and for vfa_frame_cuts_f32 only before the second. */
+#define VFA_FLAG_ROWS_ONLY (1 << 28)
+#define VFA_FLAG_SKIP_ROWS (1 << 29)
 /* `flags` of vfa_project_gather_backward_f32: bit 0 = accumulate into grad_integral (otherwise it is zeroed first);
  * VFA_VOX_KERNEL_DIRECT selects the per-box atomic kernel instead of the LDS-privatised one (C = 256). */
 #define VFA_BWD_ACCUMULATE 1
@@ -231,6 +236,14 @@ int vfa_frame_workspace_layout(int n_views, int L, int W, int n_scales, size_t *
 int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
                           int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
                           const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream);
+/* The same in two calls (vfa_frame_records_f32 = boxes, then cuts): vfa_frame_boxes_f32 projects the boxes and writes records,
+ * headers, masks and the list of direct items; vfa_frame_cuts_f32 forms the work cuts of the persistent kernel from them and
+ * splits the collapse weights (`weights` NULL: left as they are in the workspace).                 replaces vfa_op.py:64-106 */
+int vfa_frame_boxes_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
+                        int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
+                        const int *feat_hw, void *workspace, size_t workspace_bytes, void *stream);
+int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *const *weights, void *workspace, size_t workspace_bytes,
+                       void *stream);
 /* Box pooling alone from the same workspace: vox (n_views, L * W, 256) fp32, BIT-IDENTICAL to vfa_project_gather_f32 (layer-major,
  * nl = 1): four bilinear samples of the integral image of scale `scale`, (((lt + rb) - rt) - lb) / area * visible.
  *                                                                                            replaces vfa_op.py:112-120

@@ -413,6 +413,60 @@ def test_direct_items_without_a_row_slot_take_the_second_launch(row_slots):
     torch.testing.assert_close(outs[row_slots], outs[None], rtol=RTOL, atol=2 * ATOL_REL * scale)
 
 
+def test_two_call_forms_of_the_entry_points_are_bitwise_the_one_call_forms():
+    """`vfa_frame_boxes_f32` + `vfa_frame_cuts_f32` leave the workspace `vfa_frame_records_f32` leaves, and the fused entry point
+    called as ROWS_ONLY then SKIP_ROWS gives the map of the single call -- the form `fused_frame` uses to wait for the boxes and for
+    the work cuts separately.  A scene with direct items (a camera inside the field), so that the pre-pass has work."""
+    import vfa_amd
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import look_at_camera
+    from vfa_amd.utils import make_grid
+    dev = _dev()
+    image_size = (720, 1280)
+    calibs = torch.tensor(np.stack([look_at_camera((1500.0, 1700.0, 250.0), (2600.0, 2300.0, 0.0), 700.0, (1280, 720)),
+                                    look_at_camera((300.0, 300.0, 200.0), (1800.0, 1900.0, 0.0), 500.0, (1280, 720))]),
+                          dtype=torch.float32).to(dev)
+    grid = make_grid(world_size=(3750, 3750), cube_LW=[150.0, 150.0], dataset="MultiviewC").to(dev)
+    L, W = grid.shape[:2]
+    args = SimpleNamespace(data="MultiviewC", image_size=image_size)
+    gen = torch.Generator().manual_seed(12)
+    lats = [torch.relu(torch.randn(2, 256, h, w, generator=gen)).to(dev) for h, w in ((90, 160), (45, 80), (23, 40))]
+    torch.manual_seed(6)
+    mods = [vfa_amd.VFA(256, grid_height=300, cube_size=(150.0, 150.0, 300), args=args).to(dev) for _ in range(3)]
+    zl, co = mods[0]._kernel_geometry(dev)
+    sizes = [tuple(l.shape[-2:]) for l in lats]
+    weights = [m.layer_major_weight() for m in mods]
+    biases = [m.collapse.bias for m in mods]
+    kind = _lib.CONV_KIND["MultiviewC"]
+    lay = ops.frame_workspace_layout(2, L, W, 3)
+    nt, K = lay["tiles_l"] * lay["tiles_w"], lay["n_chunks"]
+    one = torch.zeros(lay["total"], dtype=torch.uint8, device=dev)
+    two = torch.zeros(lay["total"], dtype=torch.uint8, device=dev)
+    ops.frame_records(calibs, grid, zl, co, kind, image_size[::-1], sizes, weights=weights, workspace=one)
+    ops.frame_records(calibs, grid, zl, co, kind, image_size[::-1], sizes, workspace=two, cuts=False)
+    assert not two[lay["chunks"]:lay["chunks"] + 4 * (K + 1)].any(), "the boxes call must not write the cuts"
+    ops.frame_cuts(two, 2, (L, W), 3, weights=weights)
+    torch.cuda.synchronize()
+    # (the order in which direct items get their row slots is arbitrary: compare what does not name a slot)
+    sizes_of = {"live": nt * 4, "direct": nt * 4, "overflow": nt * 4, "recs": 2 * nt * 32 * 96, "wfrag": 8 * 16 * 2 * 64 * 16}
+    for key, nbytes in sizes_of.items():
+        for s in range(3):
+            assert torch.equal(one[lay[key][s]:lay[key][s] + nbytes], two[lay[key][s]:lay[key][s] + nbytes]), (key, s)
+    for key in ("chunks", "ranks"):
+        assert torch.equal(one[lay[key]:lay[key] + 4 * (K + 1)], two[lay[key]:lay[key] + 4 * (K + 1)]), key
+    assert int(one[lay["counter"]:lay["counter"] + 4].cpu().numpy().view(np.uint32)[0]) > 5, "the scene should have direct items"
+    integrals = ops.integral_images(lats)
+    with torch.no_grad():
+        ref = ops.pool_collapse(integrals, biases, one, (L, W))
+        assert ops.pool_collapse(integrals, biases, two, (L, W), stage="rows") is None
+        got = ops.pool_collapse(integrals, biases, two, (L, W), stage="main")
+    assert torch.equal(got, ref)
+    with pytest.raises(_lib.VFAHipError):  # both stage flags at once
+        _lib.call("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array([None] * 3), _lib.ptr(two), two.numel(),
+                  _lib.ptr(got), 2, L, W, 3, _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)]), 0,
+                  _lib.FLAG_ROWS_ONLY | _lib.FLAG_SKIP_ROWS, _lib.current_stream_handle())
+
+
 @pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 7, None), ("multiviewc_200x200x1", 2, (21, 40)), ("multiviewc_200x200x1", 1, (3, 5))])
 def test_work_cuts_cover_every_item_once(name, n_cam, crop):
     """`tile_chunks_kernel`: the n_chunks + 1 cuts (tile, rank) of the item sequence are monotonic, start at (0, 0), end at (n_tiles, 0),

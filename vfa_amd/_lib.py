@@ -16,6 +16,9 @@ VOX_KERNEL_DIRECT, VOX_KERNEL_TAP_CACHE = 0x100, 0x200
 BWD_ACCUMULATE = 1
 
 
+FLAG_ROWS_ONLY, FLAG_SKIP_ROWS = 1 << 28, 1 << 29  # VFA_FLAG_ROWS_ONLY / VFA_FLAG_SKIP_ROWS (vfa_pool_collapse_relu_sum_f32)
+
+
 def collapse_flags(terms=0, reserved_cus=0):
     """`flags` of the MFMA collapse entry points: product terms (0 = default 3) | VFA_FLAG_RESERVED_CUS(n)."""
     return (int(terms) & 0xf) | ((int(reserved_cus) & 0xff) << 8)
@@ -55,6 +58,9 @@ SIGNATURES = {
     "vfa_frame_workspace_layout": [_c_int, _c_int, _c_int, _c_int, _vp, _vp],
     "vfa_frame_records_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
                               _c_int, _vp, _vp, _vp, _c_size_t, _vp],
+    "vfa_frame_boxes_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
+                            _c_int, _vp, _vp, _c_size_t, _vp],
+    "vfa_frame_cuts_f32": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_size_t, _vp],
     "vfa_pool_windows_f32": [_vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_pool_collapse_relu_sum_f32": [_vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
                                        _vp],

@@ -1340,9 +1340,9 @@ int vfa_frame_workspace_layout(int n_views, int L, int W, int n_scales, size_t *
     return 0;
 }
 
-int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
-                          int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
-                          const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream)
+int vfa_frame_boxes_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
+                        int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
+                        const int *feat_hw, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales || conv_kind < 0 || conv_kind > 2 || !feat_hw)
         return VFA_ERR_BAD_ARGUMENT;
@@ -1366,35 +1366,42 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
         a.hdrs[k] = ws + lay.hdrs[k];
         a.recs[k] = ws + lay.recs[k];
     }
-    // a single entry point = few launches: one memset (all view masks), the records kernel (which also clears the spare
-    // record behind each scale's table), the chunk boundaries, one weight-split launch
-    {
-        a.row_counter = reinterpret_cast<unsigned *>(ws + lay.counter);
-        a.rows_cap = (unsigned)rows_cap_of(lay, workspace_bytes);
-        a.row_list = reinterpret_cast<unsigned *>(ws + lay.row_list);
-        a.item_w = reinterpret_cast<unsigned short *>(ws + lay.item_w);
-        a.views_pad = lay.views_pad;
-        const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s);
-        if (e != hipSuccess) return (int)e;
-    }
+    // one memset (all view masks) and the records kernel (which also clears the spare record behind each scale's table)
+    a.row_counter = reinterpret_cast<unsigned *>(ws + lay.counter);
+    a.rows_cap = (unsigned)rows_cap_of(lay, workspace_bytes);
+    a.row_list = reinterpret_cast<unsigned *>(ws + lay.row_list);
+    a.item_w = reinterpret_cast<unsigned short *>(ws + lay.item_w);
+    a.views_pad = lay.views_pad;
+    const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s);
+    if (e != hipSuccess) return (int)e;
     const long long pairs = (long long)n_views * lay.n_tiles;
     hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(kWave), 0, s, a);
-    int st = (int)hipGetLastError();
-    if (st) return st;
-    {
-        ChunkArgs ca;
-        for (int k = 0; k < kMaxScales; ++k) {
-            const int q = k < n_scales ? k : 0;
-            ca.live[k] = a.live[q]; ca.overflow[k] = a.overflow[q];
-        }
-        ca.n_scales = n_scales; ca.n_tiles = lay.n_tiles; ca.n_views = n_views; ca.views_pad = lay.views_pad;
-        ca.item_w = reinterpret_cast<const unsigned short *>(ws + lay.item_w);
-        ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
-        ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);
-        if (n_views <= 8) hipLaunchKernelGGL(tile_chunks_kernel<1>, dim3(1), dim3(1024), 0, s, ca);
-        else hipLaunchKernelGGL(tile_chunks_kernel<4>, dim3(1), dim3(1024), 0, s, ca);
+    return (int)hipGetLastError();
+}
+
+int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *const *weights, void *workspace, size_t workspace_bytes,
+                       void *stream)
+{
+    if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales) return VFA_ERR_BAD_ARGUMENT;
+    if (n_views > 32) return VFA_ERR_UNSUPPORTED;
+    const WorkspaceLayout lay = layout_of(n_views, L, W, n_scales);
+    if (lay.n_tiles == 0 || n_views == 0) return 0;
+    if (!workspace || workspace_bytes < lay.rows) return VFA_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    ChunkArgs ca;
+    for (int k = 0; k < kMaxScales; ++k) {
+        const int q = k < n_scales ? k : 0;
+        ca.live[k] = reinterpret_cast<const unsigned *>(ws + lay.live[q]);
+        ca.overflow[k] = reinterpret_cast<const unsigned *>(ws + lay.overflow[q]);
     }
-    st = (int)hipGetLastError();
+    ca.n_scales = n_scales; ca.n_tiles = lay.n_tiles; ca.n_views = n_views; ca.views_pad = lay.views_pad;
+    ca.item_w = reinterpret_cast<const unsigned short *>(ws + lay.item_w);
+    ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
+    ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);
+    if (n_views <= 8) hipLaunchKernelGGL(tile_chunks_kernel<1>, dim3(1), dim3(1024), 0, s, ca);
+    else hipLaunchKernelGGL(tile_chunks_kernel<4>, dim3(1), dim3(1024), 0, s, ca);
+    int st = (int)hipGetLastError();
     if (st) return st;
     if (weights) {
         SplitArgs sa;
@@ -1405,9 +1412,19 @@ int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z
         }
         hipLaunchKernelGGL(split_weight_frag_kernel, dim3(8 * kSteps * 64 / 256, n_scales), dim3(256), 0, s, sa);
         st = (int)hipGetLastError();
-        if (st) return st;
     }
-    return 0;
+    return st;
+}
+
+// a single entry point = few launches: boxes (memset + records kernel), then the work cuts and one weight-split launch
+int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
+                          int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
+                          const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int st = vfa_frame_boxes_f32(calibs, grid, z_layers, corner_off, n_views, L, W, conv_kind, img_w, img_h, cmin, cmax, n_scales, feat_hw,
+                                       workspace, workspace_bytes, stream);
+    if (st) return st;
+    return vfa_frame_cuts_f32(n_views, L, W, n_scales, weights, workspace, workspace_bytes, stream);
 }
 
 int vfa_pool_windows_f32(const float *integral, const void *workspace, size_t workspace_bytes, float *vox, int n_views, int L, int W,
@@ -1450,7 +1467,8 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
                                    int accumulate, int flags, void *stream)
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xfff;
-    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00)) return VFA_ERR_BAD_ARGUMENT;
+    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00 | VFA_FLAG_ROWS_ONLY | VFA_FLAG_SKIP_ROWS)) return VFA_ERR_BAD_ARGUMENT;
+    if ((flags & VFA_FLAG_ROWS_ONLY) && (flags & VFA_FLAG_SKIP_ROWS)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales || !feat_hw || !integrals ||
         (terms != 0 && terms != 3 && terms != 4))
         return VFA_ERR_BAD_ARGUMENT;
@@ -1502,7 +1520,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     a.rows = reinterpret_cast<const float *>(ws + lay.rows);
     a.row_counter = reinterpret_cast<const unsigned *>(ws + lay.counter);
     a.rows_cap = rows_cap;
-    if (!(debug & 64)) { // pre-pass: pooled rows of the direct items (a block leaves at once where its tile has none)
+    if (!(debug & 64) && !(flags & VFA_FLAG_SKIP_ROWS)) { // pre-pass: pooled rows of the direct items (a block leaves at once where its tile has none)
         RowsArgs ra;
         for (int k = 0; k < kMaxScales; ++k) {
             ra.integral[k] = a.sc[k].integral; ra.recs[k] = a.sc[k].recs;
@@ -1515,7 +1533,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
         ra.flags = a.flags;
         hipLaunchKernelGGL(pool_rows_kernel, dim3(1024), dim3(512), 0, s, ra);
         const int st0 = (int)hipGetLastError();
-        if (st0) return st0;
+        if (st0 || (flags & VFA_FLAG_ROWS_ONLY)) return st0;
     }
     if (debug & 64) { // diagnostic: only the second launch (direct items without a row slot)
         hipLaunchKernelGGL((pool_collapse_kernel<3, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);

@@ -50,7 +50,8 @@ class KernelTimer:
 
 def _launch(name, *args, tag=None):
     kt = KernelTimer.active
-    if kt is None or (kt.only is not None and name not in kt.only):
+    # (the "rows" pre-pass call of the two-stage fused entry point is left untimed: the timed call is the persistent kernel)
+    if kt is None or (kt.only is not None and name not in kt.only) or (isinstance(tag, tuple) and tag and tag[-1] == "rows"):
         _lib.call(name, *args)
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -346,11 +347,13 @@ def collapse_gemm(vox2d, weight, out=None, terms=0, reserved_cus=0):
 
 
 def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_hws, weights=None, crange=(-1, 0.95),
-                  workspace=None, row_slots=None):
+                  workspace=None, row_slots=None, cuts=True):
     """Geometry of one frame for the fused inference kernel (``pool_collapse``): box records of every (view, cell) for each
     feature scale + the split collapse weights -> workspace tensor (reference vfa_op.py:64-106, set-up of :112-115).
 
-    calibs (n,3,4), grid (L,W,3) or (1,L,W,3), feat_hws = [(Hf,Wf), ...] (1..3 scales), weights = one (256,256) per scale."""
+    calibs (n,3,4), grid (L,W,3) or (1,L,W,3), feat_hws = [(Hf,Wf), ...] (1..3 scales), weights = one (256,256) per scale.
+    ``cuts=False``: only the boxes (``vfa_frame_boxes_f32``: what the pre-pass of ``pool_collapse`` needs); ``frame_cuts`` then
+    adds the work cuts and the weight split."""
     _lib.require_device(calibs, grid, z_layers, corner_off)
     grid = _f32c(grid.reshape(grid.shape[-3], grid.shape[-2], 3))
     L, W = grid.shape[:2]
@@ -374,32 +377,53 @@ def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_
         assert len(weights) == ns and all(tuple(w.shape) == (256, 256) for w in weights)
         _lib.require_device(*weights)
         wts = _lib.ptr_array(weights)
+    if not cuts:
+        _launch("vfa_frame_boxes_f32", _lib.ptr(calibs), _lib.ptr(grid), _lib.ptr(z_layers), _lib.ptr(corner_off), n, L, W,
+                int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), ns, hw,
+                _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(), tag=(n, L, W, ns))
+        return workspace
     _launch("vfa_frame_records_f32", _lib.ptr(calibs), _lib.ptr(grid), _lib.ptr(z_layers), _lib.ptr(corner_off), n, L, W,
             int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), ns, hw, wts,
             _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(), tag=(n, L, W, ns))
     return workspace
 
 
-def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0):
+def frame_cuts(workspace, n_views, grid_lw, n_scales, weights=None):
+    """Second half of ``frame_records(..., cuts=False)``: the work cuts of the persistent kernel + the split collapse weights."""
+    _lib.require_device(workspace)
+    wts = None
+    if weights is not None:
+        weights = [_f32c(w) for w in weights]
+        assert len(weights) == n_scales and all(tuple(w.shape) == (256, 256) for w in weights)
+        _lib.require_device(*weights)
+        wts = _lib.ptr_array(weights)
+    _launch("vfa_frame_cuts_f32", int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_scales), wts, _lib.ptr(workspace),
+            workspace.numel(), _lib.current_stream_handle(), tag=(int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_scales)))
+    return workspace
+
+
+def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0, stage="all"):
     """out (L*W, 256) (+)= sum_scale sum_view relu(vox . W^T + b): pooling + collapse + ReLU + view / scale sum in one
     persistent kernel, the voxel features never touch HBM (reference vfa_op.py:112-125, vfanet.py:79, 82).
 
     integrals = one (n, Hf+2, Wf+2, 256) zero-bordered channels-last integral image per scale (``integral_image``);
-    workspace = ``frame_records`` of the same frame."""
+    workspace = ``frame_records`` of the same frame.  ``stage``: "all", or the entry point in two calls -- "rows" (the pre-pass
+    over the direct items: needs only the boxes of the frame; returns None) and later "main" (everything else)."""
     _lib.require_device(*integrals, workspace, out)
+    stage_flag = {"all": 0, "rows": _lib.FLAG_ROWS_ONLY, "main": _lib.FLAG_SKIP_ROWS}[stage]
     ns = len(integrals)
     n = integrals[0].shape[0]
     L, W = grid_lw
     assert all(i.shape[0] == n and i.shape[3] == 256 and i.is_contiguous() and i.dtype == torch.float32 for i in integrals)
-    if out is None:
+    if out is None and stage != "rows":
         out = torch.empty((L * W, 256), dtype=torch.float32, device=integrals[0].device)
         accumulate = False
     biases = [None if b is None else _f32c(b) for b in (biases if biases is not None else [None] * ns)]
     hw = _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)])
     _launch("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array(biases), _lib.ptr(workspace),
-            workspace.numel(), _lib.ptr(out), n, L, W, ns, hw, 1 if accumulate else 0,
-            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16),  # debug: diagnostic build, tools/ only
-            _lib.current_stream_handle(), tag=(n, L, W, tuple((i.shape[1] - 2, i.shape[2] - 2) for i in integrals)))
+            workspace.numel(), _lib.ptr(out) if out is not None else None, n, L, W, ns, hw, 1 if accumulate else 0,
+            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16) | stage_flag,  # debug: diagnostic build, tools/ only
+            _lib.current_stream_handle(), tag=(n, L, W, tuple((i.shape[1] - 2, i.shape[2] - 2) for i in integrals), stage))
     return out
 
 

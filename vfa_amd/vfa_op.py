@@ -161,14 +161,31 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
         ws = torch.empty(max(_lib.lib().vfa_frame_workspace_bytes(calibs.shape[0], length, width, len(mods)), 1),
                          dtype=torch.uint8, device=dev)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h),
-                              [tuple(f.shape[-2:]) for f in features], weights=weights, crange=crange, workspace=ws)
+        feat_hws = [tuple(f.shape[-2:]) for f in features]
+        if side is cur:
+            ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h), feat_hws, weights=weights,
+                              crange=crange, workspace=ws)
+            boxes_done = None
+        else:
+            # two joins: the pre-pass over the direct items needs the boxes only; the work cuts (a single-workgroup kernel that
+            # is slow beside the bandwidth-bound integral images) are waited for one kernel later
+            with torch.cuda.stream(side):
+                ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h), feat_hws, crange=crange,
+                                  workspace=ws, cuts=False)
+                boxes_done = torch.cuda.Event()
+                boxes_done.record(side)
+                ops.frame_cuts(ws, calibs.shape[0], (length, width), len(mods), weights=weights)
         if integrals is None:
             integrals = ops.integral_images(features)  # all strides in one launch pair
+        biases = [m.collapse.bias for m in mods]
+        if boxes_done is None:
+            return ops.pool_collapse(integrals, biases, ws, (length, width), out=out, accumulate=accumulate, terms=COLLAPSE_TERMS,
+                                     reserved_cus=reserved_cus)
+        cur.wait_event(boxes_done)
+        ops.pool_collapse(integrals, biases, ws, (length, width), terms=COLLAPSE_TERMS, reserved_cus=reserved_cus, stage="rows")
         cur.wait_stream(side)
-        return ops.pool_collapse(integrals, [m.collapse.bias for m in mods], ws, (length, width), out=out,
-                                 accumulate=accumulate, terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
+        return ops.pool_collapse(integrals, biases, ws, (length, width), out=out, accumulate=accumulate, terms=COLLAPSE_TERMS,
+                                 reserved_cus=reserved_cus, stage="main")
 
 
 def window_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0):
