@@ -374,16 +374,19 @@ def main():
     leg.step()  # one-off set-up outside warm-up and timing: kernel selection per problem shape
     leg.drain()
     # Warm-up steps: HIP events around EVERY entry point (the `kernels` table).  Timed steps: only around the roofline
-    # kernel -- each timed launch puts two event records in the queue (~3 us apiece).
+    # kernel, sampled -- each timed launch puts two event records in the queue (~3 us apiece).
     with ops.KernelTimer() as kt_warm:
         for _ in range(a.warmup):
             leg.step()
         leg.drain()
         leg.fence()
-    kt = ops.KernelTimer(only=ROOFLINE_ENTRY_POINTS)
+    # (every 8th launch: 25 samples spread over the 200 default steps; timing every launch costs the step ~1 %)
+    kt = ops.KernelTimer(only=ROOFLINE_ENTRY_POINTS, every=8 if a.steps >= 64 else 1)
     dt = leg.timed(a.steps, kt)
     ks = kt.summary()
     roofline = roofline_of(ks, ops, a.workload)
+    if roofline is not None:
+        roofline["sampled"] = f"HIP events around every {kt.every}th launch of the timed region" if kt.every > 1 else "HIP events around every launch of the timed region"
     ks_all = kt_warm.summary() if a.warmup > 0 else ks
     def calls_per_frame(v):  # (the fused entry point is called twice per frame: "rows" pre-pass + the rest; count frames)
         rows = sum(r["launches"] for t, r in v["by_tag"].items() if isinstance(t, tuple) and t and t[-1] == "rows")
