@@ -61,6 +61,7 @@ CASES = [  # workload, cameras, grid crop (rows, cols) or None
     ("multiviewc_200x200x1", None, None),          # the bench frame: 7 cameras x 3 scales, 1250 full tiles
     ("multiviewc_200x200x1", 2, (37, 53)),         # ragged grid: partial tiles on both edges
     ("wildtrack_480x1440x1", 3, (100, 1440)),      # Wildtrack conversion, 1080p maps
+    ("multiviewc_200x200x1", 11, (45, 64)),        # more than 8 cameras: two view groups per tile in the work-cut kernel
 ]
 
 
@@ -467,7 +468,8 @@ def test_two_call_forms_of_the_entry_points_are_bitwise_the_one_call_forms():
                   _lib.FLAG_ROWS_ONLY | _lib.FLAG_SKIP_ROWS, _lib.current_stream_handle())
 
 
-@pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 7, None), ("multiviewc_200x200x1", 2, (21, 40)), ("multiviewc_200x200x1", 1, (3, 5))])
+@pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 7, None), ("multiviewc_200x200x1", 2, (21, 40)), ("multiviewc_200x200x1", 1, (3, 5)),
+                                            ("multiviewc_200x200x1", 13, (60, 90))])
 def test_work_cuts_cover_every_item_once(name, n_cam, crop):
     """`tile_chunks_kernel`: the n_chunks + 1 cuts (tile, rank) of the item sequence are monotonic, start at (0, 0), end at (n_tiles, 0),
     never point behind the last item of a tile, and the pieces between them carry equal estimated COST (the kernel's cost model,
