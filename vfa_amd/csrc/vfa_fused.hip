@@ -398,7 +398,7 @@ __device__ __forceinline__ float4 sample4(float4 nw, float4 ne, float4 sw, float
 }
 // Pooling layout: a wave owns four boxes of the tile and pools them SIDE BY SIDE -- 16 lanes x float4 = 64 channels of one
 // box, four boxes per wave instruction, four channel quarters per item.  Box parameters are per-lane registers (the box
-// record, loaded with ordinary vector loads one item ahead), control flow is the same for every box (always 16 taps: the
+// record, read from the LDS slots behind the tap window, where LDS-DMA put it), control flow is the same for every box (always 16 taps: the
 // duplicates of narrow boxes hit the same LDS words), so the quarter loop is one straight-line body that the compiler
 // software-pipelines.  A 16-lane group reads 256 contiguous bytes of a tap slot: conflict-free for any mix of slots.
 struct LRec { uint4 v[6]; }; // one box record per lane: v[0..3] the 16 tap weights, v[4] rcp, flags, rows; v[5] cols, masked, area
@@ -440,7 +440,7 @@ struct Item { int tile, scale, view; unsigned rest; bool valid; int rank; }; // 
 template <int TERMS, bool DIAG, bool DIRECT>
 __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 {
-    __shared__ float4 s_taps[(kMaxSlots + kRecSlots) * 64];         // 126 KiB: the tap window of the current item + its box records
+    __shared__ float4 s_taps[(kMaxSlots + kRecSlots) * 64];         // 123 + 3 KiB: the tap window of the current item + its box records
     __shared__ __align__(16) unsigned char s_planes[2 * kPlane];    // 32 KiB: bf16 hi / lo planes of the 32 x 256 A tile
     __shared__ uint4 s_hdr[2][16];                                  // tile headers of the next two items (32 B used of each 256)
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
