@@ -376,7 +376,7 @@ struct FusedArgs {
     unsigned long long *diag;       // diagnostic build only: per workgroup 8 cycle counters
 };
 // diagnostic ablations (VFA_FLAG_DEBUG(mask), pool_collapse_kernel<TERMS, true> only)
-constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgOneW = 8, kDbgNoRecords = 16, kDbgStamps = 128; // (64: only the direct-item launch)
+constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgOneW = 8, kDbgNoRecords = 16, kDbgNoExtra = 32, kDbgStamps = 128; // (64: only the direct-item launch)
 
 struct Frag { bf16x8 hi, lo; };
 
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     auto write_tile = [&](int tile, const f32x16 &sum, bool have_sum) {
         const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
         float extra = 0.0f; // fully masked (view, scale) items of this tile: vox = 0 -> relu(bias)
-        if (!DIRECT) {
+        if (!DIRECT && !(DIAG && (a.debug & kDbgNoExtra))) {
 #pragma unroll
             for (int s = 0; s < kMaxScales; ++s)
                 if (s < a.n_scales) extra += (float)(a.n_views - __popc(live_all(tile, s))) * rbias[s];
