@@ -873,7 +873,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)s_planes + (unsigned)fb;
             auto frags = [&](int k, bf16x8 &hh, bf16x8 &ll) {
                 const unsigned addr = pa + (unsigned)((k ^ (key2 >> 1)) << 5);
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(hh), "=&v"(ll) : "v"(addr), "n"(kPlane));
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(hh), "=&v"(ll) : "v"(addr), "n"(kPlane) : "memory");
             };
             bf16x8 fh[3], fl[3];
             frags(0, fh[0], fl[0]);
