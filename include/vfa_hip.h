@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VFA_ABI_VERSION 2
+#define VFA_ABI_VERSION 3
 
 /* world-unit conversion of the grid, reference vfa_op.py:23-44 (chosen by args.data) */
 #define VFA_CONV_MULTIVIEWC 0 /* x / 1.0                                   */
@@ -254,6 +254,43 @@ int vfa_pool_windows_f32(const float *integral, const void *workspace, size_t wo
 int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, const void *workspace,
                                    size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales, const int *feat_hw,
                                    int accumulate, int flags, void *stream);
+
+/* ---- the frame as a producer / consumer pipeline, any number of z-layers (vfa_pipe.hip) ----------------------------------------
+ *
+ * The inference hot path for C = 256 and ANY K = n_layers * 256 (the reference builds collapse = Linear(C * nl -> C),
+ * vfa_op.py:50-59, and every shipped config has nl > 1: vfa/config.py:22-24, 49-52, 77-80):
+ *
+ *   vfa_pipe_boxes_f32     geometry once per frame: every (view, cell, LAYER) cube projected once, a 96-byte box record per scale
+ *                          and a 32-byte tap-window header per (tile, layer, view, scale)        replaces vfa_op.py:64-106
+ *   vfa_pipe_cuts_f32      cost-balanced work cuts + collapse.weight of every scale as bf16 hi / lo MFMA fragments.
+ *                          weights[k]: (256, 256 * n_layers) fp32 in the REFERENCE layout, column = c * n_layers + layer
+ *                          (vfa_op.py:59, :120) -- no host-side permutation
+ *   vfa_pipe_records_f32   both of the above
+ *   vfa_pipe_collapse_relu_sum_f32
+ *                          out (L * W, 256) (+)= sum_scale sum_view relu(vox . W^T + b): one persistent kernel, 12 waves per
+ *                          CU -- four pool boxes (the reference's exact fp32 FMA chains) while eight multiply the previous
+ *                          64 rows x 64 channels on the matrix cores (bf16 two-piece split, 3 products, fp32 accumulation; the
+ *                          accumulators of four views stay in registers across all layers, `relu` follows the whole
+ *                          K = n_layers * 256); the voxel features never reach HBM      replaces vfa_op.py:110-125, vfanet.py:79, 82
+ *
+ * workspace: caller-owned, vfa_pipe_workspace_bytes(); the geometry calls fill it, the kernel reads it (and uses its hand-off
+ * area: a tile cut between two workgroups is finished by whichever arrives last, nobody waits).  integrals[k]: zero-bordered
+ * channels-last (n_views, Hf+2, Wf+2, 256).  n_views <= 32.  flags: VFA_FLAG_TERMS_MASK (0 / 3 = three products, 4 adds lo.lo) |
+ * VFA_FLAG_RESERVED_CUS(n) | VFA_FLAG_DEBUG(mask).  On a single-layer grid the result equals
+ * vfa_pool_collapse_relu_sum_f32 bit for bit. */
+size_t vfa_pipe_workspace_bytes(int n_views, int L, int W, int n_layers, int n_scales);
+int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_scales, size_t *offsets, int *tiles);
+int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off, int n_views,
+                       int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales, const int *feat_hw,
+                       void *workspace, size_t workspace_bytes, void *stream);
+int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, const float *const *weights, void *workspace,
+                      size_t workspace_bytes, void *stream);
+int vfa_pipe_records_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off,
+                         int n_views, int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
+                         const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream);
+int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, void *workspace, size_t workspace_bytes,
+                                   float *out, int n_views, int L, int W, int n_layers, int n_scales, const int *feat_hw, int accumulate,
+                                   int flags, void *stream);
 
 /* ---- consumers of the path ---------------------------------------------------------------------------
  *

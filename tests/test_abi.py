@@ -34,8 +34,8 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(built_lib)
     for name in _declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/vfa_hip.h but not exported"
-    assert lib.vfa_abi_version() == 2
-    assert not hasattr(lib, "vfa_set_option")  # ABI v2: tuning choices are per-call flags, the library keeps no state
+    assert lib.vfa_abi_version() == 3
+    assert not hasattr(lib, "vfa_set_option")  # since ABI v2: tuning choices are per-call flags, the library keeps no state
 
 
 def test_python_binding_covers_every_declared_symbol(built_lib):

@@ -1,0 +1,324 @@
+"""The pipelined per-frame inference path for ANY number of z-layers (``vfa_pipe_records_f32`` +
+``vfa_pipe_collapse_relu_sum_f32``: geometry once per frame; pooling waves and matrix waves side by side in one persistent kernel;
+the accumulators of four views in registers across all layers; vox never in HBM) against the older kernels, float64 from
+bit-pinned voxel features and the CPU oracle.   ``-m gpu``.
+
+Reference lines covered: vfa/model/vfa_op.py:50-59 (collapse = Linear(C * nl -> C)), :61-125 (all of VFA.forward),
+vfa/model/vfanet.py:64-82 (camera loop); shipped layer counts vfa/config.py:22-24, 49-52, 77-80.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL_REL = 1e-4, 1e-5
+PIPE_ENTRY = "vfa_pipe_collapse_relu_sum_f32"
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _mods(wl, dev, seed=1, scale=3.0, n=3):
+    import vfa_amd
+    torch.manual_seed(seed)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+            for _ in range(n)]
+    with torch.no_grad():
+        for m in mods:  # bigger weights and a negative-leaning bias: the ReLU cuts a real share of the outputs
+            m.collapse.weight.mul_(scale)
+            m.collapse.bias.uniform_(-0.3, 0.1)
+    return mods
+
+
+def _float64_reference(mods, lats, calibs, grid, wl, cells=None):
+    """sum_scale sum_view relu(vox . W^T + b) in float64 from the BITWISE-pinned voxel features of the direct pooling kernel
+    (layer-major vox against the layer-major view of collapse.weight)."""
+    from vfa_amd import _lib, ops
+    dev = grid.device
+    n = calibs.shape[0]
+    grid_flat = grid.reshape(-1, 3).contiguous()
+    cells = grid_flat.shape[0] if cells is None else cells
+    want = torch.zeros(cells, 256, dtype=torch.float64, device=dev)
+    for m, lat in zip(mods, lats):
+        zl, co = m._kernel_geometry(dev)
+        vox = ops.project_gather(ops.integral_image(lat), calibs.reshape(n, 12).contiguous(), grid_flat, zl, co,
+                                 _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1], cell_count=cells, kernel="direct")
+        want += torch.relu(vox.double() @ m.layer_major_weight().double().T + m.collapse.bias.double()).sum(0)
+    return want
+
+
+def _check(name, got, want):
+    scale = want.abs().max().item()
+    assert scale > 0
+    tol = RTOL * want.abs() + ATOL_REL * scale
+    worst = ((got.double() - want).abs() / tol).max().item()
+    print(f"[margin] {name}: worst |err| / tolerance = {worst:.3f}")
+    torch.testing.assert_close(got.double(), want, rtol=RTOL, atol=ATOL_REL * scale, msg=lambda m: f"{name}: {m}")
+
+
+def _frame(name, n_cam, crop, dev, seed=3, origin=(11, 5)):
+    from vfa_amd.synthetic import make_workload
+    wl = make_workload(name, channels=256, seed=seed, **({"n_cam": n_cam} if n_cam else {}))
+    n = wl["n_cam"]
+    grid = wl["grid"] if crop is None else wl["grid"][:, origin[0]:origin[0] + crop[0], origin[1]:origin[1] + crop[1]].contiguous()
+    lats = [torch.cat([wl["features"][c][s] for c in range(n)]).to(dev) for s in range(3)]
+    return wl, grid.to(dev), lats, wl["calibs"].to(dev)
+
+
+SINGLE = [  # workload, cameras, grid crop (rows, cols) or None
+    ("multiviewc_200x200x1", None, None),          # the bench frame: 7 cameras (groups of 4 + 3) x 3 scales, 1250 full tiles
+    ("multiviewc_200x200x1", 2, (37, 53)),         # ragged grid, one half-empty group per (tile, scale)
+    ("wildtrack_480x1440x1", 3, (100, 1440)),      # Wildtrack conversion, 1080p maps
+    ("multiviewc_200x200x1", 11, (45, 64)),        # three groups per (tile, scale)
+    ("multiviewc_200x200x1", 8, (16, 24)),         # fewer tiles than workgroups: nearly every tile is shared by two of them
+]
+
+
+@pytest.mark.parametrize("name,n_cam,crop", SINGLE)
+def test_pipe_equals_the_serial_fused_kernel_bit_for_bit_on_single_layer_grids(name, n_cam, crop, monkeypatch):
+    """Same pooling arithmetic, same product sequence (k ascending, lo.hi / hi.hi / hi.lo per k-step), same order of the view and
+    scale sums: on nl = 1 the pipelined kernel must reproduce ``vfa_pool_collapse_relu_sum_f32`` exactly."""
+    import vfa_amd
+    from vfa_amd import ops, vfa_op
+    dev = _dev()
+    wl, grid, lats, calibs = _frame(name, n_cam, crop, dev)
+    mods = _mods(wl, dev)
+    L, W = grid.shape[1:3]
+    with torch.no_grad():
+        monkeypatch.setattr(vfa_op, "PIPE", True)
+        with ops.KernelTimer() as kt:
+            piped = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        torch.cuda.synchronize()
+        assert PIPE_ENTRY in kt.summary() and "vfa_pool_collapse_relu_sum_f32" not in kt.summary(), sorted(kt.summary())
+        monkeypatch.setattr(vfa_op, "PIPE", False)
+        with ops.KernelTimer() as kt:
+            serial = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        torch.cuda.synchronize()
+        assert "vfa_pool_collapse_relu_sum_f32" in kt.summary() and PIPE_ENTRY not in kt.summary(), sorted(kt.summary())
+        monkeypatch.setattr(vfa_op, "PIPE", True)
+        again = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+    assert torch.isfinite(piped).all()
+    p = piped[0].permute(1, 2, 0).reshape(L * W, 256)
+    s = serial[0].permute(1, 2, 0).reshape(L * W, 256)
+    bad = (p != s).any(1).nonzero().flatten()
+    assert bad.numel() == 0, f"{bad.numel()} of {L * W} cells differ, first {bad[:8].tolist()}, max |diff| {(p - s).abs().max().item():.3e}"
+    assert torch.equal(again, piped)  # deterministic, shared tiles included (fixed addition order of the parts)
+
+
+MULTI = [  # workload, cameras, crop, origin
+    ("multiviewc_156x156x5", None, (40, 64), (60, 40)),   # shipped MultiviewC: 5 layers, K = 1280
+    ("wildtrack_120x360x8", 7, (24, 96), (50, 130)),      # shipped Wildtrack: 8 layers, many masked boxes
+    ("multiviewx_160x250x8", 6, (28, 72), (70, 90)),      # shipped MultiviewX: 6 cameras = groups of 4 + 2
+    ("synthetic4k_512x512x32", 3, (12, 40), (250, 240)),  # 32 layers, K = 8192, 4K feature maps
+    ("multiviewc_156x156x5", 1, (21, 35), (10, 100)),     # one camera: every group has one sub-tile
+]
+
+
+@pytest.mark.parametrize("name,n_cam,crop,origin", MULTI)
+def test_pipe_multi_layer_vs_float64_and_the_vox_through_hbm_path(name, n_cam, crop, origin, monkeypatch):
+    import vfa_amd
+    from vfa_amd import ops, vfa_op
+    dev = _dev()
+    wl, grid, lats, calibs = _frame(name, n_cam, crop, dev, origin=origin)
+    mods = _mods(wl, dev)
+    nl = mods[0].num_grid_layer
+    assert nl > 1
+    L, W = grid.shape[1:3]
+    with torch.no_grad():
+        monkeypatch.setattr(vfa_op, "PIPE", True)
+        with ops.KernelTimer() as kt:
+            piped = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        torch.cuda.synchronize()
+        assert PIPE_ENTRY in kt.summary() and "vfa_project_gather_f32" not in kt.summary(), sorted(kt.summary())
+        monkeypatch.setattr(vfa_op, "PIPE", False)
+        with ops.KernelTimer() as kt:
+            older = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        torch.cuda.synchronize()
+        assert PIPE_ENTRY not in kt.summary() and "vfa_project_gather_f32" in kt.summary(), sorted(kt.summary())
+        want = _float64_reference(mods, lats, calibs, grid, wl)
+        monkeypatch.setattr(vfa_op, "PIPE", True)
+        again = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+    p = piped[0].permute(1, 2, 0).reshape(L * W, 256)
+    o = older[0].permute(1, 2, 0).reshape(L * W, 256)
+    assert torch.isfinite(p).all()
+    _check(f"{name} x{nl} pipe vs float64", p, want)
+    _check(f"{name} x{nl} vox-through-HBM path vs float64", o, want)
+    assert torch.equal(again, piped)
+
+
+@pytest.mark.parametrize("data,image_size,cube,gh,world,step,cam", [
+    ("MultiviewC", (720, 1280), (75.0, 75.0, 40), 160, (3750, 3750), (75.0, 75.0), "ring"),       # 4 layers
+    ("MultiviewX", (1080, 1920), (8, 8, 16), 64, (640, 1000), (8, 8), "mx"),                        # 4 layers
+    ("Wildtrack", (1080, 1920), (12, 12, 8), 24, (480, 1440), (12, 12), "wt"),                      # 3 layers
+    ("MultiviewC", (720, 1280), (150.0, 150.0, 100), 300, (3750, 3750), (150.0, 150.0), "inside"),  # 3 layers, huge near boxes
+])
+def test_pipe_vs_oracle_small_multi_layer_scenes(oracle, data, image_size, cube, gh, world, step, cam):
+    """Multi-layer scenes of every dataset conversion against the CPU oracle end to end (oracle voxel features in the
+    reference's column order c * nl + layer, float64 product with collapse.weight as it is): cameras far, near and INSIDE the
+    field (boxes behind the camera, boxes whose tap window does not fit LDS and are pooled from L2, fully masked tiles, views
+    and layers)."""
+    import vfa_amd
+    from vfa_amd.synthetic import look_at_camera, ring_cameras
+    from vfa_amd.utils import make_grid
+    dev = _dev()
+    H, W_img = image_size
+    if cam == "ring":
+        calibs = ring_cameras(5, (1875.0, 1875.0, 0.0), 2700.0, 600.0, 900.0, (W_img, H))
+    elif cam == "inside":
+        calibs = torch.tensor(np.stack([look_at_camera((1500.0, 1700.0, 250.0), (2600.0, 2300.0, 0.0), 700.0, (W_img, H)),
+                                        look_at_camera((300.0, 300.0, 200.0), (1800.0, 1900.0, 0.0), 500.0, (W_img, H))]),
+                              dtype=torch.float32)
+    elif cam == "mx":
+        calibs = torch.tensor(np.stack([look_at_camera((-5.0, 8.0, 3.0), (12.0, 8.0, 0.0), 1700.0, (W_img, H)),
+                                        look_at_camera((30.0, 20.0, 2.5), (12.0, 6.0, 0.0), 1400.0, (W_img, H))]),
+                              dtype=torch.float32)
+    else:
+        wt_c = (480 * 2.5 / 2 - 300.0, 1440 * 2.5 / 2 - 900.0, 0.0)
+        calibs = ring_cameras(3, wt_c, 0.45 * 1440 * 2.5, 400.0, 1100.0, (W_img, H))
+    grid = make_grid(world_size=world, cube_LW=list(step), dataset=data)
+    args = SimpleNamespace(data=data, image_size=image_size)
+    n = calibs.shape[0]
+    gen = torch.Generator().manual_seed(7)
+    sizes = [(45, 80), (23, 40), (12, 20)]
+    lats = [torch.relu(torch.randn(n, 256, h, w, generator=gen)) for h, w in sizes]
+    torch.manual_seed(3)
+    mods = [vfa_amd.VFA(256, grid_height=gh, cube_size=cube, args=args).to(dev) for _ in range(3)]
+    nl = mods[0].num_grid_layer
+    assert nl > 1
+    with torch.no_grad():
+        for m in mods:
+            m.collapse.weight.mul_(3.0)
+            m.collapse.bias.uniform_(-0.3, 0.1)
+        with vfa_amd.ops.KernelTimer() as kt:
+            out = vfa_amd.aggregate_views(*mods, *(l.to(dev) for l in lats), calibs.to(dev), grid.to(dev)[None])
+        torch.cuda.synchronize()
+    assert PIPE_ENTRY in kt.summary()
+    L, W = grid.shape[:2]
+    zl_h, co_h = oracle.z_layers_of(gh, cube), oracle.corner_offsets(cube)
+    want = np.zeros((L * W, 256), np.float64)
+    vis_total = 0
+    for si, m in enumerate(mods):
+        w64 = m.collapse.weight.detach().cpu().double().numpy()
+        b64 = m.collapse.bias.detach().cpu().double().numpy()
+        for c in range(n):
+            f = lats[si][c].numpy()
+            box, area, vis = oracle.box_params(calibs[c].numpy(), grid.reshape(-1, 3).numpy(), zl_h, co_h, data, image_size,
+                                               f.shape[1], f.shape[2])
+            vox = oracle.gather(oracle.integral_image(f), box, area, vis)
+            vis_total += int(vis.sum())
+            want += np.maximum(vox.astype(np.float64) @ w64.T + b64, 0.0)
+    assert vis_total > 0
+    got = out[0].permute(1, 2, 0).reshape(L * W, 256).cpu()
+    _check(f"{data}/{cam} x{nl}", got, torch.from_numpy(want))
+
+
+def test_pipe_single_scale_accumulate_degenerate_grids_and_bands(monkeypatch):
+    """`VFA.forward` (one camera, one scale: the reference's own interface) on a multi-layer grid; accumulate on top of an
+    existing map; grids smaller than one 8 x 4 tile; a view that sees nothing; the frame in bands of grid rows."""
+    import vfa_amd
+    from vfa_amd import ops, vfa_op
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload("multiviewc_156x156x5", channels=256, seed=5, n_cam=2)
+    mods = _mods(wl, dev, seed=2)
+    lat = wl["features"][0][1].to(dev)
+    calib = wl["calibs"][0].to(dev)
+    for rows, cols in ((3, 5), (4, 8), (1, 1), (9, 17)):
+        grid = wl["grid"][:, 70:70 + rows, 80:80 + cols].contiguous().to(dev)
+        with torch.no_grad(), ops.KernelTimer() as kt:
+            out = mods[1](lat, calib, grid)
+        torch.cuda.synchronize()
+        assert PIPE_ENTRY in kt.summary()
+        want = _float64_reference([mods[1]], [lat], calib[None], grid, wl)
+        _check(f"forward {rows}x{cols}", out[0].permute(1, 2, 0).reshape(rows * cols, 256), want)
+    # accumulate
+    grid = wl["grid"][:, 40:61, 30:70].contiguous().to(dev)
+    base = torch.randn(21 * 40, 256, device=dev)
+    feats = [wl["features"][1][0].to(dev)]
+    with torch.no_grad():
+        got = vfa_op.pipe_frame([mods[0]], feats, wl["calibs"][1:2].to(dev), grid, out=base.clone(), accumulate=True)
+        want = base.double() + _float64_reference([mods[0]], feats, wl["calibs"][1:2].to(dev), grid, wl)
+    _check("accumulate", got, want)
+    # a camera looking away: every box masked -> every output row is relu(bias) (vox = 0)
+    away = torch.tensor([[900., 0, 640, -1e9], [0, 900., 360, -1e9], [0, 0, 0., 1.]], device=dev)  # every corner clamps to -1
+    with torch.no_grad():
+        out = mods[2](wl["features"][0][2].to(dev), away, grid)
+    want = torch.relu(mods[2].collapse.bias.detach()).expand(21 * 40, 256)
+    assert torch.equal(out[0].permute(1, 2, 0).reshape(-1, 256), want)
+    # bands: a workspace limit that forces several passes over bands of grid rows gives the same map bit for bit
+    grid = wl["grid"][:, 30:83, 20:101].contiguous().to(dev)
+    lats = [torch.cat([wl["features"][c][s] for c in range(2)]).to(dev) for s in range(3)]
+    calibs = wl["calibs"].to(dev)
+    with torch.no_grad():
+        whole = vfa_op.pipe_frame(mods, lats, calibs, grid)
+        monkeypatch.setattr(vfa_op, "PIPE_WS_LIMIT", ops.pipe_workspace_bytes(2, 16, 81, 5, 3))
+        with ops.KernelTimer() as kt:
+            banded = vfa_op.pipe_frame(mods, lats, calibs, grid)
+        torch.cuda.synchronize()
+    assert kt.summary()[PIPE_ENTRY]["launches"] >= 3
+    assert torch.equal(whole, banded)
+
+
+def test_pipe_work_cuts_match_the_serial_restatement():
+    """The chunk tables the device kernel leaves in the workspace against a serial Python restatement of the same rule
+    (tests/native/pipe_seq_harness.cpp holds the C++ one and checks the step order on the CPU)."""
+    from vfa_amd import _lib, ops
+    dev = _dev()
+    wl, grid, lats, calibs = _frame("multiviewc_156x156x5", None, (50, 70), dev, origin=(20, 30))
+    mods = _mods(wl, dev)
+    m0 = mods[0]
+    zl, co = m0._kernel_geometry(dev)
+    n, nl, ns = calibs.shape[0], m0.num_grid_layer, 3
+    L, W = grid.shape[1:3]
+    ws = ops.pipe_records(calibs, grid, zl, co, _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1],
+                          [tuple(l.shape[-2:]) for l in lats], weights=[m.collapse.weight for m in mods])
+    torch.cuda.synchronize()
+    lay = ops.pipe_workspace_layout(n, L, W, nl, ns)
+    host = ws.cpu().numpy()
+    tiles = lay["tiles_l"] * lay["tiles_w"]
+    K = lay["n_chunks"]
+    live = [host[lay["live"][s]:lay["live"][s] + 4 * tiles].view(np.uint32) for s in range(ns)]
+    start = host[lay["chunks"]:lay["chunks"] + 4 * (K + 1)].view(np.int32)
+    rank = host[lay["ranks"]:lay["ranks"] + 4 * (K + 1)].view(np.int32)
+    assert sum(int(l.sum() > 0) for l in live) == ns
+
+    def groups_of(t):  # costs of the groups of tile t in (scale, view) order
+        out = []
+        for s in range(ns):
+            left = bin(int(live[s][t])).count("1")
+            while left > 0:
+                nj = min(left, 4)
+                out.append(4 * nl * ((nj + 1) // 2) + 2 + (3 if not out else 0))
+                left -= nj
+        return out
+
+    costs = [groups_of(t) for t in range(tiles)]
+    weight = [sum(c) if c else 1 for c in costs]
+    before = np.concatenate([[0], np.cumsum(weight)])
+    total = int(before[-1])
+    exp_start, exp_rank = np.full(K + 1, tiles, np.int32), np.zeros(K + 1, np.int32)
+    c = 0
+    for t in range(tiles):
+        tb, w0 = int(before[t]), 0
+        for k, wi in enumerate(costs[t]):
+            while c < K:
+                pc = (total * c + K - 1) // K
+                if pc >= tb + w0 + wi:
+                    break
+                kk = k if (pc - tb - w0) * 2 < wi else k + 1
+                if kk >= len(costs[t]):
+                    exp_start[c], exp_rank[c] = (t + 1 if t + 1 < tiles else tiles), 0
+                else:
+                    exp_start[c], exp_rank[c] = t, kk
+                c += 1
+            w0 += wi
+        if not costs[t]:
+            while c < K and (total * c + K - 1) // K < tb + 1:
+                exp_start[c], exp_rank[c] = t, 0
+                c += 1
+    assert np.array_equal(start, exp_start) and np.array_equal(rank, exp_rank)

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvfa_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 CONV_KIND = {"MultiviewC": 0, "MultiviewX": 1, "Wildtrack": 2}
 VOX_REFERENCE, VOX_LAYER_MAJOR = 0, 1
@@ -63,6 +63,15 @@ SIGNATURES = {
     "vfa_frame_cuts_f32": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_size_t, _vp],
     "vfa_pool_windows_f32": [_vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_pool_collapse_relu_sum_f32": [_vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
+                                       _vp],
+    "vfa_pipe_workspace_bytes": [_c_int, _c_int, _c_int, _c_int, _c_int],
+    "vfa_pipe_workspace_layout": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp],
+    "vfa_pipe_boxes_f32": [_vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
+                           _c_int, _vp, _vp, _c_size_t, _vp],
+    "vfa_pipe_cuts_f32": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_size_t, _vp],
+    "vfa_pipe_records_f32": [_vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
+                             _c_int, _vp, _vp, _vp, _c_size_t, _vp],
+    "vfa_pipe_collapse_relu_sum_f32": [_vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
                                        _vp],
 }
 

@@ -154,12 +154,17 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     reserved = RESERVED_CUS if (bool(distributed) and dist.is_available() and dist.is_initialized()
                                 and dist.get_world_size(reduce_group) > 1) else 0
     work = ((vfa8, lat8), (vfa16, lat16), (vfa32, lat32))
+    mods3 = [vfa8, vfa16, vfa32]
     if integrals is not None:
-        assert n > 0 and vfa_op.fused_frame_ok([vfa8, vfa16, vfa32], n) and not torch.is_grad_enabled(), \
-            "integral-image inputs need the fused inference path"
+        assert n > 0 and not torch.is_grad_enabled() and (vfa_op.pipe_frame_ok(mods3, n) or vfa_op.fused_frame_ok(mods3, n)), \
+            "integral-image inputs need a per-frame inference path"
         ortho = torch.empty((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
-        vfa_op.fused_frame([vfa8, vfa16, vfa32], None, calibs, grid, crange, out=ortho, reserved_cus=reserved,
-                           integrals=list(integrals))
+        frame = vfa_op.pipe_frame if vfa_op.pipe_frame_ok(mods3, n) else vfa_op.fused_frame
+        frame(mods3, None, calibs, grid, crange, out=ortho, reserved_cus=reserved, integrals=list(integrals))
+    elif n > 0 and vfa_op.pipe_frame_ok(mods3, n, (lat8, lat16, lat32)):
+        # inference, any number of z-layers: geometry once per frame + ONE persistent kernel (pooling waves beside matrix waves)
+        ortho = torch.empty((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
+        vfa_op.pipe_frame(mods3, [lat8, lat16, lat32], calibs, grid, crange, out=ortho, reserved_cus=reserved)
     elif n > 0 and all(m.mfma_collapse_ok(lat) for m, lat in work):
         # inference on single-layer grids: per scale, pooling then ONE MFMA kernel that forms collapse + bias + ReLU and
         # sums the views into the map (sum over views per scale, then over scales: the reference's sums re-associated,

@@ -1,0 +1,1053 @@
+// vfa_pipe.hip -- the inference hot path for ANY number of z-layers (C = 256) as a producer / consumer pipeline inside one
+// persistent workgroup per CU.  Supersedes the serial pool -> multiply kernel of vfa_fused.hip (single-layer grids only).
+//
+//   reference                                                              here
+//   corners, convert, project, clamp, bbox, area, visibility               pipe_records_kernel: once per frame for all scales
+//     vfa/model/vfa_op.py:64-88, 104-106; vfa/utils.py:50-59                 and ALL z-layers (box records + tap windows)
+//   4 x grid_sample of the integral image, box mean, mask  :112-120        pooling waves 8-11 of pipe_kernel (fp32, the
+//                                                                            reference's FMA chains, bit for bit)
+//   collapse = Linear(C * nl -> C)                          :50-59, :123   matrix waves 0-7: bf16-split MFMA, K = nl * 256
+//   relu; f8 + f16 + f32; ortho += ...       :124; vfa/model/vfanet.py:79,82  in registers of the matrix waves
+//
+// Why this shape.  `relu` follows the sum over the whole K = nl * 256, so the 32 x 256 accumulator of a (tile, view, scale)
+// has to stay on the CU while all nl layers are pooled and multiplied, and one layer of `collapse.weight` (256 KiB as bf16
+// hi + lo) cannot stay in registers beside it.  A workgroup therefore keeps the accumulators of a GROUP of four views of a
+// tile (128 rows) and streams the weight through registers in slices of 64 k x 256 n, each used for all 128 rows: 64 KiB of
+// weight traffic per 32 x 256 x 256 product instead of 256.  Pooling (VALU + LDS) and the products (matrix pipe) run
+// CONCURRENTLY on different waves: three waves per SIMD -- two matrix waves, one pooling wave -- one barrier per step of
+// 64 rows x 64 channels (vfa_pipe_seq.h has the step order).  Tap windows arrive by LDS-DMA one step ahead, issued by the matrix
+// waves between their MFMAs; boxes whose window does not fit (right in front of a camera) are pooled from L2 by the same
+// pooling code (no pre-pass, no row scratch).  A tile cut between workgroups is finished by whichever of them arrives
+// LAST (a ticket per tile: no workgroup ever waits for another).
+//
+// Numerics: pooling = the reference's exact fp32 sequence up to `v * RN(1 / area)` (<= 1.5 ulp from its division); product =
+// three bf16 MFMA products of a two-piece (16-bit) split of both operands, fp32 accumulation, k ascending -- on a single-layer
+// grid the SAME sequence as vfa_fused.hip, so the two kernels agree bit for bit there.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vfa_geom.h"
+#include "vfa_pipe_seq.h"
+
+namespace {
+using namespace vfa_dev;
+using namespace vfa_pipe;
+
+constexpr int kTileW = 8, kTileL = 4, kTileBoxes = kTileW * kTileL;
+constexpr int kC = 256;
+constexpr int kRecBytes = 96, kHdrBytes = 32;
+constexpr int kMaxScales = 3;
+constexpr int kSlotBytes = kC * 4;              // one tap in the integral image: 256 fp32
+constexpr int kQSlot = 256;                     // ... and the 64-channel quarter of it that a step needs
+constexpr int kWinSlots = 112;                  // LDS tap window of a (tile, view, layer, scale), in quarter slots
+constexpr int kWinBytes = kWinSlots * kQSlot;   // 28 KiB; four of them: two being pooled, two arriving
+constexpr int kMatWaves = 8, kPoolWaves = 4, kThreads = 64 * (kMatWaves + kPoolWaves);
+constexpr int kStepRows = 64;                   // rows of a step: two sub-tiles
+// A tile of a step in LDS, per bf16 plane: 8 chunks (16 bytes = 8 k) x 64 rows x 16 bytes, chunk stride padded by 32 bytes
+// (the pooling waves' 8-byte stores of neighbouring chunks then fall into different banks)
+constexpr int kChunkStride = kStepRows * 16 + 32;
+constexpr int kPlaneBytes = 8 * kChunkStride;   // 8448
+constexpr int kSteps = 16;                      // k-steps of v_mfma_f32_32x32x16_bf16 per layer
+constexpr int kChunks = 8192, kMaxBlocks = 512;
+constexpr int kVis = 1;
+constexpr int kTileLive = 1, kTileDirect = 2;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ScaleDims { int Hf, Wf; };
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+__device__ __forceinline__ float relu_t(float x) { return (x < 0.0f) ? 0.0f : x; } // NaN stays NaN
+
+// ------------------------------------------------------------------------------------------------
+// 1. geometry of the frame: one half-wave per (view, tile), lane = cell of the tile; every z-layer, every scale
+//    records / headers of a scale: index ((tile * nl + layer) * n_views + view)
+// ------------------------------------------------------------------------------------------------
+struct RecordArgs {
+    BoxGeom g;
+    int n_views, L, W, tiles_w, n_tiles, n_scales, nl;
+    ScaleDims dims[kMaxScales];
+    unsigned *live[kMaxScales];      // (n_tiles) bit v = view v has a live box in the tile, in any layer
+    unsigned char *hdrs[kMaxScales];
+    unsigned char *recs[kMaxScales];
+};
+
+__global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
+{
+    __shared__ uint4 stage[2][kTileBoxes * 6];
+    const int lane = threadIdx.x, half = lane >> 5, b = lane & 31;
+    const long long pair = (long long)blockIdx.x * 2 + half;
+    const bool pair_ok = pair < (long long)a.n_views * a.n_tiles;
+    const int view = pair_ok ? (int)(pair / a.n_tiles) : 0, tile = pair_ok ? (int)(pair % a.n_tiles) : 0;
+    const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
+    const int cl = tl * kTileL + (b >> 3), cw = tw * kTileW + (b & 7);
+    const bool valid = pair_ok && cl < a.L && cw < a.W;
+    const int cell = valid ? cl * a.W + cw : 0;
+    const float *P = a.g.calibs + (size_t)view * 12;
+    const float g0 = a.g.grid[cell * 3 + 0], g1 = a.g.grid[cell * 3 + 1], g2 = a.g.grid[cell * 3 + 2];
+    bool live_any[kMaxScales] = {false, false, false};
+#pragma unroll 1
+    for (int layer = 0; layer < a.nl; ++layer) {
+        // the cube once per (view, cell, layer): scale-independent                     vfa_op.py:64-88, utils.py:56-59
+        float l, t, r, bt;
+        {
+            const float gx = g0 + 0.0f, gy = g1 + 0.0f; // + the int64 zeros of z_corners (vfa_op.py:52, :64)
+            const float gz = g2 + a.g.z_layers[layer];
+            l = t = r = bt = 0.0f;
+#pragma unroll 1
+            for (int k = 0; k < 8; ++k) {
+                float nu, nv;
+                project_corner(a.g, P, gx, gy, gz, k, nu, nv);
+                if (k == 0) { l = r = nu; t = bt = nv; }
+                else { l = min_t(l, nu); r = max_t(r, nu); t = min_t(t, nv); bt = max_t(bt, nv); }
+            }
+        }
+        const size_t item = ((size_t)tile * a.nl + layer) * a.n_views + view;
+#pragma unroll 1
+        for (int s = 0; s < a.n_scales; ++s) {
+            const int Hf = a.dims[s].Hf, Wf = a.dims[s].Wf;
+            const float area = box_area(l, t, r, bt, Hf, Wf);                                     // vfa_op.py:104-105
+            const bool vis = valid && box_visible(area, Hf, Wf);                                  // :106
+            const float masked = valid ? area * 0.0f : 0.0f; // value of a masked voxel: 0, or NaN when the box itself is NaN
+            const bool live_box = vis || (valid && masked != masked);
+            const Axis xl = make_axis(l, Wf), xr = make_axis(r, Wf), yt = make_axis(t, Hf), yb = make_axis(bt, Hf);
+            // tap coordinates, out-of-image taps redirected to the zero border (coordinate -1 or Hf / Wf)
+            const int xs[4] = {clampi(xl.i0, -1, Wf), clampi(xl.i0 + 1, -1, Wf), clampi(xr.i0, -1, Wf), clampi(xr.i0 + 1, -1, Wf)};
+            const int ys[4] = {clampi(yt.i0, -1, Hf), clampi(yt.i0 + 1, -1, Hf), clampi(yb.i0, -1, Hf), clampi(yb.i0 + 1, -1, Hf)};
+            // window of the tile over its VISIBLE boxes: columns [x0, x1], top rows [t0, t1], bottom rows [b0, b1]
+            constexpr int kBig = 1 << 20;
+            int x0 = vis ? min(xs[0], xs[2]) : kBig, x1 = vis ? max(xs[1], xs[3]) : -kBig;
+            int t0 = vis ? ys[0] : kBig, t1 = vis ? ys[1] : -kBig, b0 = vis ? ys[2] : kBig, b1 = vis ? ys[3] : -kBig;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) {
+                x0 = min(x0, __shfl_xor(x0, m, 32)); x1 = max(x1, __shfl_xor(x1, m, 32));
+                t0 = min(t0, __shfl_xor(t0, m, 32)); t1 = max(t1, __shfl_xor(t1, m, 32));
+                b0 = min(b0, __shfl_xor(b0, m, 32)); b1 = max(b1, __shfl_xor(b1, m, 32));
+            }
+            const unsigned long long vis_all = __ballot(vis), live_all = __ballot(live_box);
+            const bool any_vis = ((vis_all >> (32 * half)) & 0xffffffffull) != 0ull;
+            const bool any_live = ((live_all >> (32 * half)) & 0xffffffffull) != 0ull;
+            int cwid = 0, top_rows = 0, bot_rows = 0, n_slots = 0;
+            if (any_vis) {
+                cwid = x1 - x0 + 1;
+                if (b0 <= t1 + 1) { // the bands touch or overlap: one band [t0, max(t1, b1)]
+                    top_rows = max(t1, b1) - t0 + 1;
+                    bot_rows = 0;
+                    b0 = t0 + top_rows;
+                } else {
+                    top_rows = t1 - t0 + 1;
+                    bot_rows = b1 - b0 + 1;
+                }
+                n_slots = cwid * (top_rows + bot_rows);
+            }
+            const bool direct = n_slots > kWinSlots; // pooled straight from the integral image: pixel coordinates in the record
+            auto slot_row = [&](int y) { return y < t0 + top_rows ? y - t0 : top_rows + (y - b0); };
+            unsigned rows[4], cols[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (direct) { rows[k] = (unsigned)(ys[k] + 1); cols[k] = (unsigned)(xs[k] + 1); }
+                else { rows[k] = (unsigned)(slot_row(ys[k]) * cwid); cols[k] = (unsigned)(xs[k] - x0); }
+            }
+            float w[16];
+            {
+                float q[4];
+                bilinear_weights(q, xl, yt); w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];       // lt
+                bilinear_weights(q, xr, yb); w[4] = q[0]; w[5] = q[1]; w[6] = q[2]; w[7] = q[3];       // rb
+                bilinear_weights(q, xr, yt); w[8] = q[0]; w[9] = q[1]; w[10] = q[2]; w[11] = q[3];     // rt
+                bilinear_weights(q, xl, yb); w[12] = q[0]; w[13] = q[1]; w[14] = q[2]; w[15] = q[3];   // lb
+            }
+            if (pair_ok) {
+                uint4 *st = stage[half] + b * 6;
+                st[0] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
+                st[1] = make_uint4(__float_as_uint(w[4]), __float_as_uint(w[5]), __float_as_uint(w[6]), __float_as_uint(w[7]));
+                st[2] = make_uint4(__float_as_uint(w[8]), __float_as_uint(w[9]), __float_as_uint(w[10]), __float_as_uint(w[11]));
+                st[3] = make_uint4(__float_as_uint(w[12]), __float_as_uint(w[13]), __float_as_uint(w[14]), __float_as_uint(w[15]));
+                const float rcp = 1.0f / area; // correctly rounded
+                st[4] = make_uint4(__float_as_uint(rcp), vis ? (unsigned)kVis : 0u, rows[0] | (rows[1] << 16), rows[2] | (rows[3] << 16));
+                st[5] = make_uint4(cols[0] | (cols[1] << 16), cols[2] | (cols[3] << 16), __float_as_uint(masked), __float_as_uint(area));
+            }
+            __syncthreads(); // (one wave: orders the LDS writes above against the reads below)
+            if (pair_ok) {
+                uint4 *rec = reinterpret_cast<uint4 *>(a.recs[s] + item * kTileBoxes * kRecBytes);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) rec[k * 32 + b] = stage[half][k * 32 + b];
+                if (b == 0) {
+                    uint4 *hdr = reinterpret_cast<uint4 *>(a.hdrs[s] + item * kHdrBytes);
+                    const int inv = cwid > 0 ? (65536 + cwid - 1) / cwid : 0; // floor(s / cwid) == (s * inv) >> 16 for s < 128
+                    const unsigned hflags = (any_live ? kTileLive : 0) | (direct ? kTileDirect : 0);
+                    hdr[0] = make_uint4(hflags, (unsigned)n_slots, (unsigned)cwid, (unsigned)inv);
+                    hdr[1] = make_uint4((unsigned)x0, (unsigned)t0, (unsigned)top_rows, (unsigned)b0);
+                }
+            }
+            live_any[s] = live_any[s] || any_live;
+            __syncthreads(); // the stage is reused
+        }
+    }
+    if (pair_ok && b == 0)
+        for (int s = 0; s < a.n_scales; ++s)
+            if (live_any[s]) atomicOr(a.live[s] + tile, 1u << view);
+}
+
+// collapse.weight of a scale, in the REFERENCE layout (256, 256 * nl), column = c * nl + layer (vfa_op.py:59, :120), as bf16
+// hi / lo planes in MFMA B-fragment order, one 256 KiB block per layer:
+//   out[(((layer * 8 + wave) * 16 + s) * 2 + plane) * 64 + lane] (16 B) = W[n = 32 wave + (lane & 31)][c = 16 s + 8 (lane >> 5) + j], j = 0..7
+struct SplitArgs { const float *w[kMaxScales]; uint4 *out[kMaxScales]; int nl; };
+__global__ __launch_bounds__(256) void pipe_split_weight_kernel(SplitArgs sa)
+{
+    const int scale = blockIdx.y / sa.nl, layer = blockIdx.y - scale * sa.nl;
+    const float *__restrict__ w = sa.w[scale];
+    uint4 *__restrict__ out = sa.out[scale] + (size_t)layer * 8 * kSteps * 2 * 64;
+    const int idx = blockIdx.x * 256 + threadIdx.x; // (wave, s, lane)
+    if (idx >= 8 * kSteps * 64) return;
+    const int lane = idx & 63, s = (idx >> 6) & 15, wave = idx >> 10;
+    const float *src = w + (size_t)(wave * 32 + (lane & 31)) * kC * sa.nl + (size_t)(16 * s + 8 * (lane >> 5)) * sa.nl + layer;
+    union { __bf16 b[8]; uint4 u; } hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = src[(size_t)j * sa.nl];
+        hi.b[j] = (__bf16)x;
+        lo.b[j] = (__bf16)(x - (float)hi.b[j]);
+    }
+    out[((size_t)(wave * kSteps + s) * 2 + 0) * 64 + lane] = hi.u;
+    out[((size_t)(wave * kSteps + s) * 2 + 1) * 64 + lane] = lo.u;
+}
+
+// work cuts (vfa_pipe_seq.h: walk_tile): one workgroup, an LDS scan over per-thread sums, then every thread places the cuts
+// that fall into its tiles
+struct CutArgs {
+    const unsigned *live[kMaxScales];
+    int n_scales, n_tiles, n_views, nl;
+    int *chunk_start, *chunk_rank;
+};
+__global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
+{
+    __shared__ unsigned long long part[1024];
+    const int tid = threadIdx.x, n_tiles = a.n_tiles;
+    const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
+    const int per = (n_tiles + 1023) / 1024, t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
+    auto masks_of = [&](int t, unsigned *m) {
+#pragma unroll
+        for (int s = 0; s < kMaxScales; ++s) m[s] = s < a.n_scales ? (a.live[s][t] & view_mask) : 0u;
+    };
+    unsigned long long local = 0;
+    for (int t = t0; t < t1; ++t) {
+        unsigned m[kMaxScales];
+        masks_of(t, m);
+        local += walk_tile(m, a.n_scales, a.nl, [](int, unsigned, unsigned) {});
+    }
+    part[tid] = local;
+    for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_tiles; a.chunk_rank[c] = 0; }
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const unsigned long long total = part[1023];
+    unsigned long long before = part[tid] - local;
+    auto pos_of = [&](long long cc) { return (total * (unsigned long long)cc + kChunks - 1) / kChunks; };
+    for (int t = t0; t < t1; ++t) {
+        const unsigned long long tb = before;
+        long long c = tb > 0 ? (long long)((tb - 1) * kChunks / total) : 0;
+        while (c < kChunks && pos_of(c) < tb) ++c;
+        unsigned m[kMaxScales];
+        masks_of(t, m);
+        int n_groups = 0;
+        walk_tile(m, a.n_scales, a.nl, [&](int kk, unsigned, unsigned) { n_groups = kk + 1; });
+        const unsigned w = walk_tile(m, a.n_scales, a.nl, [&](int kk, unsigned w0, unsigned w1) {
+            while (c < kChunks) {
+                const unsigned long long pc = pos_of(c);
+                if (pc >= tb + w1) break;
+                const int k = ((unsigned)(pc - tb) - w0) * 2 < (w1 - w0) ? kk : kk + 1;
+                if (k >= n_groups) { a.chunk_start[c] = t + 1 < n_tiles ? t + 1 : n_tiles; a.chunk_rank[c] = 0; }
+                else { a.chunk_start[c] = t; a.chunk_rank[c] = k; }
+                ++c;
+            }
+        });
+        if (n_groups == 0)
+            for (; c < kChunks && pos_of(c) < tb + w; ++c) { a.chunk_start[c] = t; a.chunk_rank[c] = 0; }
+        before += w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2. the frame kernel
+// ------------------------------------------------------------------------------------------------
+struct PipeScale {
+    const float *integral;          // (n_views, Hf+2, Wf+2, 256) zero-bordered channels-last
+    const float *bias;              // (256) or NULL
+    const uint4 *wfrag;             // pipe_split_weight_kernel output
+    const unsigned *live;           // (n_tiles)
+    const unsigned char *hdrs, *recs;
+    int Hf, Wf;
+};
+struct PipeArgs {
+    PipeScale sc[kMaxScales];
+    int n_scales, n_views, nl, L, W, tiles_w, n_tiles;
+    float *out;                     // (L * W, 256)
+    const int *chunk_start, *chunk_rank;
+    float *partial;                 // (kMaxBlocks, 2) x 8 waves x 16 registers x 64 lanes: sums of a workgroup's part of a shared tile
+    unsigned *tickets;              // (n_tiles): parts of a shared tile that have arrived (zeroed by the geometry call)
+    int accumulate;
+    unsigned long long *diag;       // per workgroup 8 counters (VFA_FLAG_DEBUG)
+    int debug;
+};
+
+struct DevMasks {
+    const unsigned *l0, *l1, *l2; // (no array: a dynamically indexed member would put the whole sequencer into scratch memory)
+    unsigned view_mask;
+    __device__ __forceinline__ unsigned operator()(int s, int t) const
+    {
+        // scalar loads (constant address space: the geometry kernels finished before this launch)
+        const size_t p = (s == 0 ? (size_t)l0 : 0) | (s == 1 ? (size_t)l1 : 0) | (s == 2 ? (size_t)l2 : 0);
+        return *reinterpret_cast<const __attribute__((address_space(4))) unsigned *>(p + (size_t)t * 4) & view_mask;
+    }
+};
+
+struct Frag { bf16x8 hi, lo; };
+
+// a Step (vfa_pipe_seq.h) in three scalar registers: four of them are in flight per wave
+struct PStep {
+    int tile;       // < 0: no step
+    unsigned views; // view of sub-tile j in bits 8 j .. 8 j + 7
+    unsigned w;     // scale 0-1 | layer 2-11 | q 12-13 | set 14 | nj 15-17 | grp_first 18 | grp_last 19 | tile_last 20 | index & 1 21 | phase & 255 22-29
+    __device__ __forceinline__ bool valid() const { return tile >= 0; }
+    __device__ __forceinline__ int scale() const { return (int)(w & 3u); }
+    __device__ __forceinline__ int layer() const { return (int)((w >> 2) & 1023u); }
+    __device__ __forceinline__ int q() const { return (int)((w >> 12) & 3u); }
+    __device__ __forceinline__ int set() const { return (int)((w >> 14) & 1u); }
+    __device__ __forceinline__ int nj() const { return (int)((w >> 15) & 7u); }
+    __device__ __forceinline__ bool grp_first() const { return (w >> 18) & 1u; }
+    __device__ __forceinline__ bool grp_last() const { return (w >> 19) & 1u; }
+    __device__ __forceinline__ bool tile_last() const { return (w >> 20) & 1u; }
+    __device__ __forceinline__ int par() const { return (int)((w >> 21) & 1u); }
+    __device__ __forceinline__ int phase() const { return (int)((w >> 22) & 255u); } // (steps in flight differ by < 4 phases)
+    __device__ __forceinline__ int view(int j) const { return (int)((views >> (8 * j)) & 0xffu); }
+    __device__ __forceinline__ bool same_chunk(const PStep &o) const { return ((w ^ o.w) & 0x3fffu) == 0u; } // scale, layer, q
+};
+
+__device__ __forceinline__ float4 mul4(float4 a, float w) { return make_float4(a.x * w, a.y * w, a.z * w, a.w * w); }
+__device__ __forceinline__ float4 fma4(float4 a, float w, float4 c)
+{
+    return make_float4(fmaf(a.x, w, c.x), fmaf(a.y, w, c.y), fmaf(a.z, w, c.z), fmaf(a.w, w, c.w));
+}
+// bilinear sample from the four rounded weights, taps in the order nw, ne, sw, se: one product, three FMAs
+__device__ __forceinline__ float4 sample4(float4 nw, float4 ne, float4 sw, float4 se, float w0, float w1, float w2, float w3)
+{
+    float4 v = mul4(nw, w0);
+    v = fma4(ne, w1, v);
+    v = fma4(sw, w2, v);
+    v = fma4(se, w3, v);
+    return v;
+}
+
+// box of one pooling lane for a whole layer: the 16 rounded tap weights, the scale (RN(1 / area), or the masked value) and the
+// 16 tap positions (byte offsets inside the tap window, or inside the view's integral image for a direct item)
+struct LaneBox {
+    float wt[16];
+    float scl;
+    unsigned tb[16];
+};
+
+// A fragments of one k-step for the two row blocks of a step (hi / lo planes): immediate offsets from one LDS address.
+// Assembly: the reads run one k-step ahead of the MFMAs with counted waits, and the compiler must not order them behind the
+// LDS-DMA the wave has in flight (it would drain it in front of every LDS read it knows of).
+template <int KS>
+__device__ __forceinline__ void read_frags(unsigned pa, bf16x8 &h0, bf16x8 &l0, bf16x8 &h1, bf16x8 &l1)
+{
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"
+                 "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(h0), "=&v"(l0), "=&v"(h1), "=&v"(l1)
+                 : "v"(pa), "n"(KS * 2 * kChunkStride), "n"(KS * 2 * kChunkStride + kPlaneBytes), "n"(KS * 2 * kChunkStride + 512),
+                   "n"(KS * 2 * kChunkStride + 512 + kPlaneBytes)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_frags(bf16x8 &h0, bf16x8 &l0, bf16x8 &h1, bf16x8 &l1)
+{
+    if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));
+}
+
+template <int TERMS, bool DIAG>
+__global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
+{
+    // separate objects: one per role of the data (hipcc orders LDS-DMA against every LDS access it cannot prove disjoint)
+    __shared__ __align__(16) unsigned char s_win[4 * kWinBytes];            // tap windows: [step parity][sub-tile of the set]
+    __shared__ __align__(16) unsigned char s_planes[2 * 2 * kPlaneBytes];   // A tiles: [step parity][hi, lo]
+    __shared__ __align__(16) unsigned char s_rec[4 * kTileBoxes * kRecBytes]; // box records of the group's sub-tiles, one layer
+    __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
+    __shared__ unsigned s_misc[16];
+    const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63;
+
+    const int nblk = gridDim.x;
+    const int lb = (int)xcd_contiguous(blockIdx.x, (nblk + 7) / 8);
+    if (lb >= nblk) return;
+    auto range_of = [&](int wg, int &tb, int &kb, int &te, int &ke) {
+        const int c0 = (int)((long long)kChunks * wg / nblk), c1 = (int)((long long)kChunks * (wg + 1) / nblk);
+        tb = uniform_i(a.chunk_start[c0]); kb = uniform_i(a.chunk_rank[c0]);
+        te = uniform_i(a.chunk_start[c1]); ke = uniform_i(a.chunk_rank[c1]);
+    };
+    int t_begin, k_begin, t_end, k_end;
+    range_of(lb, t_begin, k_begin, t_end, k_end);
+    if (t_begin > t_end || (t_begin == t_end && k_begin >= k_end)) return;
+    const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
+    DevMasks masks;
+    masks.l0 = a.sc[0].live; masks.l1 = a.sc[1].live; masks.l2 = a.sc[2].live;
+    masks.view_mask = view_mask;
+
+    // a tile is SHARED when another workgroup holds groups of it too
+    auto shared_tile = [&](int tile) { return (tile == t_begin && k_begin > 0) || (tile == t_end && k_end > 0); };
+
+    // The loop below exists twice, once per role (`POOL`): a wave never changes its role, and inside ONE loop the registers of
+    // both roles would be live at once.  Both copies take the same steps, hence the same barriers.
+    auto run = [&](auto role_tag) {
+        constexpr bool POOL = decltype(role_tag)::value;
+        const int r = lane & 31, h = lane >> 5;           // matrix waves: row / column of the 32 x 32 block, k half
+        const int pw = wave - kMatWaves;                  // pooling waves: 0..3
+        const int pb = lane >> 2, pi = lane & 3;          // ... box 0..15 of the wave's half sub-tile, 16-byte piece 0..3
+
+        // ---------------------------------------------------------------- matrix-wave state
+        f32x16 acc[4], sum;
+        Frag wq[4];
+        float bc[kMaxScales];
+        if constexpr (!POOL) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < kMaxScales; ++s) {
+                bc[s] = (s < a.n_scales && a.sc[s].bias) ? a.sc[s].bias[wave * 32 + r] : 0.0f;
+            }
+        }
+        // ---------------------------------------------------------------- pooling-wave state: the wave's 16 boxes of each set
+        LaneBox boxA, boxB;
+        bool globA = false, globB = false, liveA = false, liveB = false;
+
+        auto hdr_word = [&](int phase, int j, int k) { return uniform_i((int)s_hdr[phase & 3][j * 8 + k]); };
+
+        // output rows of a tile: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 block, column r
+        auto write_tile = [&](int tile, const f32x16 &v, bool have) {
+            const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
+            float extra = 0.0f; // fully masked (view, scale) of this tile: vox = 0 -> relu(bias)
+#pragma unroll
+            for (int s = 0; s < kMaxScales; ++s)
+                if (s < a.n_scales) extra += (float)(a.n_views - __popc(masks(s, tile))) * relu_t(bc[s]);
+            int h2 = h, r2 = r;
+            asm volatile("" : "+v"(h2), "+v"(r2)); // (keeps the 16 row offsets out of long-lived registers)
+            float *ocol = a.out + wave * 32 + r2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * h2;
+                const int cl = tl * kTileL + (row >> 3), cw = tw * kTileW + (row & 7);
+                if (cl < a.L && cw < a.W) {
+                    float *o = ocol + (size_t)(cl * a.W + cw) * kC;
+                    float x = (have ? v[i] : 0.0f) + extra;
+                    if (a.accumulate) x += *o; // the workgroup owns these rows
+                    *o = x;
+                }
+            }
+        };
+        auto empty_tiles = [&](int t0, int t1) { // tiles without a group inside this workgroup's range
+            if constexpr (!POOL) {
+                f32x16 none = {};
+                for (int t2 = t0; t2 < t1; ++t2) write_tile(t2, none, false);
+            }
+        };
+
+        // ---------------------------------------------------------------- DMA (matrix waves)
+        auto hdr_dma = [&](const PStep &st) { // the headers of the group's sub-tiles at the step's layer: 8 lanes each
+            if (wave != 0) return;
+            int j = lane >> 3;
+            j = j < st.nj() ? j : st.nj() - 1;
+            const size_t item = ((size_t)st.tile * a.nl + st.layer()) * a.n_views + st.view(j);
+            const unsigned char *p = a.sc[st.scale()].hdrs + item * kHdrBytes + (lane & 7) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                             (__attribute__((address_space(3))) void *)(&s_hdr[st.phase() & 3][0]), 4, 0, 0);
+        };
+        // tap windows (and, at the first quarter of a layer, the box records) of the sub-tiles of step `st`
+        auto step_dma = [&](const PStep &st) {
+            const PipeScale &sc = a.sc[st.scale()];
+            const int wp = sc.Wf + 2;
+            int hw[2][8];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) hw[x][k] = hdr_word(st.phase(), min(2 * st.set() + x, 3), k);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int j = 2 * st.set() + x;
+                if (j >= st.nj() || !(hw[x][0] & kTileLive)) continue;
+                const int view = st.view(j);
+                const size_t item = ((size_t)st.tile * a.nl + st.layer()) * a.n_views + view;
+                if (st.q() == 0 && wave >= 3 * x && wave < 3 * x + 3) {
+                    const int k = wave - 3 * x;
+                    const unsigned char *p = sc.recs + item * kTileBoxes * kRecBytes + k * 1024 + lane * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                                     (__attribute__((address_space(3))) void *)(s_rec + j * kTileBoxes * kRecBytes + k * 1024), 16, 0, 0);
+                }
+                if (hw[x][0] & kTileDirect) continue;
+                const int n_slots = hw[x][1], cw = hw[x][2], inv = hw[x][3], x0 = hw[x][4], t0 = hw[x][5], top = hw[x][6], b0 = hw[x][7];
+                const int n_fill = (n_slots + 3) >> 2;
+                const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)view * (sc.Hf + 2) * wp * kSlotBytes +
+                                  st.q() * kQSlot + (lane & 15) * 16;
+                unsigned char *dst = s_win + (st.par() * 2 + x) * kWinBytes;
+                for (int f = (wave + 4 * x) & 7; f < n_fill; f += kMatWaves) { // four quarter slots per instruction, 16 lanes each
+                    const int slot = min(4 * f + (lane >> 4), n_slots - 1);
+                    const int wr = (slot * inv) >> 16, wc = slot - wr * cw;
+                    const int y = wr < top ? t0 + wr : b0 + (wr - top), xx = x0 + wc;
+                    const char *src = img + (size_t)(unsigned)((y + 1) * wp + (xx + 1)) * kSlotBytes;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(dst + f * 1024), 16, 0, 0);
+                }
+            }
+        };
+        // the 64 k x 32 n slice of collapse.weight of step `st` for this wave: 8 coalesced 1 KiB loads
+        auto w_load = [&](const PStep &st, int ks) {
+            const uint4 *src = a.sc[st.scale()].wfrag + ((size_t)(st.layer() * 8 + wave) * kSteps + st.q() * 4 + ks) * 2 * 64 + lane;
+            const uint4 uh = src[0], ul = src[64];
+            wq[ks].hi = *reinterpret_cast<const bf16x8 *>(&uh);
+            wq[ks].lo = *reinterpret_cast<const bf16x8 *>(&ul);
+        };
+
+        // ---------------------------------------------------------------- products of one step (matrix waves)
+        // SET is the parity of the step's index, hence a compile-time fact of the loop body it is called from; the weight is
+        // reloaded behind the k-steps of set 1 (the next step starts another slice), never behind those of set 0 -- a reload
+        // decided at run time inside the k-loop cost register copies at every merge point.
+        auto multiply = [&](auto set_tag, const PStep &st, const PStep &nx) {
+            constexpr int SET = decltype(set_tag)::value;
+            constexpr bool reload = SET == 1;
+            if (st.grp_first()) {
+                const float b0 = st.scale() == 0 ? bc[0] : (st.scale() == 1 ? bc[1] : bc[2]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { acc[2 * SET][i] = b0; acc[2 * SET + 1][i] = b0; } // (the bias rides in the accumulator)
+            }
+            const bool work = 2 * SET < st.nj() && !(DIAG && (a.debug & 4)); // (set 1 of a group of one or two views is empty)
+            // A fragments: lane (r, h) of row block rb reads chunk 2 ks + h, row 32 rb + r (read_frags)
+            const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)s_planes +
+                                (unsigned)(st.par() * 2 * kPlaneBytes + h * kChunkStride + r * 16);
+            // ONE set of fragment registers: the reads of k-step ks + 1 are issued behind the MFMAs of ks (which latched their A
+            // operands when they issued) and land under them and under the partner wave's MFMAs; a second set for reading ahead
+            // does not fit beside four accumulators, the tile sums and the weight slice (168 registers at three waves per SIMD)
+            bf16x8 fh0, fl0, fh1, fl1; // row block 0, row block 1
+            // Both row blocks, always: a sub-tile without a live box in this layer was ZEROED by its pooling wave, and the rows
+            // of a sub-tile the group does not have feed an accumulator nobody reads.
+            auto kstep = [&](auto ks_tag) {
+                constexpr int KS = decltype(ks_tag)::value;
+                if (work) {
+                    read_frags<KS>(pa, fh0, fl0, fh1, fl1);
+                    wait_frags<0>(fh0, fl0, fh1, fl1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
+                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
+                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
+                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                    if (TERMS >= 4) {
+                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
+                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (reload) w_load(nx, KS); // the next slice, k-step by k-step, into the registers just used
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (no scalar load may be pending beside the waits of read_frags)
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+            kstep(std::integral_constant<int, 2>{});
+            kstep(std::integral_constant<int, 3>{});
+            if (st.grp_last() && 2 * SET < st.nj()) { // vfa_op.py:124; vfanet.py:79, 82: views in index order
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[2 * SET][i]);
+                if (2 * SET + 1 < st.nj()) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[2 * SET + 1][i]);
+                }
+            }
+        };
+
+        // ---------------------------------------------------------------- pooling of one step (pooling waves)
+        auto unpack = [&](LaneBox &bx, bool &glob, const PStep &st, int j, bool direct) {
+            const uint4 *rp = reinterpret_cast<const uint4 *>(s_rec + j * kTileBoxes * kRecBytes) + ((pw & 1) * 16 + pb) * (kRecBytes / 16);
+            uint4 rv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rv[k] = rp[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bx.wt[4 * k + 0] = __uint_as_float(rv[k].x); bx.wt[4 * k + 1] = __uint_as_float(rv[k].y);
+                bx.wt[4 * k + 2] = __uint_as_float(rv[k].z); bx.wt[4 * k + 3] = __uint_as_float(rv[k].w);
+            }
+            const bool vis = (rv[4].y & (unsigned)kVis) != 0u;
+            // a masked box reads slot / pixel 0 (finite) and multiplies by its masked value (0, or NaN for a NaN box)
+            bx.scl = vis ? __uint_as_float(rv[4].x) : __uint_as_float(rv[5].z);
+            unsigned rw[4] = {rv[4].z & 0xffffu, rv[4].z >> 16, rv[4].w & 0xffffu, rv[4].w >> 16};
+            unsigned cl[4] = {rv[5].x & 0xffffu, rv[5].x >> 16, rv[5].y & 0xffffu, rv[5].y >> 16};
+            const unsigned wp = (unsigned)a.sc[st.scale()].Wf + 2u;
+            glob = direct;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned pos = direct ? rw[i] * wp + cl[k] : rw[i] + cl[k]; // pixel of the padded image / slot of the window
+                    bx.tb[4 * i + k] = (vis ? pos : 0u) * (direct ? (unsigned)kSlotBytes : (unsigned)kQSlot) + (unsigned)(pi * 16);
+                }
+        };
+        // the wave's 16 boxes x the 64 channels of quarter q: lane (box pb, piece pi) takes the 16-byte pieces
+        // ((pb + m) & 3) * 4 + pi, m = 0..3, of its taps' quarter slots -- the four boxes of an LDS cycle read different 64-byte
+        // quarters of the banks whatever slots they hold
+        auto pool = [&](auto glob_tag, const LaneBox &bx, const PStep &st, int x) {
+            constexpr bool GLOB = decltype(glob_tag)::value;
+            const int j = 2 * st.set() + x;
+            const unsigned char *win = s_win + (st.par() * 2 + x) * kWinBytes;
+            const PipeScale &sc = a.sc[st.scale()];
+            const char *img = reinterpret_cast<const char *>(sc.integral) +
+                              (size_t)st.view(j) * (sc.Hf + 2) * (sc.Wf + 2) * kSlotBytes + st.q() * kQSlot;
+            const int row = x * 32 + (pw & 1) * 16 + pb;
+            unsigned char *planes = s_planes + st.par() * 2 * kPlaneBytes;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const unsigned piece = (unsigned)((pb + m) & 3);
+                const unsigned rot = piece << 6;
+                float4 t[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if constexpr (GLOB) t[k] = *reinterpret_cast<const float4 *>(img + (size_t)(bx.tb[k] + rot));
+                    else t[k] = *reinterpret_cast<const float4 *>(win + (bx.tb[k] + rot));
+                }
+                // taps: index 4 * row + col over {top, top + 1, bottom, bottom + 1} x {left, left + 1, right, right + 1}
+                const float4 lt = sample4(t[0], t[1], t[4], t[5], bx.wt[0], bx.wt[1], bx.wt[2], bx.wt[3]);
+                const float4 rb = sample4(t[10], t[11], t[14], t[15], bx.wt[4], bx.wt[5], bx.wt[6], bx.wt[7]);
+                const float4 rt = sample4(t[2], t[3], t[6], t[7], bx.wt[8], bx.wt[9], bx.wt[10], bx.wt[11]);
+                const float4 lb2 = sample4(t[8], t[9], t[12], t[13], bx.wt[12], bx.wt[13], bx.wt[14], bx.wt[15]);
+                // (((lt + rb) - rt) - lb) * RN(1 / area)                                              (A.6)
+                float4 v = make_float4(lt.x + rb.x, lt.y + rb.y, lt.z + rb.z, lt.w + rb.w);
+                v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
+                v = make_float4(v.x - lb2.x, v.y - lb2.y, v.z - lb2.z, v.w - lb2.w);
+                const float xs[4] = {v.x * bx.scl, v.y * bx.scl, v.z * bx.scl, v.w * bx.scl};
+                // x = hi + lo + r, |r| <= 2^-17 |x|: hi = RNE bf16(x), lo = RNE bf16(x - hi)
+                union { __bf16 b[4]; uint2 u; } hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    hi.b[k] = (__bf16)xs[k];
+                    lo.b[k] = (__bf16)(xs[k] - (float)hi.b[k]);
+                }
+                // channels 16 piece + 4 pi .. + 3 of the quarter: chunk 2 piece + (pi >> 1), half pi & 1
+                const int off = (int)(2 * piece + (pi >> 1)) * kChunkStride + row * 16 + (pi & 1) * 8;
+                *reinterpret_cast<uint2 *>(planes + off) = hi.u;
+                *reinterpret_cast<uint2 *>(planes + kPlaneBytes + off) = lo.u;
+            }
+        };
+        auto pool_step = [&](auto set_tag, const PStep &st) {
+            constexpr int SET = decltype(set_tag)::value;
+            const int x = pw >> 1, j = 2 * SET + x;
+            if (j >= st.nj()) return;
+            auto one = [&](LaneBox &bx, bool &glob, bool &live) { // (called with the registers of the step's set)
+                if (st.q() == 0) {
+                    const int flags = hdr_word(st.phase(), j, 0);
+                    live = (flags & kTileLive) != 0;
+                    if (live) unpack(bx, glob, st, j, (flags & kTileDirect) != 0);
+                }
+                if (!live) { // no live box in this layer: the matrix waves multiply zeros
+                    const int row = x * 32 + (pw & 1) * 16 + pb;
+                    unsigned char *planes = s_planes + st.par() * 2 * kPlaneBytes;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int off = (2 * m + (pi >> 1)) * kChunkStride + row * 16 + (pi & 1) * 8;
+                        *reinterpret_cast<uint2 *>(planes + off) = make_uint2(0u, 0u);
+                        *reinterpret_cast<uint2 *>(planes + kPlaneBytes + off) = make_uint2(0u, 0u);
+                    }
+                    return;
+                }
+                if (DIAG && (a.debug & 2)) return;
+                if (glob) pool(std::true_type{}, bx, st, x);
+                else pool(std::false_type{}, bx, st, x);
+            };
+            if constexpr (SET == 0) one(boxA, globA, liveA);
+            else one(boxB, globB, liveB);
+        };
+
+        // ---------------------------------------------------------------- a workgroup's part of a tile is complete
+        auto finish_tile = [&](const PStep &st, int next_tile) {
+            const int tile = st.tile;
+            if (__builtin_expect(!shared_tile(tile), 1)) {
+                if constexpr (!POOL) write_tile(tile, sum, true);
+            } else {
+                // Whoever arrives LAST adds the parts (in workgroup order: one fixed association) and stores the tile; the
+                // others leave their sums in the workspace and go on.  sc1 stores and loads on both sides, every storing wave
+                // drained, then one ticket per workgroup (guide: inter-workgroup visibility, valid forms).
+                const int which = (tile == t_begin && k_begin > 0) ? 0 : 1;
+                if constexpr (!POOL) {
+                    float *pp = a.partial + (((size_t)lb * 2 + which) * 8 + wave) * 16 * 64 + lane;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) __hip_atomic_store(pp + i * 64, sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                // the workgroups that hold groups of this tile: first, last
+                int first = lb, last = lb, parts = 1;
+                for (int j = lb - 1; j >= 0; --j) {
+                    int tb, kb, te, ke;
+                    range_of(j, tb, kb, te, ke);
+                    if (te < tile || (te == tile && ke == 0)) break; // ends in front of the tile
+                    if (tb > te || (tb == te && kb >= ke)) continue; // (empty range)
+                    first = j; ++parts;
+                }
+                for (int j = lb + 1; j < nblk; ++j) {
+                    int tb, kb, te, ke;
+                    range_of(j, tb, kb, te, ke);
+                    if (tb > tile) break;
+                    if (tb > te || (tb == te && kb >= ke)) continue;
+                    last = j; ++parts;
+                }
+                if (tid == 0) {
+                    const unsigned old = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_misc[0] = old;
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const bool am_last = uniform_i((int)s_misc[0]) == parts - 1;
+                if constexpr (!POOL) {
+                    if (am_last) {
+                        f32x16 tot;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
+                        for (int j = first; j <= last; ++j) {
+                            if (j == lb) {
+#pragma unroll
+                                for (int i = 0; i < 16; ++i) tot[i] += sum[i];
+                                continue;
+                            }
+                            int tb, kb, te, ke;
+                            range_of(j, tb, kb, te, ke);
+                            if (tb > te || (tb == te && kb >= ke)) continue;
+                            const int wj = (tile == tb && kb > 0) ? 0 : 1;
+                            const float *pp = a.partial + (((size_t)j * 2 + wj) * 8 + wave) * 16 * 64 + lane;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) tot[i] += __hip_atomic_load(pp + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        write_tile(tile, tot, true);
+                    }
+                }
+            }
+            if constexpr (!POOL) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
+            }
+            empty_tiles(tile + 1, next_tile);
+        };
+
+        // ---------------------------------------------------------------- the loop
+        // every field through v_readfirstlane: the steps steer branches, barriers and LDS-DMA destinations, so they must sit in
+        // scalar registers whatever the compiler's divergence analysis makes of the generator
+        auto canon = [&](const Step &s0) {
+            PStep c;
+            c.tile = uniform_i(s0.tile);
+            c.views = (unsigned)uniform_i((int)s0.views);
+            c.w = (unsigned)uniform_i((int)((unsigned)s0.scale | ((unsigned)s0.layer << 2) | ((unsigned)s0.q << 12) | ((unsigned)s0.set << 14) |
+                                            ((unsigned)s0.nj << 15) | (s0.grp_first ? 1u << 18 : 0u) | (s0.grp_last ? 1u << 19 : 0u) |
+                                            (s0.tile_last ? 1u << 20 : 0u) | ((unsigned)(s0.index & 1) << 21) | ((unsigned)(s0.phase & 255) << 22)));
+            return c;
+        };
+        Sequencer<DevMasks> sq;
+        sq.masks = masks;
+        sq.begin(a.n_scales, a.nl, t_begin, k_begin, t_end, k_end);
+        PStep dm, dp, dd, dh; // the steps being multiplied, pooled, fetched; the one whose headers are fetched
+        dm.tile = -1; dp.tile = -1;
+        dd = canon(sq.next());
+        dh = canon(sq.next());
+        empty_tiles(k_begin == 0 ? t_begin : t_begin + 1, dd.valid() ? dd.tile : t_end);
+        if (!dd.valid()) return;
+        unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+        auto tick = [&](int k) {
+            if (DIAG) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                stamp[k] += now - t_prev;
+                t_prev = now;
+            }
+        };
+        if constexpr (!POOL) {
+            hdr_dma(dd);
+            if (dh.valid() && dh.phase() != dd.phase()) hdr_dma(dh);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) w_load(dd, ks);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!POOL) {
+            step_dma(dd);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (DIAG) t_prev = __builtin_amdgcn_s_memtime();
+        // One step: the pooling waves pool step `dp` (set PSET), the matrix waves fetch for step `dd` and multiply step `dm`
+        // (the other set).  The sets alternate with the step index, so the loop is unrolled by two.
+        auto body = [&](auto pset_tag) {
+            constexpr int PSET = decltype(pset_tag)::value, MSET = PSET ^ 1;
+            tick(0);
+            if constexpr (POOL) {
+                if (dp.valid()) pool_step(std::integral_constant<int, PSET>{}, dp);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                tick(1);
+            } else {
+                // the weight slice requested during the last step (and tile stores).  The BUILTIN, not assembly: it tells the
+                // compiler's wait-count model that nothing is pending; otherwise it waits for those loads itself -- vmcnt(0) in front
+                // of the first MFMA, behind the DMA issued below: a memory round trip per step
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                if (dd.valid() && !(DIAG && (a.debug & 1))) step_dma(dd);
+                if (dh.valid() && (!dd.valid() || dh.phase() != dd.phase())) hdr_dma(dh);
+                tick(1);
+                if (dm.valid()) multiply(std::integral_constant<int, MSET>{}, dm, dp.valid() ? dp : dm);
+                tick(2);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // windows / records / headers of the next step have landed
+                tick(3);
+            }
+            if constexpr (MSET == 1) {
+                if (__builtin_expect(dm.valid() && dm.tile_last(), 0)) finish_tile(dm, dp.valid() ? dp.tile : t_end);
+            }
+            tick(4);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            tick(5);
+            if (DIAG) stamp[7] += 1;
+        };
+        for (;;) {
+            dm = dp; dp = dd; dd = dh;
+            dh = canon(sq.next());
+            if (!dp.valid() && !dm.valid()) break;
+            body(std::integral_constant<int, 0>{}); // (steps 0, 2, ... are pooled here: set 0)
+            dm = dp; dp = dd; dd = dh;
+            dh = canon(sq.next());
+            if (!dp.valid() && !dm.valid()) break;
+            body(std::integral_constant<int, 1>{});
+        }
+        if (DIAG && a.diag && (a.debug & 0x80) && tid == ((a.debug >> 8) & 15) * 64)
+            for (int k = 0; k < 8; ++k) a.diag[(size_t)blockIdx.x * 8 + k] = stamp[k];
+    };
+    if (wave >= kMatWaves) {
+        __builtin_amdgcn_s_setprio(1); // the pooling wave is the busier third of its SIMD: it goes first
+#ifndef VFA_PIPE_NO_POOL
+        run(std::true_type{});
+#endif
+    } else {
+#ifndef VFA_PIPE_NO_MAT
+        run(std::false_type{});
+#endif
+    }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct PipeLayout {
+    size_t live[kMaxScales], tickets, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, partial, diag, total;
+    int tiles_l, tiles_w, n_tiles;
+};
+inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
+{
+    PipeLayout w;
+    w.tiles_l = (L + kTileL - 1) / kTileL;
+    w.tiles_w = (W + kTileW - 1) / kTileW;
+    w.n_tiles = w.tiles_l * w.tiles_w;
+    size_t off = 0;
+    for (int s = 0; s < kMaxScales; ++s) { // view masks and tickets first, contiguous: zeroed by ONE memset
+        w.live[s] = off;
+        off = align_up(off + (s < n_scales ? (size_t)w.n_tiles * 4 : 0), 256);
+    }
+    w.tickets = off;
+    off = align_up(off + (size_t)w.n_tiles * 4, 256);
+    w.masks_bytes = off;
+    const size_t items = (size_t)w.n_tiles * nl * n_views;
+    for (int s = 0; s < kMaxScales; ++s) {
+        const bool on = s < n_scales;
+        w.hdrs[s] = off;  off = align_up(off + (on ? items * kHdrBytes : 0), 256);
+        w.recs[s] = off;  off = align_up(off + (on ? items * kTileBoxes * kRecBytes : 0), 256);
+        w.wfrag[s] = off; off = align_up(off + (on ? (size_t)nl * 8 * kSteps * 2 * 64 * 16 : 0), 256);
+    }
+    w.chunks = off;  off = align_up(off + (kChunks + 1) * sizeof(int), 256);
+    w.ranks = off;   off = align_up(off + (kChunks + 1) * sizeof(int), 256);
+    w.partial = off; off = align_up(off + (size_t)kMaxBlocks * 2 * 8 * 16 * 64 * sizeof(float), 256);
+    w.diag = off;    off = align_up(off + (size_t)kMaxBlocks * 8 * sizeof(unsigned long long), 256);
+    w.total = off;
+    return w;
+}
+
+inline bool dims_ok(int n_views, int L, int W, int nl, int n_scales)
+{
+    return n_views >= 0 && L >= 0 && W >= 0 && nl >= 1 && n_scales >= 1 && n_scales <= kMaxScales;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t vfa_pipe_workspace_bytes(int n_views, int L, int W, int n_layers, int n_scales)
+{
+    if (!dims_ok(n_views, L, W, n_layers, n_scales)) return 0;
+    return layout_of(n_views, L, W, n_layers, n_scales).total;
+}
+
+int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_scales, size_t *offsets, int *tiles)
+{
+    if (!dims_ok(n_views, L, W, n_layers, n_scales) || !offsets || !tiles) return VFA_ERR_BAD_ARGUMENT;
+    const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
+    for (int k = 0; k < kMaxScales; ++k) {
+        offsets[4 * k + 0] = lay.live[k];
+        offsets[4 * k + 1] = lay.hdrs[k];
+        offsets[4 * k + 2] = lay.recs[k];
+        offsets[4 * k + 3] = lay.wfrag[k];
+    }
+    offsets[12] = lay.tickets;
+    offsets[13] = lay.chunks;
+    offsets[14] = lay.ranks;
+    offsets[15] = lay.diag;
+    offsets[16] = lay.total;
+    tiles[0] = lay.tiles_l;
+    tiles[1] = lay.tiles_w;
+    tiles[2] = kWinSlots;
+    tiles[3] = kChunks;
+    return 0;
+}
+
+int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off, int n_views,
+                       int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales, const int *feat_hw,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!dims_ok(n_views, L, W, n_layers, n_scales) || conv_kind < 0 || conv_kind > 2 || !feat_hw) return VFA_ERR_BAD_ARGUMENT;
+    if (n_views > 32) return VFA_ERR_UNSUPPORTED; // live-view masks are 32 bits wide
+    const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
+    if (lay.n_tiles == 0 || n_views == 0) return 0;
+    if ((long long)n_views * lay.n_tiles >= (1ll << 31) - 2) return VFA_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < lay.total) return VFA_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    RecordArgs a;
+    a.g = BoxGeom{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
+    a.n_views = n_views; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles; a.n_scales = n_scales; a.nl = n_layers;
+    for (int k = 0; k < kMaxScales; ++k) {
+        a.dims[k].Hf = k < n_scales ? feat_hw[2 * k] : 1;
+        a.dims[k].Wf = k < n_scales ? feat_hw[2 * k + 1] : 1;
+        if (a.dims[k].Hf <= 0 || a.dims[k].Wf <= 0 || a.dims[k].Hf > 65533 || a.dims[k].Wf > 65533) return VFA_ERR_BAD_ARGUMENT;
+        // (tap positions of a direct item are byte offsets into one view's padded image, 32 bits)
+        if ((unsigned long long)(a.dims[k].Hf + 2) * (a.dims[k].Wf + 2) * kSlotBytes >= (1ull << 32)) return VFA_ERR_UNSUPPORTED;
+        a.live[k] = reinterpret_cast<unsigned *>(ws + lay.live[k]);
+        a.hdrs[k] = ws + lay.hdrs[k];
+        a.recs[k] = ws + lay.recs[k];
+    }
+    const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s); // view masks and tile tickets
+    if (e != hipSuccess) return (int)e;
+    const long long pairs = (long long)n_views * lay.n_tiles;
+    hipLaunchKernelGGL(pipe_records_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(kWave), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, const float *const *weights, void *workspace,
+                      size_t workspace_bytes, void *stream)
+{
+    if (!dims_ok(n_views, L, W, n_layers, n_scales)) return VFA_ERR_BAD_ARGUMENT;
+    if (n_views > 32) return VFA_ERR_UNSUPPORTED;
+    const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
+    if (lay.n_tiles == 0 || n_views == 0) return 0;
+    if (!workspace || workspace_bytes < lay.total) return VFA_ERR_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    CutArgs ca;
+    for (int k = 0; k < kMaxScales; ++k) ca.live[k] = reinterpret_cast<const unsigned *>(ws + lay.live[k < n_scales ? k : 0]);
+    ca.n_scales = n_scales; ca.n_tiles = lay.n_tiles; ca.n_views = n_views; ca.nl = n_layers;
+    ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
+    ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);
+    hipLaunchKernelGGL(pipe_cuts_kernel, dim3(1), dim3(1024), 0, s, ca);
+    int st = (int)hipGetLastError();
+    if (st) return st;
+    if (weights) {
+        SplitArgs sa;
+        sa.nl = n_layers;
+        for (int k = 0; k < kMaxScales; ++k) {
+            sa.w[k] = weights[k < n_scales ? k : 0];
+            sa.out[k] = reinterpret_cast<uint4 *>(ws + lay.wfrag[k < n_scales ? k : 0]);
+            if (!sa.w[k]) return VFA_ERR_BAD_ARGUMENT;
+        }
+        hipLaunchKernelGGL(pipe_split_weight_kernel, dim3(8 * kSteps * 64 / 256, n_scales * n_layers), dim3(256), 0, s, sa);
+        st = (int)hipGetLastError();
+    }
+    return st;
+}
+
+int vfa_pipe_records_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off,
+                         int n_views, int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
+                         const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int st = vfa_pipe_boxes_f32(calibs, grid, z_layers, n_layers, corner_off, n_views, L, W, conv_kind, img_w, img_h, cmin, cmax,
+                                      n_scales, feat_hw, workspace, workspace_bytes, stream);
+    if (st) return st;
+    return vfa_pipe_cuts_f32(n_views, L, W, n_layers, n_scales, weights, workspace, workspace_bytes, stream);
+}
+
+int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, void *workspace, size_t workspace_bytes,
+                                   float *out, int n_views, int L, int W, int n_layers, int n_scales, const int *feat_hw, int accumulate,
+                                   int flags, void *stream)
+{
+    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xfff;
+    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00)) return VFA_ERR_BAD_ARGUMENT;
+    if (!dims_ok(n_views, L, W, n_layers, n_scales) || !feat_hw || !integrals || (terms != 0 && terms != 3 && terms != 4))
+        return VFA_ERR_BAD_ARGUMENT;
+    if (n_views > 32) return VFA_ERR_UNSUPPORTED;
+    const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
+    if (lay.n_tiles == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_views == 0) {
+        if (!accumulate) return (int)hipMemsetAsync(out, 0, (size_t)L * W * kC * sizeof(float), s);
+        return 0;
+    }
+    if (!workspace || workspace_bytes < lay.total || !out) return VFA_ERR_BAD_ARGUMENT;
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    PipeArgs a;
+    for (int k = 0; k < kMaxScales; ++k) {
+        const int q = k < n_scales ? k : 0;
+        a.sc[k].integral = integrals[q];
+        a.sc[k].bias = biases ? biases[q] : nullptr;
+        a.sc[k].wfrag = reinterpret_cast<const uint4 *>(ws + lay.wfrag[q]);
+        a.sc[k].live = reinterpret_cast<const unsigned *>(ws + lay.live[q]);
+        a.sc[k].hdrs = ws + lay.hdrs[q];
+        a.sc[k].recs = ws + lay.recs[q];
+        a.sc[k].Hf = feat_hw[2 * q];
+        a.sc[k].Wf = feat_hw[2 * q + 1];
+        if (!a.sc[k].integral) return VFA_ERR_BAD_ARGUMENT;
+    }
+    a.n_scales = n_scales; a.n_views = n_views; a.nl = n_layers; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles;
+    a.out = out; a.accumulate = accumulate;
+    a.chunk_start = reinterpret_cast<const int *>(ws + lay.chunks);
+    a.chunk_rank = reinterpret_cast<const int *>(ws + lay.ranks);
+    a.partial = reinterpret_cast<float *>(ws + lay.partial);
+    a.tickets = reinterpret_cast<unsigned *>(ws + lay.tickets);
+    a.diag = reinterpret_cast<unsigned long long *>(ws + lay.diag);
+    a.debug = debug;
+    int n_cu = 256;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            cus > 0)
+            n_cu = cus;
+    }
+    if (reserved_cus > 0 && n_cu - reserved_cus >= 8) n_cu -= reserved_cus;
+    int nblk = lay.n_tiles < n_cu ? lay.n_tiles : n_cu;
+    nblk = (nblk + 7) / 8 * 8; // xcd_contiguous deals whole eighths; surplus workgroups find an empty range and leave
+    if (nblk > kMaxBlocks) nblk = kMaxBlocks;
+    // every call takes its own tickets: a second pass over the same workspace (accumulate) must not see the first one's
+    const hipError_t e = hipMemsetAsync(a.tickets, 0, (size_t)lay.n_tiles * 4, s);
+    if (e != hipSuccess) return (int)e;
+    if (debug)
+        hipLaunchKernelGGL((pipe_kernel<3, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+    else if (terms == 4)
+        hipLaunchKernelGGL((pipe_kernel<4, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL((pipe_kernel<3, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+} // extern "C"

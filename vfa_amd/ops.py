@@ -464,3 +464,94 @@ def frame_workspace_layout(n_views, L, W, n_scales):
                chunks=int(off[23]), ranks=int(off[24]),
                tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the frame as a producer / consumer pipeline, any number of z-layers (vfa_pipe.hip)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def pipe_workspace_bytes(n_views, L, W, n_layers, n_scales):
+    return int(_lib.lib().vfa_pipe_workspace_bytes(int(n_views), int(L), int(W), int(n_layers), int(n_scales)))
+
+
+def pipe_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_hws, weights=None, crange=(-1, 0.95), workspace=None,
+                 cuts=True):
+    """Geometry of one frame for ``pipe_collapse``: box records and tap-window headers of every (view, cell, layer) for each
+    feature scale, the work cuts and the split collapse weights -> workspace (reference vfa_op.py:64-106).
+
+    calibs (n,3,4), grid (L,W,3) or (1,L,W,3), z_layers (nl), feat_hws = [(Hf,Wf), ...] (1..3 scales), weights = one
+    (256, 256*nl) per scale in the REFERENCE column order c*nl + layer (``collapse.weight`` as it is).  ``cuts=False``: the
+    boxes only (``pipe_cuts`` adds the rest)."""
+    _lib.require_device(calibs, grid, z_layers, corner_off)
+    grid = _f32c(grid.reshape(grid.shape[-3], grid.shape[-2], 3))
+    L, W = grid.shape[:2]
+    calibs = _f32c(calibs.reshape(-1, 12))
+    n = calibs.shape[0]
+    z_layers, corner_off = _f32c(z_layers.reshape(-1)), _f32c(corner_off.reshape(8, 3))
+    nl, ns = z_layers.numel(), len(feat_hws)
+    need = pipe_workspace_bytes(n, L, W, nl, ns)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=calibs.device)
+    hw = _lib.int_array([v for f in feat_hws for v in f])
+    args = (_lib.ptr(calibs), _lib.ptr(grid), _lib.ptr(z_layers), nl, _lib.ptr(corner_off), n, L, W, int(conv_kind),
+            float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), ns, hw)
+    if not cuts:
+        _launch("vfa_pipe_boxes_f32", *args, _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(), tag=(n, L, W, nl, ns))
+        return workspace
+    wts = None
+    if weights is not None:
+        weights = [_f32c(w) for w in weights]
+        assert len(weights) == ns and all(tuple(w.shape) == (256, 256 * nl) for w in weights)
+        _lib.require_device(*weights)
+        wts = _lib.ptr_array(weights)
+    _launch("vfa_pipe_records_f32", *args, wts, _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(),
+            tag=(n, L, W, nl, ns))
+    return workspace
+
+
+def pipe_cuts(workspace, n_views, grid_lw, n_layers, n_scales, weights=None):
+    """Second half of ``pipe_records(..., cuts=False)``: the work cuts of the persistent kernel + the split collapse weights."""
+    _lib.require_device(workspace)
+    wts = None
+    if weights is not None:
+        weights = [_f32c(w) for w in weights]
+        assert len(weights) == n_scales and all(tuple(w.shape) == (256, 256 * n_layers) for w in weights)
+        _lib.require_device(*weights)
+        wts = _lib.ptr_array(weights)
+    _launch("vfa_pipe_cuts_f32", int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_layers), int(n_scales), wts, _lib.ptr(workspace),
+            workspace.numel(), _lib.current_stream_handle(), tag=(int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_layers), int(n_scales)))
+    return workspace
+
+
+def pipe_collapse(integrals, biases, workspace, grid_lw, n_layers, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0):
+    """out (L*W, 256) (+)= sum_scale sum_view relu(vox . W^T + b) for K = n_layers * 256: pooling, collapse, ReLU, view and scale
+    sums in one persistent kernel (pooling waves and matrix waves side by side); the voxel features never touch HBM
+    (reference vfa_op.py:110-125, vfanet.py:79, 82).  workspace = ``pipe_records`` of the same frame."""
+    _lib.require_device(*integrals, workspace, out)
+    ns = len(integrals)
+    n = integrals[0].shape[0]
+    L, W = grid_lw
+    assert all(i.shape[0] == n and i.shape[3] == 256 and i.is_contiguous() and i.dtype == torch.float32 for i in integrals)
+    if out is None:
+        out = torch.empty((L * W, 256), dtype=torch.float32, device=integrals[0].device)
+        accumulate = False
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (L * W, 256)
+    biases = [None if b is None else _f32c(b) for b in (biases if biases is not None else [None] * ns)]
+    hw = _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)])
+    _launch("vfa_pipe_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array(biases), _lib.ptr(workspace),
+            workspace.numel(), _lib.ptr(out), n, L, W, int(n_layers), ns, hw, 1 if accumulate else 0,
+            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16), _lib.current_stream_handle(),
+            tag=(n, L, W, int(n_layers), tuple((i.shape[1] - 2, i.shape[2] - 2) for i in integrals)))
+    return out
+
+
+def pipe_workspace_layout(n_views, L, W, n_layers, n_scales):
+    """Offsets inside the ``pipe_records`` workspace, for tests and tools."""
+    import ctypes
+    off = (ctypes.c_size_t * 17)()
+    tiles = (ctypes.c_int * 4)()
+    _lib.call("vfa_pipe_workspace_layout", int(n_views), int(L), int(W), int(n_layers), int(n_scales), off, tiles)
+    names = ("live", "hdrs", "recs", "wfrag")
+    out = {nm: [int(off[4 * k + i]) for k in range(n_scales)] for i, nm in enumerate(names)}
+    out.update(tickets=int(off[12]), chunks=int(off[13]), ranks=int(off[14]), diag=int(off[15]), total=int(off[16]),
+               tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]))
+    return out

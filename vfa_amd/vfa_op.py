@@ -188,6 +188,88 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
                                  reserved_cus=reserved_cus, stage="main")
 
 
+# Inference with C = 256 on ANY number of z-layers: "1" (default) = geometry once per frame (`vfa_pipe_records_f32`) + ONE persistent
+# producer / consumer kernel (`vfa_pipe_collapse_relu_sum_f32`: pooling waves beside matrix waves, the accumulators of four views
+# in registers over all layers); "0" = the older paths (FUSED_POOL on single-layer grids, vox through HBM on multi-layer ones).
+PIPE = os.environ.get("VFA_AMD_PIPE", "1") == "1"
+# bound on the per-frame geometry workspace of the pipeline path; larger frames are processed in bands of grid rows
+PIPE_WS_LIMIT = int(os.environ.get("VFA_AMD_PIPE_WS_BYTES", str(3 << 30)))
+
+
+def pipe_frame_ok(mods, n_views, tensors=()):
+    """The pipelined per-frame inference path covers these projector modules (one per feature scale; any layer count, the
+    same for all) for this many cameras, and no gradient is wanted."""
+    m0 = mods[0]
+    if not (PIPE and COLLAPSE_KERNEL != "library" and 1 <= len(mods) <= 3 and 0 < n_views <= 32):
+        return False
+    if not all(m.channel == 256 and m.collapse.out_features == 256 and m.num_grid_layer == m0.num_grid_layer
+               and m.geometry_key == m0.geometry_key and getattr(m.args, "data", None) == getattr(m0.args, "data", None)
+               and tuple(m.args.image_size) == tuple(m0.args.image_size) for m in mods):
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    params = [p for m in mods for p in (m.collapse.weight, m.collapse.bias)] + [t for t in tensors if t is not None]
+    return not any(p.requires_grad for p in params)
+
+
+def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0, integrals=None):
+    """All scales, all cameras and all z-layers of one frame: ``out (L*W, 256) (+)= sum_scale sum_view relu(collapse_scale(vox))``
+    (reference vfa_op.py:61-125 for every camera and scale, vfanet.py:79, 82).
+
+    mods / features: one ``VFA`` and one (n,256,Hf,Wf) lateral batch per scale.  Integral images (one launch pair for all
+    scales), ``ops.pipe_records`` (geometry once per frame, on a second stream beside them) and ``ops.pipe_collapse`` (everything
+    else, one persistent kernel).  Inference only; needs ``pipe_frame_ok``.  Frames whose geometry workspace would exceed
+    ``PIPE_WS_LIMIT`` are processed in bands of grid rows (the bands are independent: every output row belongs to one)."""
+    if integrals is not None:
+        features = [i.permute(0, 3, 1, 2)[:, :, 1:-1, 1:-1] for i in integrals]  # views: only their shapes are read below
+    _lib.require_device(calibs, grid, *features)
+    m0 = mods[0]
+    conv_kind = _conv_kind(m0.args)
+    img_h, img_w = (float(v) for v in m0.args.image_size)  # the path uses image_size[::-1] (vfa_op.py:75)
+    if grid.dim() < 3:
+        raise ValueError("pipe_frame needs the grid as (L, W, 3) or (1, L, W, 3): the tiles follow its rows and columns")
+    grid = grid.reshape(grid.shape[-3], grid.shape[-2], 3)
+    length, width = grid.shape[0], grid.shape[1]
+    dev = features[0].device
+    n, nl, ns = calibs.shape[0], m0.num_grid_layer, len(mods)
+    z_layers, corner_off = m0._kernel_geometry(dev)
+    if out is None:
+        out = torch.empty((length * width, 256), dtype=torch.float32, device=dev)
+        accumulate = False
+    if out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != (length * width, 256):
+        raise ValueError("pipe_frame: out must be a contiguous fp32 (L*W, 256) tensor")
+    if length * width == 0:
+        return out
+    feat_hws = [tuple(f.shape[-2:]) for f in features]
+    # bands of grid rows (multiples of the 4-row tiles) that keep the geometry workspace under the limit
+    rows = length
+    while rows > 4 and ops.pipe_workspace_bytes(n, rows, width, nl, ns) > PIPE_WS_LIMIT:
+        rows = max(4, ((rows + 1) // 2 + 3) // 4 * 4)
+    with torch.no_grad():
+        cur = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if SIDE_STREAM and integrals is None else cur
+        weights = [m.collapse.weight for m in mods]  # reference layout: the weight-split kernel reads column c * nl + layer
+        biases = [m.collapse.bias for m in mods]
+        ws = torch.empty(max(ops.pipe_workspace_bytes(n, min(rows, length), width, nl, ns), 1), dtype=torch.uint8, device=dev)
+        for r0 in range(0, length, rows):
+            r1 = min(length, r0 + rows)
+            band = grid[r0:r1]
+            if side is not cur:
+                side.wait_stream(cur)  # (the previous band's kernel has read the workspace)
+            with torch.cuda.stream(side):
+                ops.pipe_records(calibs, band, z_layers, corner_off, conv_kind, (img_w, img_h), feat_hws, weights=weights,
+                                 crange=crange, workspace=ws)
+            if integrals is None:
+                integrals = ops.integral_images(features)  # all strides in one launch pair, beside the geometry
+            if side is not cur:
+                cur.wait_stream(side)
+            ops.pipe_collapse(integrals, biases, ws, (r1 - r0, width), nl, out=out[r0 * width:r1 * width], accumulate=accumulate,
+                              terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
+        if side is not cur:
+            ws.record_stream(side)
+    return out
+
+
 def window_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0):
     """Same contract as ``fused_frame``, as separate kernels per scale: geometry once per frame (``ops.frame_records``), then
     per scale the integral images, the LDS-window pooling kernel (``ops.pool_windows``: voxel features in HBM, bit-exact) and
@@ -354,10 +436,12 @@ class VFA(nn.Module):
             return out
         if n == 0:
             return out if accumulate else out.zero_()
-        if fused_frame_ok([self], n):
+        if grid.dim() >= 3 and pipe_frame_ok([self], n, (features,)):
+            return pipe_frame([self], [features], calibs, grid, crange, out=out, accumulate=accumulate, reserved_cus=reserved_cus)
+        if grid.dim() >= 3 and fused_frame_ok([self], n):
             return fused_frame([self], [features], calibs, grid, crange, out=out, accumulate=accumulate,
                                reserved_cus=reserved_cus)
-        if fused_frame_ok([self], n, "window") and n * n_cells * C * 4 <= VOX_BYTES_LIMIT:
+        if grid.dim() >= 3 and fused_frame_ok([self], n, "window") and n * n_cells * C * 4 <= VOX_BYTES_LIMIT:
             return window_frame([self], [features], calibs, grid, crange, out=out, accumulate=accumulate,
                                 reserved_cus=reserved_cus)
         with torch.no_grad():
@@ -381,7 +465,7 @@ class VFA(nn.Module):
         length, width = grid.shape[-3], grid.shape[-2]
         if visualize:
             self.visualize_cube(feature, calib, grid, crange)
-        if self.mfma_collapse_ok(feature):
+        if self.mfma_collapse_ok(feature) or (grid.dim() >= 3 and pipe_frame_ok([self], 1, (feature,))):
             ortho = self.project_sum(feature, calib.reshape(1, 3, 4), grid, crange)
         else:
             lin = self.project_views(feature, calib.reshape(1, 3, 4), grid, crange)
