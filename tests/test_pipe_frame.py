@@ -91,6 +91,7 @@ def test_pipe_equals_the_serial_fused_kernel_bit_for_bit_on_single_layer_grids(n
     L, W = grid.shape[1:3]
     with torch.no_grad():
         monkeypatch.setattr(vfa_op, "PIPE", True)
+        monkeypatch.setattr(vfa_op, "PIPE_SINGLE_LAYER", True)
         with ops.KernelTimer() as kt:
             piped = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
         torch.cuda.synchronize()
@@ -102,11 +103,22 @@ def test_pipe_equals_the_serial_fused_kernel_bit_for_bit_on_single_layer_grids(n
         assert "vfa_pool_collapse_relu_sum_f32" in kt.summary() and PIPE_ENTRY not in kt.summary(), sorted(kt.summary())
         monkeypatch.setattr(vfa_op, "PIPE", True)
         again = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        # Both kernels add the parts of a tile that was cut between two workgroups in another association than an uncut tile
+        # (and cut at different places), so bitwise equality holds on the tiles neither of them cut: launch both on 8
+        # workgroups (VFA_FLAG_RESERVED_CUS(248)): at most 7 cut tiles each
+        p8 = vfa_op.pipe_frame(mods, lats, calibs, grid, reserved_cus=248)
+        s8 = vfa_op.fused_frame(mods, lats, calibs, grid, reserved_cus=248)
     assert torch.isfinite(piped).all()
     p = piped[0].permute(1, 2, 0).reshape(L * W, 256)
     s = serial[0].permute(1, 2, 0).reshape(L * W, 256)
-    bad = (p != s).any(1).nonzero().flatten()
-    assert bad.numel() == 0, f"{bad.numel()} of {L * W} cells differ, first {bad[:8].tolist()}, max |diff| {(p - s).abs().max().item():.3e}"
+    _check(f"{name} pipe vs serial kernel, full launch", p, s.double())
+    tl, tw = (L + 3) // 4, (W + 7) // 8
+    cell = torch.arange(L * W, device=dev)
+    tile_of = (cell // W // 4) * tw + (cell % W) // 8
+    bad_tiles = torch.unique(tile_of[(p8 != s8).any(1)])
+    assert bad_tiles.numel() <= 14, f"{bad_tiles.numel()} of {tl * tw} tiles differ on 8 workgroups: {bad_tiles[:16].tolist()}, " \
+                                    f"max |diff| {(p8 - s8).abs().max().item():.3e}"
+    _check(f"{name} pipe vs serial kernel, 8 workgroups", p8, s8.double())
     assert torch.equal(again, piped)  # deterministic, shared tiles included (fixed addition order of the parts)
 
 
@@ -250,7 +262,7 @@ def test_pipe_single_scale_accumulate_degenerate_grids_and_bands(monkeypatch):
         out = mods[2](wl["features"][0][2].to(dev), away, grid)
     want = torch.relu(mods[2].collapse.bias.detach()).expand(21 * 40, 256)
     assert torch.equal(out[0].permute(1, 2, 0).reshape(-1, 256), want)
-    # bands: a workspace limit that forces several passes over bands of grid rows gives the same map bit for bit
+    # bands: a workspace limit that forces several passes over bands of grid rows gives the same map
     grid = wl["grid"][:, 30:83, 20:101].contiguous().to(dev)
     lats = [torch.cat([wl["features"][c][s] for c in range(2)]).to(dev) for s in range(3)]
     calibs = wl["calibs"].to(dev)
@@ -261,7 +273,8 @@ def test_pipe_single_scale_accumulate_degenerate_grids_and_bands(monkeypatch):
             banded = vfa_op.pipe_frame(mods, lats, calibs, grid)
         torch.cuda.synchronize()
     assert kt.summary()[PIPE_ENTRY]["launches"] >= 3
-    assert torch.equal(whole, banded)
+    # (the bands cut tiles between workgroups at other places: another association of the sums of those tiles)
+    _check("banded vs whole", banded, whole.double())
 
 
 def test_pipe_work_cuts_match_the_serial_restatement():

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Diagnostics of the pipelined frame kernel (vfa_pipe.hip) on a named workload: launch time of `vfa_pipe_collapse_relu_sum_f32`,
+of the geometry pass and of the serial fused kernel beside it (single-layer grids), phase ablations (VFA_FLAG_DEBUG: 1 no
+window DMA, 2 no pooling, 4 no MFMA) and per-wave cycle stamps (128 | wave << 8).  Numbers only; ablated results are meaningless.
+
+    python tools/bench_pipe.py [workload] [--stamps]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import vfa_amd  # noqa: E402
+from vfa_amd import _lib, ops  # noqa: E402
+from vfa_amd.synthetic import make_workload  # noqa: E402
+
+name = next((a for a in sys.argv[1:] if not a.startswith("--")), "multiviewc_200x200x1")
+stamps = "--stamps" in sys.argv
+dev = torch.device("cuda:0")
+wl = make_workload(name, channels=256, seed=0)
+n = wl["n_cam"]
+torch.manual_seed(0)
+mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
+nl = mods[0].num_grid_layer
+lats = [torch.cat([wl["features"][c][s] for c in range(n)]).to(dev) for s in range(3)]
+calibs, grid = wl["calibs"].to(dev), wl["grid"].to(dev)
+L, W = grid.shape[1:3]
+rows = L
+while rows > 4 and ops.pipe_workspace_bytes(n, rows, W, nl, 3) > (3 << 30):
+    rows = max(4, ((rows + 1) // 2 + 3) // 4 * 4)
+if rows < L:
+    print(f"(frame of {L} rows measured on its first band of {rows} rows)")
+    L = rows
+    grid = grid[:, :L].contiguous()
+zl, co = mods[0]._kernel_geometry(dev)
+kind = _lib.CONV_KIND[wl["args"].data]
+img_wh = wl["args"].image_size[::-1]
+sizes = [tuple(l.shape[-2:]) for l in lats]
+
+
+def timed(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+with torch.no_grad():
+    integrals = ops.integral_images(lats)
+    weights = [m.collapse.weight for m in mods]
+    biases = [m.collapse.bias for m in mods]
+    ws = ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights)
+    t_rec = timed(lambda: ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws))
+    t_box = timed(lambda: ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, workspace=ws, cuts=False))
+    ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws)
+    t_int = timed(lambda: ops.integral_images(lats))
+    out = torch.empty(L * W, 256, device=dev)
+    # header statistics
+    lay = ops.pipe_workspace_layout(n, L, W, nl, 3)
+    tiles = lay["tiles_l"] * lay["tiles_w"]
+    items_live = 0
+    for s in range(3):
+        hdr = ws[lay["hdrs"][s]:lay["hdrs"][s] + tiles * nl * n * 32].cpu().numpy().view(np.uint32).reshape(-1, 8)
+        live = (hdr[:, 0] & 1) == 1
+        direct = live & (((hdr[:, 0] >> 1) & 1) == 1)
+        slots = hdr[:, 1][live & ~direct]
+        items_live += int(live.sum())
+        print(f"  scale {s}: items {hdr.shape[0]}, live {int(live.sum())}, pooled from L2 {int(direct.sum())}, "
+              f"window slots mean {slots.mean() if slots.size else 0:.1f} max {slots.max() if slots.size else 0}")
+    print(f"{name}: {n} views, {L}x{W}x{nl}, {tiles} tiles | geometry {t_rec:.1f} us (boxes {t_box:.1f}) | integral images {t_int:.1f} us | "
+          f"workspace {ws.numel() / 1e6:.0f} MB")
+    t_full = timed(lambda: ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out), reps=20, warm=10)
+    flops = items_live * 3 * 2 * 32 * 256 * 256
+    print(f"  pipe_collapse           {t_full:9.1f} us   {items_live} live 32x256x256 products: {flops / t_full / 1e6:7.1f} TFLOP/s bf16 issued-equivalent "
+          f"({flops / t_full / 1e6 / 2500:.3f} of the dense peak), {t_full * 1e-6 * 2.4e9 * 256 / max(items_live, 1):.0f} CU-cycles @2.4GHz per product")
+    if nl == 1:
+        ws_old = ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=[m.layer_major_weight().contiguous() for m in mods])
+        t_old = timed(lambda: ops.pool_collapse(integrals, biases, ws_old, (L, W), out=out), reps=20, warm=10)
+        print(f"  serial fused kernel     {t_old:9.1f} us")
+    for mask, label in ((1, "no window DMA"), (2, "no pooling"), (4, "no MFMA"), (6, "no pooling, no MFMA"), (7, "skeleton only")):
+        us = timed(lambda: ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=mask))
+        print(f"  pipe_collapse [{label:>20}] {us:9.1f} us")
+    if stamps:
+        names = ["step head", "wait for W", "pool / DMA issue", "multiply", "generator + wait for DMA", "tile finish", "barrier", "steps"]
+        for wave in (0, 3, 4, 7, 8, 9, 10, 11):
+            ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=128 | (wave << 8))
+            torch.cuda.synchronize()
+            d = ws[lay["diag"]:lay["diag"] + 512 * 64].cpu().numpy().view(np.uint64).reshape(512, 8).astype(np.float64)
+            d = d[d[:, 7] > 0]
+            steps = d[:, 7]
+            per = d[:, :7].sum(0) / steps.sum()
+            role = "pool" if wave >= 8 else "matrix"
+            print(f"  wave {wave:2d} ({role}): cycles per step " + ", ".join(f"{names[k]} {per[k]:.0f}" for k in range(7) if wave < 8 or k not in (1, 3, 4))
+                  + f" | total {per.sum():.0f}, steps per workgroup {steps.mean():.0f} (max/mean {steps.max() / steps.mean():.3f}), "
+                  f"cycles per workgroup max/mean {d[:, :7].sum(1).max() / d[:, :7].sum(1).mean():.3f}")

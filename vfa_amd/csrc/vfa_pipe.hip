@@ -379,6 +379,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
     __shared__ __align__(16) unsigned char s_rec[4 * kTileBoxes * kRecBytes]; // box records of the group's sub-tiles, one layer
     __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
     __shared__ unsigned s_misc[16];
+    __shared__ __align__(16) unsigned s_steps[4][4];                        // the next steps, generated by wave 0: [index & 3][tile, views, w, -]
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63;
 
     const int nblk = gridDim.x;
@@ -469,41 +470,40 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                              (__attribute__((address_space(3))) void *)(&s_hdr[st.phase() & 3][0]), 4, 0, 0);
         };
-        // tap windows (and, at the first quarter of a layer, the box records) of the sub-tiles of step `st`
+        // Tap window (and, at the first quarter of a layer, the box records) of ONE sub-tile of step `st`: waves 0-3 fetch for the
+        // first sub-tile of the set, waves 4-7 for the second -- a wave then walks one header / view / image chain, not two.
         auto step_dma = [&](const PStep &st) {
+            const int x = wave >> 2, wq4 = wave & 3, j = 2 * st.set() + x;
+            if (j >= st.nj()) return;
+            // flags and slot count into scalar registers (they steer branches and the loop); the window geometry stays in vector
+            // registers (the same value in every lane): it only feeds the per-lane address arithmetic
+            const uint4 *hp = reinterpret_cast<const uint4 *>(&s_hdr[st.phase() & 3][j * 8]);
+            const uint4 h0 = hp[0], h1 = hp[1];
             const PipeScale &sc = a.sc[st.scale()];
             const int wp = sc.Wf + 2;
-            int hw[2][8];
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) hw[x][k] = hdr_word(st.phase(), min(2 * st.set() + x, 3), k);
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const int j = 2 * st.set() + x;
-                if (j >= st.nj() || !(hw[x][0] & kTileLive)) continue;
-                const int view = st.view(j);
-                const size_t item = ((size_t)st.tile * a.nl + st.layer()) * a.n_views + view;
-                if (st.q() == 0 && wave >= 3 * x && wave < 3 * x + 3) {
-                    const int k = wave - 3 * x;
-                    const unsigned char *p = sc.recs + item * kTileBoxes * kRecBytes + k * 1024 + lane * 16;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
-                                                     (__attribute__((address_space(3))) void *)(s_rec + j * kTileBoxes * kRecBytes + k * 1024), 16, 0, 0);
-                }
-                if (hw[x][0] & kTileDirect) continue;
-                const int n_slots = hw[x][1], cw = hw[x][2], inv = hw[x][3], x0 = hw[x][4], t0 = hw[x][5], top = hw[x][6], b0 = hw[x][7];
-                const int n_fill = (n_slots + 3) >> 2;
-                const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)view * (sc.Hf + 2) * wp * kSlotBytes +
-                                  st.q() * kQSlot + (lane & 15) * 16;
-                unsigned char *dst = s_win + (st.par() * 2 + x) * kWinBytes;
-                for (int f = (wave + 4 * x) & 7; f < n_fill; f += kMatWaves) { // four quarter slots per instruction, 16 lanes each
-                    const int slot = min(4 * f + (lane >> 4), n_slots - 1);
-                    const int wr = (slot * inv) >> 16, wc = slot - wr * cw;
-                    const int y = wr < top ? t0 + wr : b0 + (wr - top), xx = x0 + wc;
-                    const char *src = img + (size_t)(unsigned)((y + 1) * wp + (xx + 1)) * kSlotBytes;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(dst + f * 1024), 16, 0, 0);
-                }
+            const int hflags = uniform_i((int)h0.x);
+            if (!(hflags & kTileLive)) return;
+            const int view = st.view(j);
+            const size_t item = ((size_t)st.tile * a.nl + st.layer()) * a.n_views + view;
+            if (st.q() == 0 && wq4 < 3) {
+                const unsigned char *p = sc.recs + item * kTileBoxes * kRecBytes + wq4 * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                                 (__attribute__((address_space(3))) void *)(s_rec + j * kTileBoxes * kRecBytes + wq4 * 1024), 16, 0, 0);
+            }
+            if ((hflags & kTileDirect) || (DIAG && (a.debug & 1))) return; // (diagnostic 1: no window fills; the records still come)
+            const int n_slots = uniform_i((int)h0.y);
+            const int cw = (int)h0.z, inv = (int)h0.w, x0 = (int)h1.x, t0 = (int)h1.y, top = (int)h1.z, b0 = (int)h1.w;
+            const int n_fill = (n_slots + 3) >> 2;
+            const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)view * (sc.Hf + 2) * wp * kSlotBytes +
+                              st.q() * kQSlot + (lane & 15) * 16;
+            unsigned char *dst = s_win + (st.par() * 2 + x) * kWinBytes;
+            for (int f = wq4; f < n_fill; f += 4) { // four quarter slots per instruction, 16 lanes each
+                const int slot = min(4 * f + (lane >> 4), n_slots - 1);
+                const int wr = (slot * inv) >> 16, wc = slot - wr * cw;
+                const int y = wr < top ? t0 + wr : b0 + (wr - top), xx = x0 + wc;
+                const char *src = img + (size_t)(unsigned)((y + 1) * wp + (xx + 1)) * kSlotBytes;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(dst + f * 1024), 16, 0, 0);
             }
         };
         // the 64 k x 32 n slice of collapse.weight of step `st` for this wave: 8 coalesced 1 KiB loads
@@ -609,6 +609,10 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                               (size_t)st.view(j) * (sc.Hf + 2) * (sc.Wf + 2) * kSlotBytes + st.q() * kQSlot;
             const int row = x * 32 + (pw & 1) * 16 + pb;
             unsigned char *planes = s_planes + st.par() * 2 * kPlaneBytes;
+            // All sixteen taps of a 16-byte piece are requested at once and consumed as they arrive (counted waits).  A hand-made
+            // software pipeline across the four pieces (the next piece's taps requested as soon as half of this piece's were
+            // consumed) measured 35 % SLOWER (4 900 against 3 620 cycles per step): more registers, spills, and the
+            // scheduling barriers it needs keep the compiler from interleaving arithmetic and reads.
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const unsigned piece = (unsigned)((pb + m) & 3);
@@ -742,24 +746,57 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         };
 
         // ---------------------------------------------------------------- the loop
-        // every field through v_readfirstlane: the steps steer branches, barriers and LDS-DMA destinations, so they must sit in
-        // scalar registers whatever the compiler's divergence analysis makes of the generator
-        auto canon = [&](const Step &s0) {
+        // ONE wave runs the generator (wave 0, ~150 scalar instructions per call: run by all twelve waves it kept the CU's scalar
+        // unit busy for 900-1600 cycles per step) and hands whole PHASES -- (group, layer): eight steps -- to the others through a
+        // ring in LDS; every wave expands the steps itself, a dozen scalar instructions each.  Everything that steers branches,
+        // barriers and LDS-DMA destinations goes through v_readfirstlane: it must sit in scalar registers.
+        PStep dm, dp, dd, dh; // the steps being multiplied, pooled, fetched; the one whose headers are fetched
+        Sequencer<DevMasks> sq;
+        auto produce = [&](int n) { // (wave 0) phase n -> LDS: tile, views, scale | layer << 2 | nj << 15 | more << 20 | phase << 22
+            const Phase ph = sq.next_phase();
+            const unsigned w = (unsigned)ph.scale | ((unsigned)ph.layer << 2) | ((unsigned)ph.nj << 15) | (ph.more_in_tile ? 1u << 20 : 0u) |
+                               ((unsigned)(ph.phase & 255) << 22);
+            if (lane == 0) *reinterpret_cast<uint4 *>(&s_steps[n & 3][0]) = make_uint4((unsigned)ph.tile, ph.views, w, 0u);
+        };
+        PStep php;       // the phase of `dh` (w: as written by produce)
+        int ph_no = 0;   // ... its number, ... and the step of it that `dh` is
+        int k8 = 0, par = 0;
+        auto load_phase = [&](int n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&s_steps[n & 3][0]);
+            php.tile = uniform_i((int)v.x); php.views = (unsigned)uniform_i((int)v.y); php.w = (unsigned)uniform_i((int)v.z);
+        };
+        auto expand = [&]() { // step k8 of phase php
             PStep c;
-            c.tile = uniform_i(s0.tile);
-            c.views = (unsigned)uniform_i((int)s0.views);
-            c.w = (unsigned)uniform_i((int)((unsigned)s0.scale | ((unsigned)s0.layer << 2) | ((unsigned)s0.q << 12) | ((unsigned)s0.set << 14) |
-                                            ((unsigned)s0.nj << 15) | (s0.grp_first ? 1u << 18 : 0u) | (s0.grp_last ? 1u << 19 : 0u) |
-                                            (s0.tile_last ? 1u << 20 : 0u) | ((unsigned)(s0.index & 1) << 21) | ((unsigned)(s0.phase & 255) << 22)));
+            c.tile = php.tile; c.views = php.views;
+            const unsigned q = (unsigned)k8 >> 1, set = (unsigned)k8 & 1u, layer = (php.w >> 2) & 1023u;
+            const bool gf = layer == 0u && q == 0u, gl = layer == (unsigned)(a.nl - 1) && q == 3u;
+            const bool tl = gl && set == 1u && !((php.w >> 20) & 1u);
+            c.w = (php.w & ~(1u << 20)) | (q << 12) | (set << 14) | (gf ? 1u << 18 : 0u) | (gl ? 1u << 19 : 0u) | (tl ? 1u << 20 : 0u) |
+                  ((unsigned)par << 21);
             return c;
         };
-        Sequencer<DevMasks> sq;
-        sq.masks = masks;
-        sq.begin(a.n_scales, a.nl, t_begin, k_begin, t_end, k_end);
-        PStep dm, dp, dd, dh; // the steps being multiplied, pooled, fetched; the one whose headers are fetched
-        dm.tile = -1; dp.tile = -1;
-        dd = canon(sq.next());
-        dh = canon(sq.next());
+        auto advance = [&]() { // the next step into `dh`
+            if (!php.valid()) { dh = php; return; }
+            par ^= 1;
+            if (++k8 == 8) {
+                k8 = 0;
+                load_phase(++ph_no);
+            }
+            dh = php.valid() ? expand() : php;
+        };
+        if (wave == 0) {
+            sq.masks = masks;
+            sq.begin(a.n_scales, a.nl, t_begin, k_begin, t_end, k_end);
+            produce(0); produce(1); produce(2);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dm.tile = -1; dp.tile = -1; dm.views = dp.views = 0u; dm.w = dp.w = 0u;
+        load_phase(0);
+        dd = php.valid() ? expand() : php;
+        dh = dd;
+        advance();
         empty_tiles(k_begin == 0 ? t_begin : t_begin + 1, dd.valid() ? dd.tile : t_end);
         if (!dd.valid()) return;
         unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
@@ -794,36 +831,47 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             if constexpr (POOL) {
                 if (dp.valid()) pool_step(std::integral_constant<int, PSET>{}, dp);
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                tick(1);
+                tick(2);
             } else {
                 // the weight slice requested during the last step (and tile stores).  The BUILTIN, not assembly: it tells the
                 // compiler's wait-count model that nothing is pending; otherwise it waits for those loads itself -- vmcnt(0) in front
                 // of the first MFMA, behind the DMA issued below: a memory round trip per step
                 __builtin_amdgcn_s_waitcnt(0x0f70);
-                if (dd.valid() && !(DIAG && (a.debug & 1))) step_dma(dd);
-                if (dh.valid() && (!dd.valid() || dh.phase() != dd.phase())) hdr_dma(dh);
                 tick(1);
-                if (dm.valid()) multiply(std::integral_constant<int, MSET>{}, dm, dp.valid() ? dp : dm);
+                // The two matrix waves of a SIMD take their two jobs in opposite order: waves 0-3 request the next step's
+                // windows (a chain of scalar work and LDS / scalar-cache round trips, ~1500 cycles) and then multiply, waves 4-7
+                // multiply first -- one of the pair is on the matrix pipe while the other does its address arithmetic.
+                const bool dma_first = wave < 4;
+                if (dma_first) {
+                    if (dd.valid()) step_dma(dd);
+                    if (dh.valid() && (!dd.valid() || dh.phase() != dd.phase())) hdr_dma(dh);
+                }
                 tick(2);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // windows / records / headers of the next step have landed
+                if (dm.valid()) multiply(std::integral_constant<int, MSET>{}, dm, dp.valid() ? dp : dm);
                 tick(3);
+                if (!dma_first) {
+                    if (dd.valid()) step_dma(dd);
+                }
+                if (wave == 0 && k8 == 0 && php.valid()) produce(ph_no + 2); // (`dh` has just entered phase ph_no: two phases ahead)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // windows / records / headers of the next step have landed
+                tick(4);
             }
             if constexpr (MSET == 1) {
                 if (__builtin_expect(dm.valid() && dm.tile_last(), 0)) finish_tile(dm, dp.valid() ? dp.tile : t_end);
             }
-            tick(4);
+            tick(5);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            tick(5);
+            tick(6);
             if (DIAG) stamp[7] += 1;
         };
         for (;;) {
             dm = dp; dp = dd; dd = dh;
-            dh = canon(sq.next());
+            advance();
             if (!dp.valid() && !dm.valid()) break;
             body(std::integral_constant<int, 0>{}); // (steps 0, 2, ... are pooled here: set 0)
             dm = dp; dp = dd; dd = dh;
-            dh = canon(sq.next());
+            advance();
             if (!dp.valid() && !dm.valid()) break;
             body(std::integral_constant<int, 1>{});
         }

@@ -59,7 +59,29 @@ struct Step {
     VFA_SEQ_HD bool same_chunk(const Step &o) const { return scale == o.scale && layer == o.layer && q == o.q; }
 };
 
-// Generator of the steps of one workgroup.  `Masks` returns the live-view mask of (scale, tile).
+// A phase = (group, layer): eight steps, quarter q = k >> 1, set = k & 1 for k = 0 .. 7.  The kernel hands PHASES from the one
+// wave that runs the generator to the others (through LDS) and every wave derives the steps itself (step_of).
+struct Phase {
+    int tile;        // < 0: no phase
+    int scale, layer, nj;
+    unsigned views;
+    int phase, rank;
+    bool more_in_tile; // another group of this workgroup follows in the same tile
+    VFA_SEQ_HD bool valid() const { return tile >= 0; }
+};
+
+VFA_SEQ_HD Step step_of(const Phase &ph, int k, int nl, int index)
+{
+    Step st;
+    st.tile = ph.tile; st.scale = ph.scale; st.layer = ph.layer; st.q = k >> 1; st.set = k & 1; st.nj = ph.nj; st.views = ph.views;
+    st.phase = ph.phase; st.rank = ph.rank; st.index = index;
+    st.grp_first = ph.layer == 0 && st.q == 0;
+    st.grp_last = ph.layer == nl - 1 && st.q == 3;
+    st.tile_last = st.grp_last && st.set == 1 && !ph.more_in_tile;
+    return st;
+}
+
+// Generator of the phases / steps of one workgroup.  `Masks` returns the live-view mask of (scale, tile).
 template <class Masks>
 struct Sequencer {
     Masks masks;
@@ -82,7 +104,7 @@ struct Sequencer {
     {
         n_scales = n_scales_; nl = nl_; t_end = t_end_; k_end = k_end_;
         t_lim = k_end > 0 ? t_end + 1 : t_end;
-        tile = t_begin; scale = 0; rank = 0; layer = q = set = 0; nj = 0; phase = -1; index = -1;
+        tile = t_begin; scale = 0; rank = 0; layer = q = set = 0; nj = 0; phase = -1; index = -1; cur.tile = -1;
         views = 0; in_group = false; more_in_tile = false;
         load_tile();
         rest = m0;
@@ -121,36 +143,34 @@ struct Sequencer {
         }
         return false;
     }
-    VFA_SEQ_HD Step next()
+    VFA_SEQ_HD Phase next_phase()
     {
-        Step st;
-        st.tile = -1; st.scale = st.layer = st.q = st.set = st.nj = 0; st.views = 0; st.phase = st.rank = st.index = 0;
-        st.grp_first = st.grp_last = st.tile_last = false;
-        if (in_group) { // advance inside the group: set, then quarter, then layer
-            if (set == 0) set = 1;
-            else {
-                set = 0;
-                if (q + 1 < 4) ++q;
-                else {
-                    q = 0;
-                    if (layer + 1 < nl) { ++layer; ++phase; }
-                    else { in_group = false; ++rank; }
-                }
-            }
+        Phase ph;
+        ph.tile = -1; ph.scale = ph.layer = ph.nj = 0; ph.views = 0; ph.phase = ph.rank = 0; ph.more_in_tile = false;
+        if (in_group) {
+            if (layer + 1 < nl) ++layer;
+            else { in_group = false; ++rank; }
         }
         if (!in_group) {
-            if (!next_group()) return st;
+            if (!next_group()) return ph;
             in_group = true;
-            layer = q = set = 0;
-            ++phase;
+            layer = 0;
         }
+        ++phase;
+        ph.tile = tile; ph.scale = scale; ph.layer = layer; ph.nj = nj; ph.views = views; ph.phase = phase; ph.rank = rank;
+        ph.more_in_tile = more_in_tile;
+        return ph;
+    }
+    // the steps one by one (CPU harness; the kernel expands the phases itself)
+    Phase cur;
+    VFA_SEQ_HD Step next()
+    {
+        if (index < 0 || q == 7) { cur = next_phase(); q = 0; }
+        else ++q; // (q doubles as the step counter inside the phase here)
+        if (!cur.valid()) { Step st; st.tile = -1; st.scale = st.layer = st.q = st.set = st.nj = 0; st.views = 0; st.phase = st.rank = st.index = 0;
+                            st.grp_first = st.grp_last = st.tile_last = false; q = 7; index = index < 0 ? 0 : index; return st; }
         ++index;
-        st.tile = tile; st.scale = scale; st.layer = layer; st.q = q; st.set = set; st.nj = nj; st.views = views;
-        st.phase = phase; st.rank = rank; st.index = index;
-        st.grp_first = layer == 0 && q == 0;
-        st.grp_last = layer == nl - 1 && q == 3;
-        st.tile_last = st.grp_last && set == 1 && !more_in_tile;
-        return st;
+        return step_of(cur, q, nl, index);
     }
 };
 

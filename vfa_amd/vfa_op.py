@@ -192,6 +192,8 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
 # producer / consumer kernel (`vfa_pipe_collapse_relu_sum_f32`: pooling waves beside matrix waves, the accumulators of four views
 # in registers over all layers); "0" = the older paths (FUSED_POOL on single-layer grids, vox through HBM on multi-layer ones).
 PIPE = os.environ.get("VFA_AMD_PIPE", "1") == "1"
+# ... on single-layer grids too ("0": the serial kernel of vfa_fused.hip keeps them, `FUSED_POOL`)
+PIPE_SINGLE_LAYER = os.environ.get("VFA_AMD_PIPE_SINGLE_LAYER", "0") == "1"
 # bound on the per-frame geometry workspace of the pipeline path; larger frames are processed in bands of grid rows
 PIPE_WS_LIMIT = int(os.environ.get("VFA_AMD_PIPE_WS_BYTES", str(3 << 30)))
 
@@ -201,6 +203,8 @@ def pipe_frame_ok(mods, n_views, tensors=()):
     same for all) for this many cameras, and no gradient is wanted."""
     m0 = mods[0]
     if not (PIPE and COLLAPSE_KERNEL != "library" and 1 <= len(mods) <= 3 and 0 < n_views <= 32):
+        return False
+    if m0.num_grid_layer == 1 and not PIPE_SINGLE_LAYER and fused_frame_ok(mods, n_views):
         return False
     if not all(m.channel == 256 and m.collapse.out_features == 256 and m.num_grid_layer == m0.num_grid_layer
                and m.geometry_key == m0.geometry_key and getattr(m.args, "data", None) == getattr(m0.args, "data", None)
