@@ -204,7 +204,7 @@ def pipe_frame_ok(mods, n_views, tensors=()):
     m0 = mods[0]
     if not (PIPE and COLLAPSE_KERNEL != "library" and 1 <= len(mods) <= 3 and 0 < n_views <= 32):
         return False
-    if m0.num_grid_layer == 1 and not PIPE_SINGLE_LAYER and fused_frame_ok(mods, n_views):
+    if m0.num_grid_layer == 1 and not PIPE_SINGLE_LAYER:
         return False
     if not all(m.channel == 256 and m.collapse.out_features == 256 and m.num_grid_layer == m0.num_grid_layer
                and m.geometry_key == m0.geometry_key and getattr(m.args, "data", None) == getattr(m0.args, "data", None)
