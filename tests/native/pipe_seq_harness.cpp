@@ -28,7 +28,7 @@ static void serial_cuts(const std::vector<unsigned> &live, int n_tiles, int n_sc
     for (int t = 0; t < n_tiles; ++t) {
         unsigned m[3] = {0, 0, 0};
         for (int s = 0; s < n_scales; ++s) m[s] = live[(size_t)s * n_tiles + t];
-        before[t + 1] = before[t] + walk_tile(m, n_scales, nl, [](int, unsigned, unsigned) {});
+        before[t + 1] = before[t] + walk_tile(m, n_scales, nl, 0u, [](int, unsigned, unsigned) {});
     }
     const unsigned long long total = before[n_tiles];
     start.assign(n_chunks + 1, n_tiles);
@@ -40,8 +40,8 @@ static void serial_cuts(const std::vector<unsigned> &live, int n_tiles, int n_sc
         for (int s = 0; s < n_scales; ++s) m[s] = live[(size_t)s * n_tiles + t];
         const unsigned long long tb = before[t];
         int n_groups = 0;
-        walk_tile(m, n_scales, nl, [&](int k, unsigned, unsigned) { n_groups = k + 1; });
-        const unsigned w = walk_tile(m, n_scales, nl, [&](int kk, unsigned w0, unsigned w1) {
+        walk_tile(m, n_scales, nl, 0u, [&](int k, unsigned, unsigned) { n_groups = k + 1; });
+        const unsigned w = walk_tile(m, n_scales, nl, 0u, [&](int kk, unsigned w0, unsigned w1) {
             while (c < n_chunks) {
                 const unsigned long long pc = pos_of(c);
                 if (pc >= tb + w1) break;

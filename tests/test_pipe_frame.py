@@ -300,13 +300,16 @@ def test_pipe_work_cuts_match_the_serial_restatement():
     rank = host[lay["ranks"]:lay["ranks"] + 4 * (K + 1)].view(np.int32)
     assert sum(int(l.sum() > 0) for l in live) == ns
 
-    def groups_of(t):  # costs of the groups of tile t in (scale, view) order
+    globs = host[lay["globs"]:lay["globs"] + 4 * tiles].view(np.uint32)
+
+    def groups_of(t):  # costs of the groups of tile t in (scale, view) order (vfa_pipe_seq.h: group_cost, walk_tile)
         out = []
         for s in range(ns):
             left = bin(int(live[s][t])).count("1")
             while left > 0:
                 nj = min(left, 4)
-                out.append(4 * nl * ((nj + 1) // 2) + 2 + (3 if not out else 0))
+                sets = (nj + 1) // 2
+                out.append(4 * nl * (76 * sets + 49 * (2 - sets)) + 16 + ((27 + 4 * 66 * int(globs[t])) if not out else 0))
                 left -= nj
         return out
 

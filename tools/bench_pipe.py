@@ -85,12 +85,12 @@ with torch.no_grad():
         ws_old = ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=[m.layer_major_weight().contiguous() for m in mods])
         t_old = timed(lambda: ops.pool_collapse(integrals, biases, ws_old, (L, W), out=out), reps=20, warm=10)
         print(f"  serial fused kernel     {t_old:9.1f} us")
-    for mask, label in ((1, "no window DMA"), (2, "no pooling"), (4, "no MFMA"), (6, "no pooling, no MFMA"), (7, "skeleton only")):
+    for mask, label in ((1, "no window DMA"), (2, "no pooling"), (4, "no MFMA"), (6, "no pooling, no MFMA"), (7, "skeleton only"), (32, "diagnostic build"), (8, "no setprio"), (16, "matrix waves prio 2")):
         us = timed(lambda: ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=mask))
         print(f"  pipe_collapse [{label:>20}] {us:9.1f} us")
     if stamps:
         names = ["step head", "wait for W", "pool / DMA issue", "multiply", "generator + wait for DMA", "tile finish", "barrier", "steps"]
-        for wave in (0, 3, 4, 7, 8, 9, 10, 11):
+        for wave in range(12):
             ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=128 | (wave << 8))
             torch.cuda.synchronize()
             d = ws[lay["diag"]:lay["diag"] + 512 * 64].cpu().numpy().view(np.uint64).reshape(512, 8).astype(np.float64)
@@ -101,3 +101,59 @@ with torch.no_grad():
             print(f"  wave {wave:2d} ({role}): cycles per step " + ", ".join(f"{names[k]} {per[k]:.0f}" for k in range(7) if wave < 8 or k not in (1, 3, 4))
                   + f" | total {per.sum():.0f}, steps per workgroup {steps.mean():.0f} (max/mean {steps.max() / steps.mean():.3f}), "
                   f"cycles per workgroup max/mean {d[:, :7].sum(1).max() / d[:, :7].sum(1).mean():.3f}")
+
+    if "--fit" in sys.argv:
+        # Per-workgroup cycles against what the workgroup had to do: the constants of the work-cut cost model (vfa_pipe_seq.h).
+        ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws)
+        ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=128 | (8 << 8))
+        torch.cuda.synchronize()
+        host = ws.cpu().numpy()
+        d = host[lay["diag"]:lay["diag"] + 512 * 64].view(np.uint64).reshape(512, 8).astype(np.float64)
+        K = lay["n_chunks"]
+        start = host[lay["chunks"]:lay["chunks"] + 4 * (K + 1)].view(np.int32)
+        rank = host[lay["ranks"]:lay["ranks"] + 4 * (K + 1)].view(np.int32)
+        live = [host[lay["live"][s]:lay["live"][s] + 4 * tiles].view(np.uint32) for s in range(3)]
+        hdrs = [host[lay["hdrs"][s]:lay["hdrs"][s] + tiles * nl * n * 32].view(np.uint32).reshape(tiles, nl, n, 8) for s in range(3)]
+        nblk = int((d[:, 7] > 0).sum() + 7) // 8 * 8
+        nblk = min(max(nblk, 8), 256)
+        rows = []
+        for blk in range(nblk):
+            lb = (blk & 7) * (nblk // 8) + (blk >> 3)
+            c0, c1 = K * lb // nblk, K * (lb + 1) // nblk
+            tb, kb, te, ke = int(start[c0]), int(rank[c0]), int(start[c1]), int(rank[c1])
+            real = dummy = glob = ntile = shared = groups = 0
+            for t in range(tb, min(te + (1 if ke > 0 else 0), tiles)):
+                k = 0
+                mine = False
+                for s in range(3):
+                    views = [v for v in range(n) if (int(live[s][t]) >> v) & 1]
+                    for g0 in range(0, len(views), 4):
+                        grp = views[g0:g0 + 4]
+                        ok = not (t == tb and k < kb) and not (t == te and k >= ke)
+                        k += 1
+                        if not ok:
+                            continue
+                        mine = True
+                        groups += 1
+                        for layer in range(nl):
+                            for st in range(2):
+                                sub = grp[2 * st:2 * st + 2]
+                                lv = [v for v in sub if hdrs[s][t, layer, v, 0] & 1]
+                                if lv:
+                                    real += 4
+                                    glob += 4 * sum(1 for v in lv if hdrs[s][t, layer, v, 0] & 2)
+                                else:
+                                    dummy += 4
+                if mine:
+                    ntile += 1
+                    if (t == tb and kb > 0) or (t == te and ke > 0):
+                        shared += 1
+            rows.append((blk, real, dummy, glob, ntile, shared, groups, d[blk, :7].sum()))
+        A = np.array([[r[1], r[2], r[3], r[4], r[5], r[6]] for r in rows if r[7] > 0], np.float64)
+        y = np.array([r[7] for r in rows if r[7] > 0])
+        coef, *_ = np.linalg.lstsq(A, y, rcond=None)
+        pred = A @ coef
+        print("  fit (cycles): step with work %.0f, empty step %.0f, + per sub-tile step pooled from L2 %.0f, per tile %.0f, per shared tile %.0f, per group %.0f"
+              % tuple(coef))
+        print(f"  measured max/mean {y.max() / y.mean():.3f}; residual rms {np.sqrt(np.mean((pred - y) ** 2)) / y.mean():.3f} of the mean; "
+              f"if cut by this model: max/mean of the residual-corrected load {1 + (y - pred).max() / y.mean():.3f}")

@@ -39,7 +39,7 @@ constexpr int kRecBytes = 96, kHdrBytes = 32;
 constexpr int kMaxScales = 3;
 constexpr int kSlotBytes = kC * 4;              // one tap in the integral image: 256 fp32
 constexpr int kQSlot = 256;                     // ... and the 64-channel quarter of it that a step needs
-constexpr int kWinSlots = 112;                  // LDS tap window of a (tile, view, layer, scale), in quarter slots
+constexpr int kWinSlots = 108;                  // LDS tap window of a (tile, view, layer, scale), in quarter slots
 constexpr int kWinBytes = kWinSlots * kQSlot;   // 28 KiB; four of them: two being pooled, two arriving
 constexpr int kMatWaves = 8, kPoolWaves = 4, kThreads = 64 * (kMatWaves + kPoolWaves);
 constexpr int kStepRows = 64;                   // rows of a step: two sub-tiles
@@ -68,6 +68,7 @@ struct RecordArgs {
     int n_views, L, W, tiles_w, n_tiles, n_scales, nl;
     ScaleDims dims[kMaxScales];
     unsigned *live[kMaxScales];      // (n_tiles) bit v = view v has a live box in the tile, in any layer
+    unsigned *globs;                 // (n_tiles) live (view, layer, scale) items whose tap window does not fit LDS
     unsigned char *hdrs[kMaxScales];
     unsigned char *recs[kMaxScales];
 };
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
     const float *P = a.g.calibs + (size_t)view * 12;
     const float g0 = a.g.grid[cell * 3 + 0], g1 = a.g.grid[cell * 3 + 1], g2 = a.g.grid[cell * 3 + 2];
     bool live_any[kMaxScales] = {false, false, false};
+    unsigned n_glob = 0;
 #pragma unroll 1
     for (int layer = 0; layer < a.nl; ++layer) {
         // the cube once per (view, cell, layer): scale-independent                     vfa_op.py:64-88, utils.py:56-59
@@ -180,12 +182,14 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
                 }
             }
             live_any[s] = live_any[s] || any_live;
+            if (any_live && direct) ++n_glob;
             __syncthreads(); // the stage is reused
         }
     }
     if (pair_ok && b == 0)
         for (int s = 0; s < a.n_scales; ++s)
             if (live_any[s]) atomicOr(a.live[s] + tile, 1u << view);
+    if (pair_ok && b == 0 && n_glob) atomicAdd(a.globs + tile, n_glob);
 }
 
 // collapse.weight of a scale, in the REFERENCE layout (256, 256 * nl), column = c * nl + layer (vfa_op.py:59, :120), as bf16
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(256) void pipe_split_weight_kernel(SplitArgs sa)
 // that fall into its tiles
 struct CutArgs {
     const unsigned *live[kMaxScales];
+    const unsigned *globs;
     int n_scales, n_tiles, n_views, nl;
     int *chunk_start, *chunk_rank;
 };
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
     for (int t = t0; t < t1; ++t) {
         unsigned m[kMaxScales];
         masks_of(t, m);
-        local += walk_tile(m, a.n_scales, a.nl, [](int, unsigned, unsigned) {});
+        local += walk_tile(m, a.n_scales, a.nl, a.globs[t], [](int, unsigned, unsigned) {});
     }
     part[tid] = local;
     for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_tiles; a.chunk_rank[c] = 0; }
@@ -254,8 +259,9 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
         unsigned m[kMaxScales];
         masks_of(t, m);
         int n_groups = 0;
-        walk_tile(m, a.n_scales, a.nl, [&](int kk, unsigned, unsigned) { n_groups = kk + 1; });
-        const unsigned w = walk_tile(m, a.n_scales, a.nl, [&](int kk, unsigned w0, unsigned w1) {
+        const unsigned globs = a.globs[t];
+        walk_tile(m, a.n_scales, a.nl, globs, [&](int kk, unsigned, unsigned) { n_groups = kk + 1; });
+        const unsigned w = walk_tile(m, a.n_scales, a.nl, globs, [&](int kk, unsigned w0, unsigned w1) {
             while (c < kChunks) {
                 const unsigned long long pc = pos_of(c);
                 if (pc >= tb + w1) break;
@@ -306,26 +312,6 @@ struct DevMasks {
 };
 
 struct Frag { bf16x8 hi, lo; };
-
-// a Step (vfa_pipe_seq.h) in three scalar registers: four of them are in flight per wave
-struct PStep {
-    int tile;       // < 0: no step
-    unsigned views; // view of sub-tile j in bits 8 j .. 8 j + 7
-    unsigned w;     // scale 0-1 | layer 2-11 | q 12-13 | set 14 | nj 15-17 | grp_first 18 | grp_last 19 | tile_last 20 | index & 1 21 | phase & 255 22-29
-    __device__ __forceinline__ bool valid() const { return tile >= 0; }
-    __device__ __forceinline__ int scale() const { return (int)(w & 3u); }
-    __device__ __forceinline__ int layer() const { return (int)((w >> 2) & 1023u); }
-    __device__ __forceinline__ int q() const { return (int)((w >> 12) & 3u); }
-    __device__ __forceinline__ int set() const { return (int)((w >> 14) & 1u); }
-    __device__ __forceinline__ int nj() const { return (int)((w >> 15) & 7u); }
-    __device__ __forceinline__ bool grp_first() const { return (w >> 18) & 1u; }
-    __device__ __forceinline__ bool grp_last() const { return (w >> 19) & 1u; }
-    __device__ __forceinline__ bool tile_last() const { return (w >> 20) & 1u; }
-    __device__ __forceinline__ int par() const { return (int)((w >> 21) & 1u); }
-    __device__ __forceinline__ int phase() const { return (int)((w >> 22) & 255u); } // (steps in flight differ by < 4 phases)
-    __device__ __forceinline__ int view(int j) const { return (int)((views >> (8 * j)) & 0xffu); }
-    __device__ __forceinline__ bool same_chunk(const PStep &o) const { return ((w ^ o.w) & 0x3fffu) == 0u; } // scale, layer, q
-};
 
 __device__ __forceinline__ float4 mul4(float4 a, float w) { return make_float4(a.x * w, a.y * w, a.z * w, a.w * w); }
 __device__ __forceinline__ float4 fma4(float4 a, float w, float4 c)
@@ -379,7 +365,8 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
     __shared__ __align__(16) unsigned char s_rec[4 * kTileBoxes * kRecBytes]; // box records of the group's sub-tiles, one layer
     __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
     __shared__ unsigned s_misc[16];
-    __shared__ __align__(16) unsigned s_steps[4][4];                        // the next steps, generated by wave 0: [index & 3][tile, views, w, -]
+    __shared__ __align__(16) unsigned s_phase[4][4];                        // phase records (wave 0): [phase & 3]{tile, views, w, -}
+    __shared__ __align__(16) unsigned s_desc[4][8][2][8];                   // fetch descriptors (wave 0): [phase & 3][step of the phase][sub-tile]
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63;
 
     const int nblk = gridDim.x;
@@ -400,6 +387,28 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
 
     // a tile is SHARED when another workgroup holds groups of it too
     auto shared_tile = [&](int tile) { return (tile == t_begin && k_begin > 0) || (tile == t_end && k_end > 0); };
+
+    // the workgroups that hold groups of `tile` beside this one: first, last, how many (this one included)
+    auto share_of = [&](int tile, int &first, int &last, int &parts) {
+        first = lb; last = lb; parts = 1;
+        for (int j = lb - 1; j >= 0; --j) {
+            int tb, kb, te, ke;
+            range_of(j, tb, kb, te, ke);
+            if (te < tile || (te == tile && ke == 0)) break; // ends in front of the tile
+            if (tb > te || (tb == te && kb >= ke)) continue; // (empty range)
+            first = j; ++parts;
+        }
+        for (int j = lb + 1; j < nblk; ++j) {
+            int tb, kb, te, ke;
+            range_of(j, tb, kb, te, ke);
+            if (tb > tile) break;
+            if (tb > te || (tb == te && kb >= ke)) continue;
+            last = j; ++parts;
+        }
+    };
+    int sh_b_first = lb, sh_b_last = lb, sh_b_parts = 1, sh_e_first = lb, sh_e_last = lb, sh_e_parts = 1;
+    if (k_begin > 0) share_of(t_begin, sh_b_first, sh_b_last, sh_b_parts);
+    if (k_end > 0) share_of(t_end, sh_e_first, sh_e_last, sh_e_parts);
 
     // The loop below exists twice, once per role (`POOL`): a wave never changes its role, and inside ONE loop the registers of
     // both roles would be live at once.  Both copies take the same steps, hence the same barriers.
@@ -429,8 +438,22 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         LaneBox boxA, boxB;
         bool globA = false, globB = false, liveA = false, liveB = false;
 
-        auto hdr_word = [&](int phase, int j, int k) { return uniform_i((int)s_hdr[phase & 3][j * 8 + k]); };
-
+        // A phase record (LDS, written by wave 0): tile, the views of the group, w = scale | layer << 2 | nj << 15 | more << 20
+        struct PhaseRec {
+            int tile; unsigned views, w;
+            __device__ __forceinline__ bool valid() const { return tile >= 0; }
+            __device__ __forceinline__ int scale() const { return (int)(w & 3u); }
+            __device__ __forceinline__ int layer() const { return (int)((w >> 2) & 1023u); }
+            __device__ __forceinline__ int nj() const { return (int)((w >> 15) & 7u); }
+            __device__ __forceinline__ bool more() const { return (w >> 20) & 1u; }
+            __device__ __forceinline__ int view(int j) const { return (int)((views >> (8 * j)) & 0xffu); }
+        };
+        auto phase_rec = [&](int n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
+            PhaseRec p;
+            p.tile = uniform_i((int)v.x); p.views = (unsigned)uniform_i((int)v.y); p.w = (unsigned)uniform_i((int)v.z);
+            return p;
+        };
         // output rows of a tile: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 block, column r
         auto write_tile = [&](int tile, const f32x16 &v, bool have) {
             const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
@@ -460,55 +483,100 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             }
         };
 
-        // ---------------------------------------------------------------- DMA (matrix waves)
-        auto hdr_dma = [&](const PStep &st) { // the headers of the group's sub-tiles at the step's layer: 8 lanes each
-            if (wave != 0) return;
-            int j = lane >> 3;
-            j = j < st.nj() ? j : st.nj() - 1;
-            const size_t item = ((size_t)st.tile * a.nl + st.layer()) * a.n_views + st.view(j);
-            const unsigned char *p = a.sc[st.scale()].hdrs + item * kHdrBytes + (lane & 7) * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
-                                             (__attribute__((address_space(3))) void *)(&s_hdr[st.phase() & 3][0]), 4, 0, 0);
+        // ---------------------------------------------------------------- tables and DMA
+        // Control is organised so that NO wave does scalar work that the others repeat: twelve waves share the CU's one scalar
+        // unit, and ~40 scalar instructions at the head of a step in every wave cost 600-1000 cycles per step.  Every phase has
+        // exactly eight steps (step i: phase i >> 3, quarter (i & 7) >> 1, set i & 1), so a loop counter names the step; what a
+        // step needs beyond that comes from three small LDS tables that wave 0 fills AHEAD, with the lanes as the loop:
+        //   s_phase  the generator's record of the phase                                    (at step 4 of the phase before)
+        //   s_hdr    the window headers of the group's sub-tiles at the phase's layer: DMA   (at step 5)
+        //   s_desc   per (step, sub-tile): image / record / weight addresses, flags, slots   (at step 6; first used at step 7)
+        Sequencer<DevMasks> sq;
+        auto gen_phase = [&](int n) { // (wave 0)
+            const Phase ph = sq.next_phase();
+            const unsigned w = (unsigned)ph.scale | ((unsigned)ph.layer << 2) | ((unsigned)ph.nj << 15) | (ph.more_in_tile ? 1u << 20 : 0u);
+            if (lane == 0) *reinterpret_cast<uint4 *>(&s_phase[n & 3][0]) = make_uint4((unsigned)ph.tile, ph.views, w, 0u);
         };
-        // Tap window (and, at the first quarter of a layer, the box records) of ONE sub-tile of step `st`: waves 0-3 fetch for the
-        // first sub-tile of the set, waves 4-7 for the second -- a wave then walks one header / view / image chain, not two.
-        auto step_dma = [&](const PStep &st) {
-            const int x = wave >> 2, wq4 = wave & 3, j = 2 * st.set() + x;
-            if (j >= st.nj()) return;
-            // flags and slot count into scalar registers (they steer branches and the loop); the window geometry stays in vector
-            // registers (the same value in every lane): it only feeds the per-lane address arithmetic
-            const uint4 *hp = reinterpret_cast<const uint4 *>(&s_hdr[st.phase() & 3][j * 8]);
+        auto scale_ptr = [&](int scale, const void *p0, const void *p1, const void *p2) { // (per-lane select: no scalar branches)
+            return (unsigned long long)(size_t)(scale == 0 ? p0 : (scale == 1 ? p1 : p2));
+        };
+        auto hdr_dma = [&](int n) { // (wave 0) the headers of the sub-tiles of phase n: 8 lanes each, per-lane addresses
+            const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
+            if (uniform_i((int)v.x) < 0) return;
+            const int tile = (int)v.x, scale = (int)(v.z & 3u), layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
+            int j = lane >> 3;
+            j = j < nj ? j : nj - 1;
+            const int view = (int)((v.y >> (8 * j)) & 0xffu);
+            const unsigned long long item = (unsigned long long)((tile * a.nl + layer) * a.n_views + view);
+            const unsigned long long p = scale_ptr(scale, a.sc[0].hdrs, a.sc[1].hdrs, a.sc[2].hdrs) + item * kHdrBytes + (unsigned)(lane & 7) * 4u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                             (__attribute__((address_space(3))) void *)(&s_hdr[n & 3][0]), 4, 0, 0);
+        };
+        // entry (k, x): {image address of (view, quarter), record address, flags | slots << 8, weight slice address (lanes x = 0)}
+        auto make_desc = [&](int n) { // (wave 0) lanes 0..15 = (step k, sub-tile x) of phase n
+            const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
+            if (uniform_i((int)v.x) < 0) return;
+            const int tile = (int)v.x, scale = (int)(v.z & 3u), layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
+            const int k = (lane >> 1) & 7, x = lane & 1, q = k >> 1, j = 2 * (k & 1) + x;
+            const int jj = j < nj ? j : 0;
+            const int view = (int)((v.y >> (8 * jj)) & 0xffu);
+            const unsigned flags = s_hdr[n & 3][jj * 8 + 0], n_slots = s_hdr[n & 3][jj * 8 + 1];
+            const int Hf = scale == 0 ? a.sc[0].Hf : (scale == 1 ? a.sc[1].Hf : a.sc[2].Hf);
+            const int Wf = scale == 0 ? a.sc[0].Wf : (scale == 1 ? a.sc[1].Wf : a.sc[2].Wf);
+            const unsigned long long item = (unsigned long long)((tile * a.nl + layer) * a.n_views + view);
+            const unsigned long long img = scale_ptr(scale, a.sc[0].integral, a.sc[1].integral, a.sc[2].integral) +
+                                           (unsigned long long)view * (unsigned)((Hf + 2) * (Wf + 2)) * kSlotBytes + (unsigned)(q * kQSlot);
+            const unsigned long long rec = scale_ptr(scale, a.sc[0].recs, a.sc[1].recs, a.sc[2].recs) + item * (kTileBoxes * kRecBytes);
+            const unsigned long long wsl = scale_ptr(scale, a.sc[0].wfrag, a.sc[1].wfrag, a.sc[2].wfrag) +
+                                           (unsigned long long)(((unsigned)layer * 8u * kSteps + (unsigned)q * 4u) * 2u * 64u) * 16u;
+            const unsigned fw = j < nj ? ((flags & 0xffu) | (n_slots << 8)) : 0u;
+            if (lane < 16) {
+                uint4 *d = reinterpret_cast<uint4 *>(&s_desc[n & 3][k][x][0]);
+                d[0] = make_uint4((unsigned)img, (unsigned)(img >> 32), (unsigned)rec, (unsigned)(rec >> 32));
+                d[1] = make_uint4(fw, (unsigned)wsl, (unsigned)(wsl >> 32), (unsigned)(Wf + 2));
+            }
+        };
+        // Tap window (and, at the first quarter of a layer, the box records) of ONE sub-tile of step i: waves 0-3 fetch for the
+        // first sub-tile of the set, waves 4-7 for the second.  Addresses stay in vector registers (the same value in every lane).
+        auto step_dma = [&](int i) {
+            const int n = i >> 3, k = i & 7, x = wave >> 2, wq4 = wave & 3, j = 2 * (k & 1) + x;
+            const uint4 *dp = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0]);
+            const uint4 d0 = dp[0], d1 = dp[1];
+            const uint4 *hp = reinterpret_cast<const uint4 *>(&s_hdr[n & 3][j * 8]);
             const uint4 h0 = hp[0], h1 = hp[1];
-            const PipeScale &sc = a.sc[st.scale()];
-            const int wp = sc.Wf + 2;
-            const int hflags = uniform_i((int)h0.x);
-            if (!(hflags & kTileLive)) return;
-            const int view = st.view(j);
-            const size_t item = ((size_t)st.tile * a.nl + st.layer()) * a.n_views + view;
-            if (st.q() == 0 && wq4 < 3) {
-                const unsigned char *p = sc.recs + item * kTileBoxes * kRecBytes + wq4 * 1024 + lane * 16;
+            const int fw = uniform_i((int)d1.x);
+            if (!(fw & kTileLive)) return;
+            if ((k >> 1) == 0 && wq4 < 3) {
+                const unsigned long long p = ((unsigned long long)d0.w << 32 | d0.z) + (unsigned)(wq4 * 1024 + lane * 16);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                                  (__attribute__((address_space(3))) void *)(s_rec + j * kTileBoxes * kRecBytes + wq4 * 1024), 16, 0, 0);
             }
-            if ((hflags & kTileDirect) || (DIAG && (a.debug & 1))) return; // (diagnostic 1: no window fills; the records still come)
-            const int n_slots = uniform_i((int)h0.y);
+            if ((fw & kTileDirect) || (DIAG && (a.debug & 1))) return; // (diagnostic 1: no window fills; the records still come)
+            const int n_slots = fw >> 8;
             const int cw = (int)h0.z, inv = (int)h0.w, x0 = (int)h1.x, t0 = (int)h1.y, top = (int)h1.z, b0 = (int)h1.w;
             const int n_fill = (n_slots + 3) >> 2;
-            const char *img = reinterpret_cast<const char *>(sc.integral) + (size_t)view * (sc.Hf + 2) * wp * kSlotBytes +
-                              st.q() * kQSlot + (lane & 15) * 16;
-            unsigned char *dst = s_win + (st.par() * 2 + x) * kWinBytes;
+            const unsigned long long img = ((unsigned long long)d0.y << 32 | d0.x) + (unsigned)((lane & 15) * 16);
+            const int wpad = (int)d1.w; // (Wf + 2 of the scale: see make_desc)
+            unsigned char *dst = s_win + ((k & 1) * 2 + x) * kWinBytes;
             for (int f = wq4; f < n_fill; f += 4) { // four quarter slots per instruction, 16 lanes each
                 const int slot = min(4 * f + (lane >> 4), n_slots - 1);
                 const int wr = (slot * inv) >> 16, wc = slot - wr * cw;
                 const int y = wr < top ? t0 + wr : b0 + (wr - top), xx = x0 + wc;
-                const char *src = img + (size_t)(unsigned)((y + 1) * wp + (xx + 1)) * kSlotBytes;
+                const unsigned long long src = img + (unsigned long long)(unsigned)((y + 1) * wpad + (xx + 1)) * kSlotBytes;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(dst + f * 1024), 16, 0, 0);
             }
         };
-        // the 64 k x 32 n slice of collapse.weight of step `st` for this wave: 8 coalesced 1 KiB loads
-        auto w_load = [&](const PStep &st, int ks) {
-            const uint4 *src = a.sc[st.scale()].wfrag + ((size_t)(st.layer() * 8 + wave) * kSteps + st.q() * 4 + ks) * 2 * 64 + lane;
+        // the 64 k x 32 n slice of collapse.weight of step i for this wave: 8 coalesced 1 KiB loads
+        // (the slice address of the step sits in scalar registers -- the same for every lane --, the lane's part is one add)
+        unsigned w_lo = 0, w_hi = 0;
+        auto w_addr = [&](int i) {
+            const uint4 d1 = reinterpret_cast<const uint4 *>(&s_desc[(i >> 3) & 3][i & 7][0][0])[1];
+            w_lo = (unsigned)uniform_i((int)d1.y); w_hi = (unsigned)uniform_i((int)d1.z);
+        };
+        auto w_load = [&](int ks) {
+            const char *base = reinterpret_cast<const char *>((size_t)((unsigned long long)w_hi << 32 | w_lo));
+            const uint4 *src = reinterpret_cast<const uint4 *>(base + (unsigned)(wave * kSteps * 2 * 64 * 16 + lane * 16)) + ks * 2 * 64;
             const uint4 uh = src[0], ul = src[64];
             wq[ks].hi = *reinterpret_cast<const bf16x8 *>(&uh);
             wq[ks].lo = *reinterpret_cast<const bf16x8 *>(&ul);
@@ -518,18 +586,20 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         // SET is the parity of the step's index, hence a compile-time fact of the loop body it is called from; the weight is
         // reloaded behind the k-steps of set 1 (the next step starts another slice), never behind those of set 0 -- a reload
         // decided at run time inside the k-loop cost register copies at every merge point.
-        auto multiply = [&](auto set_tag, const PStep &st, const PStep &nx) {
+        auto multiply = [&](auto set_tag, const PhaseRec &ph, int k, int par, bool next_chunk) {
             constexpr int SET = decltype(set_tag)::value;
             constexpr bool reload = SET == 1;
-            if (st.grp_first()) {
-                const float b0 = st.scale() == 0 ? bc[0] : (st.scale() == 1 ? bc[1] : bc[2]);
+            const int q = k >> 1;
+            const bool grp_first = ph.layer() == 0 && q == 0, grp_last = ph.layer() == a.nl - 1 && q == 3;
+            if (grp_first) {
+                const float b0 = ph.scale() == 0 ? bc[0] : (ph.scale() == 1 ? bc[1] : bc[2]);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { acc[2 * SET][i] = b0; acc[2 * SET + 1][i] = b0; } // (the bias rides in the accumulator)
             }
-            const bool work = 2 * SET < st.nj() && !(DIAG && (a.debug & 4)); // (set 1 of a group of one or two views is empty)
+            const bool work = 2 * SET < ph.nj() && !(DIAG && (a.debug & 4)); // (set 1 of a group of one or two views is empty)
             // A fragments: lane (r, h) of row block rb reads chunk 2 ks + h, row 32 rb + r (read_frags)
             const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)s_planes +
-                                (unsigned)(st.par() * 2 * kPlaneBytes + h * kChunkStride + r * 16);
+                                (unsigned)(par * 2 * kPlaneBytes + h * kChunkStride + r * 16);
             // ONE set of fragment registers: the reads of k-step ks + 1 are issued behind the MFMAs of ks (which latched their A
             // operands when they issued) and land under them and under the partner wave's MFMAs; a second set for reading ahead
             // does not fit beside four accumulators, the tile sums and the weight slice (168 registers at three waves per SIMD)
@@ -554,17 +624,23 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (reload) w_load(nx, KS); // the next slice, k-step by k-step, into the registers just used
+                if (reload && work) w_load(KS); // the next slice (w_addr), k-step by k-step, into the registers just used
             };
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (no scalar load may be pending beside the waits of read_frags)
             kstep(std::integral_constant<int, 0>{});
             kstep(std::integral_constant<int, 1>{});
             kstep(std::integral_constant<int, 2>{});
             kstep(std::integral_constant<int, 3>{});
-            if (st.grp_last() && 2 * SET < st.nj()) { // vfa_op.py:124; vfanet.py:79, 82: views in index order
+            // A group of one or two views has nothing in set 1: that step is a barrier and little else, too short to cover a weight
+            // load.  The next slice is then requested HERE, behind set 0 (whole, not interleaved: its registers are free now).
+            if (SET == 0 && ph.nj() <= 2 && next_chunk) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) w_load(ks);
+            }
+            if (grp_last && 2 * SET < ph.nj()) { // vfa_op.py:124; vfanet.py:79, 82: views in index order
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[2 * SET][i]);
-                if (2 * SET + 1 < st.nj()) {
+                if (2 * SET + 1 < ph.nj()) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[2 * SET + 1][i]);
                 }
@@ -572,7 +648,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         };
 
         // ---------------------------------------------------------------- pooling of one step (pooling waves)
-        auto unpack = [&](LaneBox &bx, bool &glob, const PStep &st, int j, bool direct) {
+        auto unpack = [&](LaneBox &bx, bool &glob, unsigned wp, int j, bool direct) {
             const uint4 *rp = reinterpret_cast<const uint4 *>(s_rec + j * kTileBoxes * kRecBytes) + ((pw & 1) * 16 + pb) * (kRecBytes / 16);
             uint4 rv[6];
 #pragma unroll
@@ -587,7 +663,6 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             bx.scl = vis ? __uint_as_float(rv[4].x) : __uint_as_float(rv[5].z);
             unsigned rw[4] = {rv[4].z & 0xffffu, rv[4].z >> 16, rv[4].w & 0xffffu, rv[4].w >> 16};
             unsigned cl[4] = {rv[5].x & 0xffffu, rv[5].x >> 16, rv[5].y & 0xffffu, rv[5].y >> 16};
-            const unsigned wp = (unsigned)a.sc[st.scale()].Wf + 2u;
             glob = direct;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -600,15 +675,17 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         // the wave's 16 boxes x the 64 channels of quarter q: lane (box pb, piece pi) takes the 16-byte pieces
         // ((pb + m) & 3) * 4 + pi, m = 0..3, of its taps' quarter slots -- the four boxes of an LDS cycle read different 64-byte
         // quarters of the banks whatever slots they hold
-        auto pool = [&](auto glob_tag, const LaneBox &bx, const PStep &st, int x) {
+        auto pool = [&](auto glob_tag, const LaneBox &bx, int i, int x) {
             constexpr bool GLOB = decltype(glob_tag)::value;
-            const int j = 2 * st.set() + x;
-            const unsigned char *win = s_win + (st.par() * 2 + x) * kWinBytes;
-            const PipeScale &sc = a.sc[st.scale()];
-            const char *img = reinterpret_cast<const char *>(sc.integral) +
-                              (size_t)st.view(j) * (sc.Hf + 2) * (sc.Wf + 2) * kSlotBytes + st.q() * kQSlot;
+            const int k = i & 7, set = k & 1;
+            const unsigned char *win = s_win + (set * 2 + x) * kWinBytes;
+            const char *img = nullptr;
+            if constexpr (GLOB) { // (image address of (view, quarter): descriptor of the step)
+                const uint4 d0 = reinterpret_cast<const uint4 *>(&s_desc[(i >> 3) & 3][k][x][0])[0];
+                img = reinterpret_cast<const char *>((size_t)((unsigned long long)d0.y << 32 | d0.x));
+            }
             const int row = x * 32 + (pw & 1) * 16 + pb;
-            unsigned char *planes = s_planes + st.par() * 2 * kPlaneBytes;
+            unsigned char *planes = s_planes + set * 2 * kPlaneBytes;
             // All sixteen taps of a 16-byte piece are requested at once and consumed as they arrive (counted waits).  A hand-made
             // software pipeline across the four pieces (the next piece's taps requested as soon as half of this piece's were
             // consumed) measured 35 % SLOWER (4 900 against 3 620 cycles per step): more registers, spills, and the
@@ -646,19 +723,19 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                 *reinterpret_cast<uint2 *>(planes + kPlaneBytes + off) = lo.u;
             }
         };
-        auto pool_step = [&](auto set_tag, const PStep &st) {
+        auto pool_step = [&](auto set_tag, int i) {
             constexpr int SET = decltype(set_tag)::value;
-            const int x = pw >> 1, j = 2 * SET + x;
-            if (j >= st.nj()) return;
+            const int n = i >> 3, k = i & 7, x = pw >> 1, j = 2 * SET + x;
             auto one = [&](LaneBox &bx, bool &glob, bool &live) { // (called with the registers of the step's set)
-                if (st.q() == 0) {
-                    const int flags = hdr_word(st.phase(), j, 0);
-                    live = (flags & kTileLive) != 0;
-                    if (live) unpack(bx, glob, st, j, (flags & kTileDirect) != 0);
+                if ((k >> 1) == 0) { // first quarter of the layer: this wave's 16 boxes for the whole layer
+                    const uint4 d1 = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0])[1];
+                    const int fw = uniform_i((int)d1.x);
+                    live = (fw & kTileLive) != 0;
+                    if (live) unpack(bx, glob, d1.w, j, (fw & kTileDirect) != 0);
                 }
-                if (!live) { // no live box in this layer: the matrix waves multiply zeros
+                if (!live) { // no live box in this layer (or no such sub-tile in the group): the matrix waves multiply zeros
                     const int row = x * 32 + (pw & 1) * 16 + pb;
-                    unsigned char *planes = s_planes + st.par() * 2 * kPlaneBytes;
+                    unsigned char *planes = s_planes + SET * 2 * kPlaneBytes;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         const int off = (2 * m + (pi >> 1)) * kChunkStride + row * 16 + (pi & 1) * 8;
@@ -668,16 +745,15 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                     return;
                 }
                 if (DIAG && (a.debug & 2)) return;
-                if (glob) pool(std::true_type{}, bx, st, x);
-                else pool(std::false_type{}, bx, st, x);
+                if (glob) pool(std::true_type{}, bx, i, x);
+                else pool(std::false_type{}, bx, i, x);
             };
             if constexpr (SET == 0) one(boxA, globA, liveA);
             else one(boxB, globB, liveB);
         };
 
         // ---------------------------------------------------------------- a workgroup's part of a tile is complete
-        auto finish_tile = [&](const PStep &st, int next_tile) {
-            const int tile = st.tile;
+        auto finish_tile = [&](int tile, int next_tile) {
             if (__builtin_expect(!shared_tile(tile), 1)) {
                 if constexpr (!POOL) write_tile(tile, sum, true);
             } else {
@@ -692,22 +768,10 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_s_barrier();
-                // the workgroups that hold groups of this tile: first, last
-                int first = lb, last = lb, parts = 1;
-                for (int j = lb - 1; j >= 0; --j) {
-                    int tb, kb, te, ke;
-                    range_of(j, tb, kb, te, ke);
-                    if (te < tile || (te == tile && ke == 0)) break; // ends in front of the tile
-                    if (tb > te || (tb == te && kb >= ke)) continue; // (empty range)
-                    first = j; ++parts;
-                }
-                for (int j = lb + 1; j < nblk; ++j) {
-                    int tb, kb, te, ke;
-                    range_of(j, tb, kb, te, ke);
-                    if (tb > tile) break;
-                    if (tb > te || (tb == te && kb >= ke)) continue;
-                    last = j; ++parts;
-                }
+                // the workgroups that hold groups of this tile (found once, in front of the loop: share_of)
+                const int first = tile == t_begin && k_begin > 0 ? sh_b_first : sh_e_first;
+                const int last = tile == t_begin && k_begin > 0 ? sh_b_last : sh_e_last;
+                const int parts = tile == t_begin && k_begin > 0 ? sh_b_parts : sh_e_parts;
                 if (tid == 0) {
                     const unsigned old = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_misc[0] = old;
@@ -746,59 +810,6 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         };
 
         // ---------------------------------------------------------------- the loop
-        // ONE wave runs the generator (wave 0, ~150 scalar instructions per call: run by all twelve waves it kept the CU's scalar
-        // unit busy for 900-1600 cycles per step) and hands whole PHASES -- (group, layer): eight steps -- to the others through a
-        // ring in LDS; every wave expands the steps itself, a dozen scalar instructions each.  Everything that steers branches,
-        // barriers and LDS-DMA destinations goes through v_readfirstlane: it must sit in scalar registers.
-        PStep dm, dp, dd, dh; // the steps being multiplied, pooled, fetched; the one whose headers are fetched
-        Sequencer<DevMasks> sq;
-        auto produce = [&](int n) { // (wave 0) phase n -> LDS: tile, views, scale | layer << 2 | nj << 15 | more << 20 | phase << 22
-            const Phase ph = sq.next_phase();
-            const unsigned w = (unsigned)ph.scale | ((unsigned)ph.layer << 2) | ((unsigned)ph.nj << 15) | (ph.more_in_tile ? 1u << 20 : 0u) |
-                               ((unsigned)(ph.phase & 255) << 22);
-            if (lane == 0) *reinterpret_cast<uint4 *>(&s_steps[n & 3][0]) = make_uint4((unsigned)ph.tile, ph.views, w, 0u);
-        };
-        PStep php;       // the phase of `dh` (w: as written by produce)
-        int ph_no = 0;   // ... its number, ... and the step of it that `dh` is
-        int k8 = 0, par = 0;
-        auto load_phase = [&](int n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&s_steps[n & 3][0]);
-            php.tile = uniform_i((int)v.x); php.views = (unsigned)uniform_i((int)v.y); php.w = (unsigned)uniform_i((int)v.z);
-        };
-        auto expand = [&]() { // step k8 of phase php
-            PStep c;
-            c.tile = php.tile; c.views = php.views;
-            const unsigned q = (unsigned)k8 >> 1, set = (unsigned)k8 & 1u, layer = (php.w >> 2) & 1023u;
-            const bool gf = layer == 0u && q == 0u, gl = layer == (unsigned)(a.nl - 1) && q == 3u;
-            const bool tl = gl && set == 1u && !((php.w >> 20) & 1u);
-            c.w = (php.w & ~(1u << 20)) | (q << 12) | (set << 14) | (gf ? 1u << 18 : 0u) | (gl ? 1u << 19 : 0u) | (tl ? 1u << 20 : 0u) |
-                  ((unsigned)par << 21);
-            return c;
-        };
-        auto advance = [&]() { // the next step into `dh`
-            if (!php.valid()) { dh = php; return; }
-            par ^= 1;
-            if (++k8 == 8) {
-                k8 = 0;
-                load_phase(++ph_no);
-            }
-            dh = php.valid() ? expand() : php;
-        };
-        if (wave == 0) {
-            sq.masks = masks;
-            sq.begin(a.n_scales, a.nl, t_begin, k_begin, t_end, k_end);
-            produce(0); produce(1); produce(2);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        dm.tile = -1; dp.tile = -1; dm.views = dp.views = 0u; dm.w = dp.w = 0u;
-        load_phase(0);
-        dd = php.valid() ? expand() : php;
-        dh = dd;
-        advance();
-        empty_tiles(k_begin == 0 ? t_begin : t_begin + 1, dd.valid() ? dd.tile : t_end);
-        if (!dd.valid()) return;
         unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
         auto tick = [&](int k) {
             if (DIAG) {
@@ -807,29 +818,43 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                 t_prev = now;
             }
         };
+        auto lds_fence_barrier = [&]() {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        // prologue: phase 0's record, headers, descriptors; the windows / records and the weight slice of step 0
+        if (wave == 0) {
+            sq.masks = masks;
+            sq.begin(a.n_scales, a.nl, t_begin, k_begin, t_end, k_end);
+            gen_phase(0);
+        }
+        lds_fence_barrier();
+        PhaseRec rec = phase_rec(0); // matrix waves: the phase of the step being multiplied; pooling waves: of the step being pooled
+        empty_tiles(k_begin == 0 ? t_begin : t_begin + 1, rec.valid() ? rec.tile : t_end);
+        if (!rec.valid()) return;
+        if (wave == 0) hdr_dma(0);
+        lds_fence_barrier();
+        if (wave == 0) make_desc(0);
+        lds_fence_barrier();
         if constexpr (!POOL) {
-            hdr_dma(dd);
-            if (dh.valid() && dh.phase() != dd.phase()) hdr_dma(dh);
+            step_dma(0);
+            w_addr(0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) w_load(dd, ks);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int ks = 0; ks < 4; ++ks) w_load(ks);
         }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if constexpr (!POOL) {
-            step_dma(dd);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        lds_fence_barrier();
         if (DIAG) t_prev = __builtin_amdgcn_s_memtime();
-        // One step: the pooling waves pool step `dp` (set PSET), the matrix waves fetch for step `dd` and multiply step `dm`
-        // (the other set).  The sets alternate with the step index, so the loop is unrolled by two.
-        auto body = [&](auto pset_tag) {
+        // Iteration i: the pooling waves pool step i (set i & 1), the matrix waves fetch for step i + 1 and multiply step i - 1.
+        // `live` bit 0 / 1 / 2: step i - 1 / i / i + 1 exists (a phase record with tile < 0 ends the sequence).
+        unsigned live = 2u | 4u;
+        auto body = [&](auto pset_tag, int i) {
             constexpr int PSET = decltype(pset_tag)::value, MSET = PSET ^ 1;
+            const int m = i & 7;
             tick(0);
             if constexpr (POOL) {
-                if (dp.valid()) pool_step(std::integral_constant<int, PSET>{}, dp);
+                if (m == 0 && i > 0) rec = phase_rec(i >> 3);
+                if (live & 2u) pool_step(std::integral_constant<int, PSET>{}, i);
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 tick(2);
             } else {
@@ -838,52 +863,77 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                 // of the first MFMA, behind the DMA issued below: a memory round trip per step
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 tick(1);
-                // The two matrix waves of a SIMD take their two jobs in opposite order: waves 0-3 request the next step's
-                // windows (a chain of scalar work and LDS / scalar-cache round trips, ~1500 cycles) and then multiply, waves 4-7
-                // multiply first -- one of the pair is on the matrix pipe while the other does its address arithmetic.
+                if (m == 1 && i > 1) rec = phase_rec((i - 1) >> 3);
+                if (wave == 0) { // the tables of the next phase (see `tables and DMA`)
+                    if (m == 4) gen_phase((i >> 3) + 1);
+                    else if (m == 5) hdr_dma((i >> 3) + 1);
+                    else if (m == 6) make_desc((i >> 3) + 1);
+                }
+                // The two matrix waves of a SIMD take their two jobs in opposite order: waves 0-3 request the next step's window
+                // and then multiply, waves 4-7 multiply first -- one of the pair is on the matrix pipe while the other does its
+                // address arithmetic.
                 const bool dma_first = wave < 4;
-                if (dma_first) {
-                    if (dd.valid()) step_dma(dd);
-                    if (dh.valid() && (!dd.valid() || dh.phase() != dd.phase())) hdr_dma(dh);
-                }
+                if (dma_first && (live & 4u)) step_dma(i + 1);
                 tick(2);
-                if (dm.valid()) multiply(std::integral_constant<int, MSET>{}, dm, dp.valid() ? dp : dm);
-                tick(3);
-                if (!dma_first) {
-                    if (dd.valid()) step_dma(dd);
+                if (live & 1u) {
+                    // the slice of the next chunk: behind the k-steps of set 1 (steps i - 1 = set 1, i = set 0 of the next chunk), or,
+                    // when set 1 of the group is empty, already behind set 0 (steps i - 1 = set 0, i = set 1, i + 1 = the next chunk)
+                    bool next_chunk = false;
+                    if (MSET == 1 && (live & 2u)) { w_addr(i); next_chunk = true; }
+                    if (MSET == 0 && rec.nj() <= 2 && (live & 4u)) { w_addr(i + 1); next_chunk = true; }
+                    multiply(std::integral_constant<int, MSET>{}, rec, (i - 1) & 7, MSET, next_chunk);
                 }
-                if (wave == 0 && k8 == 0 && php.valid()) produce(ph_no + 2); // (`dh` has just entered phase ph_no: two phases ahead)
+                tick(3);
+                if (!dma_first && (live & 4u)) step_dma(i + 1);
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // windows / records / headers of the next step have landed
                 tick(4);
             }
-            if constexpr (MSET == 1) {
-                if (__builtin_expect(dm.valid() && dm.tile_last(), 0)) finish_tile(dm, dp.valid() ? dp.tile : t_end);
+            if constexpr (MSET == 1) { // (step i - 1 was the last of its phase's quarter 3?)
+                const PhaseRec &pr = rec; // matrix waves: the record of step i - 1; pooling waves hold the record of step i
+                if constexpr (POOL) {
+                    // the pooling waves only need to know whether the hand-off barriers of a SHARED tile are due
+                    if (__builtin_expect(((i - 1) & 7) == 7 && (live & 1u), 0)) {
+                        const PhaseRec prev = phase_rec((i - 1) >> 3);
+                        if (prev.layer() == a.nl - 1 && !prev.more()) {
+                            const PhaseRec nxt = phase_rec(((i - 1) >> 3) + 1);
+                            finish_tile(prev.tile, nxt.valid() ? nxt.tile : t_end);
+                        }
+                    }
+                } else {
+                    if (__builtin_expect(((i - 1) & 7) == 7 && (live & 1u) && pr.layer() == a.nl - 1 && !pr.more(), 0)) {
+                        const PhaseRec nxt = phase_rec(((i - 1) >> 3) + 1);
+                        finish_tile(pr.tile, nxt.valid() ? nxt.tile : t_end);
+                    }
+                }
             }
             tick(5);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             tick(6);
             if (DIAG) stamp[7] += 1;
+            // the step that enters at i + 2: a new phase when (i + 2) & 7 == 0 (its record was written at step 4 of this phase)
+            unsigned next_live = (live >> 2) & 1u;
+            if (((i + 2) & 7) == 0 && next_live) next_live = uniform_i((int)s_phase[((i + 2) >> 3) & 3][0]) >= 0 ? 1u : 0u;
+            live = (live >> 1) | (next_live << 2);
         };
-        for (;;) {
-            dm = dp; dp = dd; dd = dh;
-            advance();
-            if (!dp.valid() && !dm.valid()) break;
-            body(std::integral_constant<int, 0>{}); // (steps 0, 2, ... are pooled here: set 0)
-            dm = dp; dp = dd; dd = dh;
-            advance();
-            if (!dp.valid() && !dm.valid()) break;
-            body(std::integral_constant<int, 1>{});
+        for (int i = 0;; i += 2) {
+            if (!(live & 3u)) break;
+            body(std::integral_constant<int, 0>{}, i); // (steps 0, 2, ... are pooled here: set 0)
+            if (!(live & 3u)) break;
+            body(std::integral_constant<int, 1>{}, i + 1);
         }
         if (DIAG && a.diag && (a.debug & 0x80) && tid == ((a.debug >> 8) & 15) * 64)
             for (int k = 0; k < 8; ++k) a.diag[(size_t)blockIdx.x * 8 + k] = stamp[k];
     };
     if (wave >= kMatWaves) {
-        __builtin_amdgcn_s_setprio(1); // the pooling wave is the busier third of its SIMD: it goes first
+        // the pooling wave is the busiest third of its SIMD and its step the longest: it goes first (its step head 150 against 500
+        // cycles, pooling 3 800 against 4 000 without the priority)
+        if (!(DIAG && (a.debug & 8))) __builtin_amdgcn_s_setprio(1);
 #ifndef VFA_PIPE_NO_POOL
         run(std::true_type{});
 #endif
     } else {
+        if (DIAG && (a.debug & 16)) __builtin_amdgcn_s_setprio(2);
 #ifndef VFA_PIPE_NO_MAT
         run(std::false_type{});
 #endif
@@ -893,7 +943,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PipeLayout {
-    size_t live[kMaxScales], tickets, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, partial, diag, total;
+    size_t live[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, partial, diag, total;
     int tiles_l, tiles_w, n_tiles;
 };
 inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
@@ -908,6 +958,8 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
         off = align_up(off + (s < n_scales ? (size_t)w.n_tiles * 4 : 0), 256);
     }
     w.tickets = off;
+    off = align_up(off + (size_t)w.n_tiles * 4, 256);
+    w.globs = off;
     off = align_up(off + (size_t)w.n_tiles * 4, 256);
     w.masks_bytes = off;
     const size_t items = (size_t)w.n_tiles * nl * n_views;
@@ -951,6 +1003,7 @@ int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_sca
         offsets[4 * k + 3] = lay.wfrag[k];
     }
     offsets[12] = lay.tickets;
+    offsets[17] = lay.globs;
     offsets[13] = lay.chunks;
     offsets[14] = lay.ranks;
     offsets[15] = lay.diag;
@@ -987,7 +1040,8 @@ int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_la
         a.hdrs[k] = ws + lay.hdrs[k];
         a.recs[k] = ws + lay.recs[k];
     }
-    const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s); // view masks and tile tickets
+    a.globs = reinterpret_cast<unsigned *>(ws + lay.globs);
+    const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s); // view masks, tile tickets, counters
     if (e != hipSuccess) return (int)e;
     const long long pairs = (long long)n_views * lay.n_tiles;
     hipLaunchKernelGGL(pipe_records_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(kWave), 0, s, a);
@@ -1006,6 +1060,7 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
     unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
     CutArgs ca;
     for (int k = 0; k < kMaxScales; ++k) ca.live[k] = reinterpret_cast<const unsigned *>(ws + lay.live[k < n_scales ? k : 0]);
+    ca.globs = reinterpret_cast<const unsigned *>(ws + lay.globs);
     ca.n_scales = n_scales; ca.n_tiles = lay.n_tiles; ca.n_views = n_views; ca.nl = n_layers;
     ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
     ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);

@@ -176,16 +176,22 @@ struct Sequencer {
 
 // ------------------------------------------------------------------------------------------------
 // work cuts: the groups of the frame in (tile, scale, view) order, cut into `n_chunks` pieces of equal estimated cost.
-// cost of a group = 4 quarters x layers x sets (steps) + kGroupCost; + kTileCost per tile with work; an empty tile kEmptyCost.
+// Cost model in units of 64 cycles, fitted to the per-workgroup cycle counts of the diagnostic build on the bench frame
+// (tools/bench_pipe.py --fit): a step with work 76, a step of an empty set 49 (it still waits for the next step's window), a
+// sub-tile pooled from L2 instead of an LDS window + 66 per step, + 16 per group (weight reloads), + 27 per tile (its store).
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned kGroupCost = 2, kTileCost = 3, kEmptyCost = 1;
+constexpr unsigned kStepCost = 76, kEmptyStepCost = 49, kGlobStepCost = 66, kGroupCost = 16, kTileCost = 27, kEmptyCost = 1;
 
-VFA_SEQ_HD unsigned group_cost(int nj, int nl) { return 4u * (unsigned)nl * (unsigned)((nj + 1) >> 1) + kGroupCost; }
+VFA_SEQ_HD unsigned group_cost(int nj, int nl)
+{
+    const unsigned sets = (unsigned)((nj + 1) >> 1);
+    return 4u * (unsigned)nl * (kStepCost * sets + kEmptyStepCost * (2u - sets)) + kGroupCost;
+}
 
 // walks the groups of a tile (masks m[0 .. n_scales)): visit(k, w0, w1) for the k-th group covering [w0, w1) of the tile's cost;
-// returns the tile's cost
+// `globs` = (view, layer, scale) items of the tile that are pooled from L2 (charged to the first group); returns the tile's cost
 template <class Visit>
-VFA_SEQ_HD unsigned walk_tile(const unsigned *m, int n_scales, int nl, Visit &&visit)
+VFA_SEQ_HD unsigned walk_tile(const unsigned *m, int n_scales, int nl, unsigned globs, Visit &&visit)
 {
     unsigned w = 0;
     int k = 0;
@@ -194,7 +200,7 @@ VFA_SEQ_HD unsigned walk_tile(const unsigned *m, int n_scales, int nl, Visit &&v
         while (left > 0) {
             const int nj = left < kGroupViews ? left : kGroupViews;
             unsigned wi = group_cost(nj, nl);
-            if (k == 0) wi += kTileCost;
+            if (k == 0) wi += kTileCost + 4u * kGlobStepCost * globs;
             visit(k, w, w + wi);
             w += wi;
             ++k;

@@ -547,11 +547,11 @@ def pipe_collapse(integrals, biases, workspace, grid_lw, n_layers, out=None, acc
 def pipe_workspace_layout(n_views, L, W, n_layers, n_scales):
     """Offsets inside the ``pipe_records`` workspace, for tests and tools."""
     import ctypes
-    off = (ctypes.c_size_t * 17)()
+    off = (ctypes.c_size_t * 18)()
     tiles = (ctypes.c_int * 4)()
     _lib.call("vfa_pipe_workspace_layout", int(n_views), int(L), int(W), int(n_layers), int(n_scales), off, tiles)
     names = ("live", "hdrs", "recs", "wfrag")
     out = {nm: [int(off[4 * k + i]) for k in range(n_scales)] for i, nm in enumerate(names)}
-    out.update(tickets=int(off[12]), chunks=int(off[13]), ranks=int(off[14]), diag=int(off[15]), total=int(off[16]),
+    out.update(tickets=int(off[12]), globs=int(off[17]), chunks=int(off[13]), ranks=int(off[14]), diag=int(off[15]), total=int(off[16]),
                tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]))
     return out
