@@ -366,8 +366,8 @@ struct FusedArgs {
     int n_scales, n_views, L, W, tiles_w, n_tiles;
     float *out;                     // (L * W, 256)
     const int *chunk_start, *chunk_rank; // (kChunks + 1) each: tile_chunks_kernel
-    float *partial;                 // per workgroup 8 waves x 16 registers x 64 lanes: sums of a tile finished by another workgroup
-    unsigned *flags;                // per workgroup: partial sums published (zeroed by pool_rows_kernel before every launch)
+    float *partial;                 // (kMaxBlocks, 2) x 8 waves x 16 registers x 64 lanes: a workgroup's part of a tile it shares (first / last tile)
+    unsigned *tickets;              // (n_tiles): parts of a shared tile that have arrived (zeroed by the host call before every launch)
     const float *rows;              // pooled rows of the direct items (pool_rows_kernel): slot x 32 boxes x 256 channels
     const unsigned *row_counter;    // direct items of the frame
     int rows_cap;                   // row slots in the workspace
@@ -463,6 +463,30 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     if (!DIRECT) range_of(lb, t_begin, k_begin, t_end, k_end);
     if (t_begin > t_end || (t_begin == t_end && k_begin >= k_end)) return;
     const int t_lim = (!DIRECT && k_end > 0) ? t_end + 1 : t_end; // tiles this workgroup looks at
+    // A tile cut between workgroups is finished by whichever of them arrives LAST (a ticket per tile): nobody ever waits for
+    // another workgroup, so the launch makes progress whatever subset of its workgroups is resident (a spin on the neighbour's
+    // flag needed all of them on the chip at once).  The partners of the two tiles this workgroup may share, found once:
+    __shared__ unsigned s_ticket;
+    auto share_of = [&](int tile, int &first, int &last, int &parts) {
+        first = lb; last = lb; parts = 1;
+        for (int j = lb - 1; j >= 0; --j) {
+            int tb, kb, te, ke;
+            range_of(j, tb, kb, te, ke);
+            if (te < tile || (te == tile && ke == 0)) break;
+            if (tb > te || (tb == te && kb >= ke)) continue; // (empty range)
+            first = j; ++parts;
+        }
+        for (int j = lb + 1; j < nblk; ++j) {
+            int tb, kb, te, ke;
+            range_of(j, tb, kb, te, ke);
+            if (tb > tile) break;
+            if (tb > te || (tb == te && kb >= ke)) continue;
+            last = j; ++parts;
+        }
+    };
+    int sh_b_first = lb, sh_b_last = lb, sh_b_parts = 1, sh_e_first = lb, sh_e_last = lb, sh_e_parts = 1;
+    if (!DIRECT && k_begin > 0) share_of(t_begin, sh_b_first, sh_b_last, sh_b_parts);
+    if (!DIRECT && k_end > 0) share_of(t_end, sh_e_first, sh_e_last, sh_e_parts);
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
 
     // view masks come by SCALAR loads (constant address space: the records kernel finished before this launch): a vector load
@@ -782,33 +806,42 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     auto flush = [&]() {
         if (pend_tile < 0) return;
         if (!DIRECT) {
-            // A tile cut between two workgroups is stored by the one that holds its beginning.  The other one (always the next
-            // in line: it STARTS with that tile, so its part is ready early in its run) leaves its partial sums in the
-            // workspace and raises a flag; agent-scope accesses, the two may sit on different XCDs.  The waits form a chain
-            // towards higher workgroup indices, never a cycle, and every workgroup that does not wait runs to its end.
-            if (pend_tile == t_end) { // (only reached with k_end > 0): somebody continues this tile
-                int j = lb + 1;
-                for (;; ++j) { // the next workgroup with a non-empty range (empty ones exist only on tiny frames)
-                    int tb, kb, te, ke;
-                    range_of(j, tb, kb, te, ke);
-                    if (tb < te || (tb == te && kb < ke)) break;
-                }
-                while (__hip_atomic_load(a.flags + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
-                const float *pp = a.partial + ((size_t)j * 8 + wave) * 16 * 64 + lane;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sum[i] += __hip_atomic_load(pp + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (pend_tile == t_begin && k_begin > 0) { // the previous workgroup holds the beginning of this tile
-                float *pp = a.partial + ((size_t)lb * 8 + wave) * 16 * 64 + lane;
+            const bool at_begin = pend_tile == t_begin && k_begin > 0, at_end = pend_tile == t_end && k_end > 0;
+            if (!(at_begin || at_end)) {
+                write_tile(pend_tile, sum, true);
+            } else {
+                // every part goes to the workspace (sc1 stores, every storing wave drained, then one ticket per workgroup); the
+                // last arriver adds the parts in workgroup order -- one fixed association -- and stores the tile
+                const int which = at_begin ? 0 : 1;
+                float *pp = a.partial + (((size_t)lb * 2 + which) * 8 + wave) * 16 * 64 + lane;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) __hip_atomic_store(pp + i * 64, sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                int lb2 = lb;
-                asm volatile("" : "+s"(lb2)); // (keeps the flag's address out of the long-lived scalar registers)
-                if (tid == 0) __hip_atomic_store(a.flags + lb2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                write_tile(pend_tile, sum, true);
+                if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.tickets + pend_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const int first = at_begin ? sh_b_first : sh_e_first, last = at_begin ? sh_b_last : sh_e_last;
+                const int parts = at_begin ? sh_b_parts : sh_e_parts;
+                if (uniform_i((int)s_ticket) == parts - 1) {
+                    f32x16 tot;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
+                    for (int j = first; j <= last; ++j) {
+                        if (j == lb) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) tot[i] += sum[i];
+                            continue;
+                        }
+                        int tb, kb, te, ke;
+                        range_of(j, tb, kb, te, ke);
+                        if (tb > te || (tb == te && kb >= ke)) continue;
+                        const int wj = (pend_tile == tb && kb > 0) ? 0 : 1;
+                        const float *qq = a.partial + (((size_t)j * 2 + wj) * 8 + wave) * 16 * 64 + lane;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) tot[i] += __hip_atomic_load(qq + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    write_tile(pend_tile, tot, true);
+                }
             }
         } else {
             write_tile(pend_tile, sum, true);
@@ -1191,13 +1224,11 @@ struct RowsArgs {
     const unsigned *row_list;    // slot -> scale << 30 | view << 25 | tile (frame_records_kernel)
     const unsigned *row_counter; // direct items of the frame
     float *rows;
-    unsigned *flags; // hand-off flags of the persistent kernel (kMaxBlocks), cleared here: this launch precedes it every time
     int n_tiles, rows_cap;
 };
 __global__ __launch_bounds__(512) void pool_rows_kernel(RowsArgs a)
 {
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, grp = lane >> 4, cq = lane & 15;
-    if (blockIdx.x == 0 && tid < kMaxBlocks) a.flags[tid] = 0u;
     const int count = min(uniform_i((int)*a.row_counter), a.rows_cap);
     const int b = 4 * wave + grp;
     // unit = (direct item, 64-channel quarter); the items come from the list the geometry pass appended to
@@ -1243,7 +1274,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
     size_t live[kMaxScales], direct[kMaxScales], overflow[kMaxScales], counter, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales],
-        masks_bytes, chunks, ranks, diag, rows, row_list, partial, flags, item_w, total;
+        masks_bytes, chunks, ranks, diag, rows, row_list, partial, tickets, item_w, total;
     int tiles_l, tiles_w, n_tiles, rows_cap, views_pad;
 };
 inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
@@ -1271,10 +1302,10 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     off = align_up(off + (kChunks + 1) * sizeof(int), 256);
     w.ranks = off;
     off = align_up(off + (kChunks + 1) * sizeof(int), 256);
-    w.flags = off; // hand-off of tiles cut between two workgroups of the persistent kernel: a flag and 32 KiB of partial sums each
-    off = align_up(off + kMaxBlocks * sizeof(unsigned), 256);
+    w.tickets = off; // hand-off of tiles cut between workgroups of the persistent kernel: a ticket per tile, two 32 KiB parts per workgroup
+    off = align_up(off + (size_t)w.n_tiles * sizeof(unsigned), 256);
     w.partial = off;
-    off = align_up(off + (size_t)kMaxBlocks * 8 * 16 * 64 * sizeof(float), 256);
+    off = align_up(off + (size_t)kMaxBlocks * 2 * 8 * 16 * 64 * sizeof(float), 256);
     w.diag = off;
     off = align_up(off + 512 * 8 * sizeof(unsigned long long), 256); // diagnostic build: 8 counters per workgroup
     // pooled rows of the direct items: room for a quarter of all (view, tile, scale) items, at most 256 MiB; the rest (none on the
@@ -1503,7 +1534,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
     a.chunk_start = reinterpret_cast<const int *>(ws + lay.chunks);
     a.chunk_rank = reinterpret_cast<const int *>(ws + lay.ranks);
     a.partial = reinterpret_cast<float *>(const_cast<unsigned char *>(ws) + lay.partial);
-    a.flags = reinterpret_cast<unsigned *>(const_cast<unsigned char *>(ws) + lay.flags);
+    a.tickets = reinterpret_cast<unsigned *>(const_cast<unsigned char *>(ws) + lay.tickets);
     a.debug = debug;
     a.diag = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(ws) + lay.diag);
     int n_cu = 256;
@@ -1530,10 +1561,13 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
         ra.row_counter = a.row_counter;
         ra.rows = reinterpret_cast<float *>(const_cast<unsigned char *>(ws) + lay.rows);
         ra.n_tiles = lay.n_tiles; ra.rows_cap = rows_cap;
-        ra.flags = a.flags;
         hipLaunchKernelGGL(pool_rows_kernel, dim3(1024), dim3(512), 0, s, ra);
         const int st0 = (int)hipGetLastError();
         if (st0 || (flags & VFA_FLAG_ROWS_ONLY)) return st0;
+    }
+    { // every call takes its own tickets (a second pass over the same workspace must not see the first one's)
+        const hipError_t e = hipMemsetAsync(a.tickets, 0, (size_t)lay.n_tiles * sizeof(unsigned), s);
+        if (e != hipSuccess) return (int)e;
     }
     if (debug & 64) { // diagnostic: only the second launch (direct items without a row slot)
         hipLaunchKernelGGL((pool_collapse_kernel<3, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
