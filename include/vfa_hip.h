@@ -275,19 +275,23 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
  *
  * workspace: caller-owned, vfa_pipe_workspace_bytes(); the geometry calls fill it, the kernel reads it (and uses its hand-off
  * area: a tile cut between two workgroups is finished by whichever arrives last, nobody waits).  integrals[k]: zero-bordered
- * channels-last (n_views, Hf+2, Wf+2, 256).  n_views <= 32.  flags: VFA_FLAG_TERMS_MASK (0 / 3 = three products, 4 adds lo.lo) |
- * VFA_FLAG_RESERVED_CUS(n) | VFA_FLAG_DEBUG(mask).  On a single-layer grid the result equals
- * vfa_pool_collapse_relu_sum_f32 bit for bit. */
+ * channels-last (n_views, Hf+2, Wf+2, 256).  n_views <= 32.  flags: VFA_FLAG_TERMS_MASK | VFA_FLAG_RESERVED_CUS(n) |
+ * VFA_FLAG_DEBUG(mask).  Terms: 0 / 3 = two bf16 pieces per operand, three products (error ~3e-6 of max|out|, inside the path's
+ * 1e-5); 4 adds lo.lo; 6 = THREE pieces per operand (x = p0 + p1 + p2 to 2^-25) and the six products down to 2^-16 of the
+ * largest: the arithmetic width of the reference's fp32 sgemm (<= 5e-7 normwise against float64), at twice the matrix work.
+ * The geometry calls take the same terms in `flags` (the three-piece variant has smaller LDS tap windows, so the geometry must
+ * know which kernel will read its records; pass the value that goes to vfa_pipe_collapse_relu_sum_f32).  On a single-layer
+ * grid the three-product result equals vfa_pool_collapse_relu_sum_f32 bit for bit (on tiles no workgroup boundary cuts). */
 size_t vfa_pipe_workspace_bytes(int n_views, int L, int W, int n_layers, int n_scales);
 int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_scales, size_t *offsets, int *tiles);
 int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off, int n_views,
                        int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales, const int *feat_hw,
-                       void *workspace, size_t workspace_bytes, void *stream);
+                       int flags, void *workspace, size_t workspace_bytes, void *stream);
 int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, const float *const *weights, void *workspace,
                       size_t workspace_bytes, void *stream);
 int vfa_pipe_records_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off,
                          int n_views, int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
-                         const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream);
+                         const int *feat_hw, const float *const *weights, int flags, void *workspace, size_t workspace_bytes, void *stream);
 int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, void *workspace, size_t workspace_bytes,
                                    float *out, int n_views, int L, int W, int n_layers, int n_scales, const int *feat_hw, int accumulate,
                                    int flags, void *stream);

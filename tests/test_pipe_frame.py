@@ -338,3 +338,40 @@ def test_pipe_work_cuts_match_the_serial_restatement():
                 exp_start[c], exp_rank[c] = t, 0
                 c += 1
     assert np.array_equal(start, exp_start) and np.array_equal(rank, exp_rank)
+
+
+@pytest.mark.parametrize("name,n_cam,crop,origin", [
+    ("multiviewc_200x200x1", 7, (48, 96), (70, 50)),      # K = 256
+    ("multiviewc_156x156x5", 5, (32, 56), (60, 40)),      # K = 1280
+])
+def test_three_piece_product_has_the_width_of_the_reference_sgemm(name, n_cam, crop, origin):
+    """VFA_FLAG_TERMS 6: three bf16 pieces per operand, six products.  The reference's ``collapse`` is an fp32 ``nn.Linear``
+    (vfa_op.py:123); an fp32 sgemm sits ~3e-7 (normwise) from float64 at these shapes.  The three-piece product must be in that
+    class -- <= 5e-7 -- an order of magnitude below the default two-piece / three-product arithmetic (~3e-6), on ordinary,
+    SIGNED and HEAVY-TAILED feature maps (the split loses nothing to cancellation or dynamic range)."""
+    from vfa_amd import vfa_op
+    dev = _dev()
+    wl, grid, lats, calibs = _frame(name, n_cam, crop, dev, origin=origin)
+    mods = _mods(wl, dev)
+    gen = torch.Generator().manual_seed(11)
+    variants = {
+        "relu(randn)": lats,
+        "signed": [l - 0.4 for l in lats],
+        "heavy-tailed": [l * (torch.exp(2.5 * torch.randn(l.shape, generator=gen)) * torch.sign(torch.randn(l.shape, generator=gen))).to(dev)
+                         for l in lats],
+    }
+    for label, feats in variants.items():
+        with torch.no_grad():
+            want = _float64_reference(mods, feats, calibs, grid, wl)
+            got6 = vfa_op.pipe_frame(mods, feats, calibs, grid, terms=6)
+            got3 = vfa_op.pipe_frame(mods, feats, calibs, grid, terms=3)
+        scale = want.abs().max().item()
+        e6 = ((got6.double() - want).norm() / want.norm()).item()
+        e3 = ((got3.double() - want).norm() / want.norm()).item()
+        m6 = (got6.double() - want).abs().max().item() / scale
+        m3 = (got3.double() - want).abs().max().item() / scale
+        print(f"[width] {name} {label}: three pieces normwise {e6:.2e} (max {m6:.2e} of max|out|), two pieces {e3:.2e} (max {m3:.2e})")
+        assert torch.isfinite(got6).all()
+        assert e6 <= 5e-7, (label, e6)
+        assert m6 <= 2e-6, (label, m6)
+        _check(f"{name} {label} two pieces", got3, want)

@@ -67,10 +67,10 @@ SIGNATURES = {
     "vfa_pipe_workspace_bytes": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "vfa_pipe_workspace_layout": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp],
     "vfa_pipe_boxes_f32": [_vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
-                           _c_int, _vp, _vp, _c_size_t, _vp],
+                           _c_int, _vp, _c_int, _vp, _c_size_t, _vp],
     "vfa_pipe_cuts_f32": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_size_t, _vp],
     "vfa_pipe_records_f32": [_vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
-                             _c_int, _vp, _vp, _vp, _c_size_t, _vp],
+                             _c_int, _vp, _vp, _c_int, _vp, _c_size_t, _vp],
     "vfa_pipe_collapse_relu_sum_f32": [_vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
                                        _vp],
 }

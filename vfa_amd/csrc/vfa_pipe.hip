@@ -39,14 +39,16 @@ constexpr int kRecBytes = 96, kHdrBytes = 32;
 constexpr int kMaxScales = 3;
 constexpr int kSlotBytes = kC * 4;              // one tap in the integral image: 256 fp32
 constexpr int kQSlot = 256;                     // ... and the 64-channel quarter of it that a step needs
-constexpr int kWinSlots = 108;                  // LDS tap window of a (tile, view, layer, scale), in quarter slots
-constexpr int kWinBytes = kWinSlots * kQSlot;   // 28 KiB; four of them: two being pooled, two arriving
+constexpr int kWinSlots = 108;                  // LDS tap window of a (tile, view, layer, scale), in quarter slots: four of them (two being
+                                                // pooled, two arriving); 27 KiB each
+constexpr int kWinSlots3 = 92;                  // ... of the three-piece variant (VFA_FLAG_TERMS 6): a third bf16 plane takes 17 KiB of LDS
 constexpr int kMatWaves = 8, kPoolWaves = 4, kThreads = 64 * (kMatWaves + kPoolWaves);
 constexpr int kStepRows = 64;                   // rows of a step: two sub-tiles
 // A tile of a step in LDS, per bf16 plane: 8 chunks (16 bytes = 8 k) x 64 rows x 16 bytes, chunk stride padded by 32 bytes
 // (the pooling waves' 8-byte stores of neighbouring chunks then fall into different banks)
 constexpr int kChunkStride = kStepRows * 16 + 32;
 constexpr int kPlaneBytes = 8 * kChunkStride;   // 8448
+constexpr int kWPlanes = 3;                     // bf16 planes of the split collapse weight in the workspace: hi, mid (= lo of the two-piece split), lo
 constexpr int kSteps = 16;                      // k-steps of v_mfma_f32_32x32x16_bf16 per layer
 constexpr int kChunks = 8192, kMaxBlocks = 512;
 constexpr int kVis = 1;
@@ -65,7 +67,7 @@ __device__ __forceinline__ float relu_t(float x) { return (x < 0.0f) ? 0.0f : x;
 // ------------------------------------------------------------------------------------------------
 struct RecordArgs {
     BoxGeom g;
-    int n_views, L, W, tiles_w, n_tiles, n_scales, nl;
+    int n_views, L, W, tiles_w, n_tiles, n_scales, nl, win_slots;
     ScaleDims dims[kMaxScales];
     unsigned *live[kMaxScales];      // (n_tiles) bit v = view v has a live box in the tile, in any layer
     unsigned *globs;                 // (n_tiles) live (view, layer, scale) items whose tap window does not fit LDS
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
                 }
                 n_slots = cwid * (top_rows + bot_rows);
             }
-            const bool direct = n_slots > kWinSlots; // pooled straight from the integral image: pixel coordinates in the record
+            const bool direct = n_slots > a.win_slots; // pooled straight from the integral image: pixel coordinates in the record
             auto slot_row = [&](int y) { return y < t0 + top_rows ? y - t0 : top_rows + (y - b0); };
             unsigned rows[4], cols[4];
 #pragma unroll
@@ -192,28 +194,31 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
     if (pair_ok && b == 0 && n_glob) atomicAdd(a.globs + tile, n_glob);
 }
 
-// collapse.weight of a scale, in the REFERENCE layout (256, 256 * nl), column = c * nl + layer (vfa_op.py:59, :120), as bf16
-// hi / lo planes in MFMA B-fragment order, one 256 KiB block per layer:
-//   out[(((layer * 8 + wave) * 16 + s) * 2 + plane) * 64 + lane] (16 B) = W[n = 32 wave + (lane & 31)][c = 16 s + 8 (lane >> 5) + j], j = 0..7
+// collapse.weight of a scale, in the REFERENCE layout (256, 256 * nl), column = c * nl + layer (vfa_op.py:59, :120), as THREE bf16
+// planes x = p0 + p1 + p2 (+ r, |r| <= 2^-25 |x|; p0 + p1 is the two-piece split) in MFMA B-fragment order, 384 KiB per layer:
+//   out[(((layer * 8 + wave) * 16 + s) * 3 + plane) * 64 + lane] (16 B) = W[n = 32 wave + (lane & 31)][c = 16 s + 8 (lane >> 5) + j], j = 0..7
 struct SplitArgs { const float *w[kMaxScales]; uint4 *out[kMaxScales]; int nl; };
 __global__ __launch_bounds__(256) void pipe_split_weight_kernel(SplitArgs sa)
 {
     const int scale = blockIdx.y / sa.nl, layer = blockIdx.y - scale * sa.nl;
     const float *__restrict__ w = sa.w[scale];
-    uint4 *__restrict__ out = sa.out[scale] + (size_t)layer * 8 * kSteps * 2 * 64;
+    uint4 *__restrict__ out = sa.out[scale] + (size_t)layer * 8 * kSteps * kWPlanes * 64;
     const int idx = blockIdx.x * 256 + threadIdx.x; // (wave, s, lane)
     if (idx >= 8 * kSteps * 64) return;
     const int lane = idx & 63, s = (idx >> 6) & 15, wave = idx >> 10;
     const float *src = w + (size_t)(wave * 32 + (lane & 31)) * kC * sa.nl + (size_t)(16 * s + 8 * (lane >> 5)) * sa.nl + layer;
-    union { __bf16 b[8]; uint4 u; } hi, lo;
+    union { __bf16 b[8]; uint4 u; } p0, p1, p2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float x = src[(size_t)j * sa.nl];
-        hi.b[j] = (__bf16)x;
-        lo.b[j] = (__bf16)(x - (float)hi.b[j]);
+        p0.b[j] = (__bf16)x;
+        const float r1 = x - (float)p0.b[j];
+        p1.b[j] = (__bf16)r1;
+        p2.b[j] = (__bf16)(r1 - (float)p1.b[j]);
     }
-    out[((size_t)(wave * kSteps + s) * 2 + 0) * 64 + lane] = hi.u;
-    out[((size_t)(wave * kSteps + s) * 2 + 1) * 64 + lane] = lo.u;
+    out[((size_t)(wave * kSteps + s) * kWPlanes + 0) * 64 + lane] = p0.u;
+    out[((size_t)(wave * kSteps + s) * kWPlanes + 1) * 64 + lane] = p1.u;
+    out[((size_t)(wave * kSteps + s) * kWPlanes + 2) * 64 + lane] = p2.u;
 }
 
 // work cuts (vfa_pipe_seq.h: walk_tile): one workgroup, an LDS scan over per-thread sums, then every thread places the cuts
@@ -312,6 +317,7 @@ struct DevMasks {
 };
 
 struct Frag { bf16x8 hi, lo; };
+struct Frag3 { bf16x8 hi, lo, lo2; };
 
 __device__ __forceinline__ float4 mul4(float4 a, float w) { return make_float4(a.x * w, a.y * w, a.z * w, a.w * w); }
 __device__ __forceinline__ float4 fma4(float4 a, float w, float4 c)
@@ -356,12 +362,25 @@ __device__ __forceinline__ void wait_frags(bf16x8 &h0, bf16x8 &l0, bf16x8 &h1, b
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h0), "+v"(l0), "+v"(h1), "+v"(l1));
 }
 
+// three planes of ONE row block (the three-piece variant keeps 48 weight registers: both row blocks' fragments would not fit)
+template <int KS, int RB, int PLANE_BYTES>
+__device__ __forceinline__ void read_frags3(unsigned pa, bf16x8 &p0, bf16x8 &p1, bf16x8 &p2)
+{
+    asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(p0), "=&v"(p1), "=&v"(p2)
+                 : "v"(pa), "n"(KS * 2 * kChunkStride + RB * 512), "n"(KS * 2 * kChunkStride + RB * 512 + PLANE_BYTES),
+                   "n"(KS * 2 * kChunkStride + RB * 512 + 2 * PLANE_BYTES)
+                 : "memory");
+}
+
 template <int TERMS, bool DIAG>
 __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
 {
     // separate objects: one per role of the data (hipcc orders LDS-DMA against every LDS access it cannot prove disjoint)
+    constexpr int kPieces = TERMS == 6 ? 3 : 2;                             // bf16 pieces of an operand
+    constexpr int kWinBytes = (TERMS == 6 ? kWinSlots3 : kWinSlots) * kQSlot;
     __shared__ __align__(16) unsigned char s_win[4 * kWinBytes];            // tap windows: [step parity][sub-tile of the set]
-    __shared__ __align__(16) unsigned char s_planes[2 * 2 * kPlaneBytes];   // A tiles: [step parity][hi, lo]
+    __shared__ __align__(16) unsigned char s_planes[2 * kPieces * kPlaneBytes]; // A tiles: [step parity][piece]
     __shared__ __align__(16) unsigned char s_rec[4 * kTileBoxes * kRecBytes]; // box records of the group's sub-tiles, one layer
     __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
     __shared__ unsigned s_misc[16];
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
 
         // ---------------------------------------------------------------- matrix-wave state
         f32x16 acc[4], sum;
-        Frag wq[4];
+        Frag3 wq[4]; // (lo2: the three-piece variant only)
         float bc[kMaxScales];
         if constexpr (!POOL) {
 #pragma unroll
@@ -528,7 +547,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                                            (unsigned long long)view * (unsigned)((Hf + 2) * (Wf + 2)) * kSlotBytes + (unsigned)(q * kQSlot);
             const unsigned long long rec = scale_ptr(scale, a.sc[0].recs, a.sc[1].recs, a.sc[2].recs) + item * (kTileBoxes * kRecBytes);
             const unsigned long long wsl = scale_ptr(scale, a.sc[0].wfrag, a.sc[1].wfrag, a.sc[2].wfrag) +
-                                           (unsigned long long)(((unsigned)layer * 8u * kSteps + (unsigned)q * 4u) * 2u * 64u) * 16u;
+                                           (unsigned long long)(((unsigned)layer * 8u * kSteps + (unsigned)q * 4u) * (unsigned)kWPlanes * 64u) * 16u;
             const unsigned fw = j < nj ? ((flags & 0xffu) | (n_slots << 8)) : 0u;
             if (lane < 16) {
                 uint4 *d = reinterpret_cast<uint4 *>(&s_desc[n & 3][k][x][0]);
@@ -576,10 +595,14 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         };
         auto w_load = [&](int ks) {
             const char *base = reinterpret_cast<const char *>((size_t)((unsigned long long)w_hi << 32 | w_lo));
-            const uint4 *src = reinterpret_cast<const uint4 *>(base + (unsigned)(wave * kSteps * 2 * 64 * 16 + lane * 16)) + ks * 2 * 64;
+            const uint4 *src = reinterpret_cast<const uint4 *>(base + (unsigned)(wave * kSteps * kWPlanes * 64 * 16 + lane * 16)) + ks * kWPlanes * 64;
             const uint4 uh = src[0], ul = src[64];
             wq[ks].hi = *reinterpret_cast<const bf16x8 *>(&uh);
             wq[ks].lo = *reinterpret_cast<const bf16x8 *>(&ul);
+            if constexpr (TERMS == 6) {
+                const uint4 u2 = src[128];
+                wq[ks].lo2 = *reinterpret_cast<const bf16x8 *>(&u2);
+            }
         };
 
         // ---------------------------------------------------------------- products of one step (matrix waves)
@@ -599,7 +622,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             const bool work = 2 * SET < ph.nj() && !(DIAG && (a.debug & 4)); // (set 1 of a group of one or two views is empty)
             // A fragments: lane (r, h) of row block rb reads chunk 2 ks + h, row 32 rb + r (read_frags)
             const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)s_planes +
-                                (unsigned)(par * 2 * kPlaneBytes + h * kChunkStride + r * 16);
+                                (unsigned)(par * kPieces * kPlaneBytes + h * kChunkStride + r * 16);
             // ONE set of fragment registers: the reads of k-step ks + 1 are issued behind the MFMAs of ks (which latched their A
             // operands when they issued) and land under them and under the partner wave's MFMAs; a second set for reading ahead
             // does not fit beside four accumulators, the tile sums and the weight slice (168 registers at three waves per SIMD)
@@ -609,6 +632,29 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             auto kstep = [&](auto ks_tag) {
                 constexpr int KS = decltype(ks_tag)::value;
                 if (work) {
+                    if constexpr (TERMS == 6) {
+                        // three pieces per operand, the six products down to 2^-16 of the largest (x = p0 + p1 + p2 to 2^-25:
+                        // p0 p0, p0 p1, p1 p0, p0 p2, p2 p0, p1 p1; what is dropped is <= 2^-23 of the product): sgemm-class
+                        bf16x8 a0, a1, a2;
+                        read_frags3<KS, 0, kPlaneBytes>(pa, a0, a1, a2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].lo2, acc[2 * SET], 0, 0, 0);
+                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wq[KS].hi, acc[2 * SET], 0, 0, 0);
+                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wq[KS].lo, acc[2 * SET], 0, 0, 0);
+                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
+                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wq[KS].hi, acc[2 * SET], 0, 0, 0);
+                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        read_frags3<KS, 1, kPlaneBytes>(pa, a0, a1, a2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].lo2, acc[2 * SET + 1], 0, 0, 0);
+                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
                     read_frags<KS>(pa, fh0, fl0, fh1, fl1);
                     wait_frags<0>(fh0, fl0, fh1, fl1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -623,6 +669,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                         acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 if (reload && work) w_load(KS); // the next slice (w_addr), k-step by k-step, into the registers just used
             };
@@ -685,7 +732,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                 img = reinterpret_cast<const char *>((size_t)((unsigned long long)d0.y << 32 | d0.x));
             }
             const int row = x * 32 + (pw & 1) * 16 + pb;
-            unsigned char *planes = s_planes + set * 2 * kPlaneBytes;
+            unsigned char *planes = s_planes + set * kPieces * kPlaneBytes;
             // All sixteen taps of a 16-byte piece are requested at once and consumed as they arrive (counted waits).  A hand-made
             // software pipeline across the four pieces (the next piece's taps requested as soon as half of this piece's were
             // consumed) measured 35 % SLOWER (4 900 against 3 620 cycles per step): more registers, spills, and the
@@ -711,16 +758,20 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                 v = make_float4(v.x - lb2.x, v.y - lb2.y, v.z - lb2.z, v.w - lb2.w);
                 const float xs[4] = {v.x * bx.scl, v.y * bx.scl, v.z * bx.scl, v.w * bx.scl};
                 // x = hi + lo + r, |r| <= 2^-17 |x|: hi = RNE bf16(x), lo = RNE bf16(x - hi)
-                union { __bf16 b[4]; uint2 u; } hi, lo;
+                // (three-piece variant: lo2 = RNE bf16(x - hi - lo), |x - hi - lo - lo2| <= 2^-25 |x|)
+                union { __bf16 b[4]; uint2 u; } hi, lo, lo2;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     hi.b[k] = (__bf16)xs[k];
-                    lo.b[k] = (__bf16)(xs[k] - (float)hi.b[k]);
+                    const float r1 = xs[k] - (float)hi.b[k];
+                    lo.b[k] = (__bf16)r1;
+                    if constexpr (TERMS == 6) lo2.b[k] = (__bf16)(r1 - (float)lo.b[k]);
                 }
                 // channels 16 piece + 4 pi .. + 3 of the quarter: chunk 2 piece + (pi >> 1), half pi & 1
                 const int off = (int)(2 * piece + (pi >> 1)) * kChunkStride + row * 16 + (pi & 1) * 8;
                 *reinterpret_cast<uint2 *>(planes + off) = hi.u;
                 *reinterpret_cast<uint2 *>(planes + kPlaneBytes + off) = lo.u;
+                if constexpr (TERMS == 6) *reinterpret_cast<uint2 *>(planes + 2 * kPlaneBytes + off) = lo2.u;
             }
         };
         auto pool_step = [&](auto set_tag, int i) {
@@ -735,12 +786,13 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                 }
                 if (!live) { // no live box in this layer (or no such sub-tile in the group): the matrix waves multiply zeros
                     const int row = x * 32 + (pw & 1) * 16 + pb;
-                    unsigned char *planes = s_planes + SET * 2 * kPlaneBytes;
+                    unsigned char *planes = s_planes + SET * kPieces * kPlaneBytes;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         const int off = (2 * m + (pi >> 1)) * kChunkStride + row * 16 + (pi & 1) * 8;
                         *reinterpret_cast<uint2 *>(planes + off) = make_uint2(0u, 0u);
                         *reinterpret_cast<uint2 *>(planes + kPlaneBytes + off) = make_uint2(0u, 0u);
+                        if constexpr (TERMS == 6) *reinterpret_cast<uint2 *>(planes + 2 * kPlaneBytes + off) = make_uint2(0u, 0u);
                     }
                     return;
                 }
@@ -967,7 +1019,7 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
         const bool on = s < n_scales;
         w.hdrs[s] = off;  off = align_up(off + (on ? items * kHdrBytes : 0), 256);
         w.recs[s] = off;  off = align_up(off + (on ? items * kTileBoxes * kRecBytes : 0), 256);
-        w.wfrag[s] = off; off = align_up(off + (on ? (size_t)nl * 8 * kSteps * 2 * 64 * 16 : 0), 256);
+        w.wfrag[s] = off; off = align_up(off + (on ? (size_t)nl * 8 * kSteps * kWPlanes * 64 * 16 : 0), 256);
     }
     w.chunks = off;  off = align_up(off + (kChunks + 1) * sizeof(int), 256);
     w.ranks = off;   off = align_up(off + (kChunks + 1) * sizeof(int), 256);
@@ -1011,14 +1063,17 @@ int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_sca
     tiles[0] = lay.tiles_l;
     tiles[1] = lay.tiles_w;
     tiles[2] = kWinSlots;
+    tiles[4] = kWinSlots3;
     tiles[3] = kChunks;
     return 0;
 }
 
 int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off, int n_views,
                        int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales, const int *feat_hw,
-                       void *workspace, size_t workspace_bytes, void *stream)
+                       int flags, void *workspace, size_t workspace_bytes, void *stream)
 {
+    const int terms = flags & VFA_FLAG_TERMS_MASK;
+    if ((flags & ~VFA_FLAG_TERMS_MASK) || (terms != 0 && terms != 3 && terms != 4 && terms != 6)) return VFA_ERR_BAD_ARGUMENT;
     if (!dims_ok(n_views, L, W, n_layers, n_scales) || conv_kind < 0 || conv_kind > 2 || !feat_hw) return VFA_ERR_BAD_ARGUMENT;
     if (n_views > 32) return VFA_ERR_UNSUPPORTED; // live-view masks are 32 bits wide
     const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
@@ -1030,6 +1085,7 @@ int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_la
     RecordArgs a;
     a.g = BoxGeom{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
     a.n_views = n_views; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles; a.n_scales = n_scales; a.nl = n_layers;
+    a.win_slots = terms == 6 ? kWinSlots3 : kWinSlots; // (the kernel variant that will read these records)
     for (int k = 0; k < kMaxScales; ++k) {
         a.dims[k].Hf = k < n_scales ? feat_hw[2 * k] : 1;
         a.dims[k].Wf = k < n_scales ? feat_hw[2 * k + 1] : 1;
@@ -1083,10 +1139,10 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
 
 int vfa_pipe_records_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off,
                          int n_views, int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
-                         const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream)
+                         const int *feat_hw, const float *const *weights, int flags, void *workspace, size_t workspace_bytes, void *stream)
 {
     const int st = vfa_pipe_boxes_f32(calibs, grid, z_layers, n_layers, corner_off, n_views, L, W, conv_kind, img_w, img_h, cmin, cmax,
-                                      n_scales, feat_hw, workspace, workspace_bytes, stream);
+                                      n_scales, feat_hw, flags, workspace, workspace_bytes, stream);
     if (st) return st;
     return vfa_pipe_cuts_f32(n_views, L, W, n_layers, n_scales, weights, workspace, workspace_bytes, stream);
 }
@@ -1097,7 +1153,7 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *c
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xfff;
     if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00)) return VFA_ERR_BAD_ARGUMENT;
-    if (!dims_ok(n_views, L, W, n_layers, n_scales) || !feat_hw || !integrals || (terms != 0 && terms != 3 && terms != 4))
+    if (!dims_ok(n_views, L, W, n_layers, n_scales) || !feat_hw || !integrals || (terms != 0 && terms != 3 && terms != 4 && terms != 6))
         return VFA_ERR_BAD_ARGUMENT;
     if (n_views > 32) return VFA_ERR_UNSUPPORTED;
     const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
@@ -1148,6 +1204,8 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *c
         hipLaunchKernelGGL((pipe_kernel<3, true>), dim3(nblk), dim3(kThreads), 0, s, a);
     else if (terms == 4)
         hipLaunchKernelGGL((pipe_kernel<4, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+    else if (terms == 6)
+        hipLaunchKernelGGL((pipe_kernel<6, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     else
         hipLaunchKernelGGL((pipe_kernel<3, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     return (int)hipGetLastError();

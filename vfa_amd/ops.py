@@ -462,7 +462,8 @@ def frame_workspace_layout(n_views, L, W, n_scales):
     out["overflow"] = [int(off[17 + k]) for k in range(n_scales)]
     out.update(diag=int(off[15]), total=int(off[16]), counter=int(off[20]), rows=int(off[21]), rows_cap=int(off[22]),
                chunks=int(off[23]), ranks=int(off[24]),
-               tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]))
+               tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]),
+               max_slots_3piece=int(tiles[4]))
     return out
 
 
@@ -474,13 +475,14 @@ def pipe_workspace_bytes(n_views, L, W, n_layers, n_scales):
 
 
 def pipe_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_hws, weights=None, crange=(-1, 0.95), workspace=None,
-                 cuts=True):
+                 cuts=True, terms=0):
     """Geometry of one frame for ``pipe_collapse``: box records and tap-window headers of every (view, cell, layer) for each
     feature scale, the work cuts and the split collapse weights -> workspace (reference vfa_op.py:64-106).
 
     calibs (n,3,4), grid (L,W,3) or (1,L,W,3), z_layers (nl), feat_hws = [(Hf,Wf), ...] (1..3 scales), weights = one
     (256, 256*nl) per scale in the REFERENCE column order c*nl + layer (``collapse.weight`` as it is).  ``cuts=False``: the
-    boxes only (``pipe_cuts`` adds the rest)."""
+    boxes only (``pipe_cuts`` adds the rest).  ``terms``: the product variant ``pipe_collapse`` will be called with (6 = three bf16
+    pieces per operand: smaller LDS tap windows, so the geometry has to know)."""
     _lib.require_device(calibs, grid, z_layers, corner_off)
     grid = _f32c(grid.reshape(grid.shape[-3], grid.shape[-2], 3))
     L, W = grid.shape[:2]
@@ -495,7 +497,8 @@ def pipe_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_h
     args = (_lib.ptr(calibs), _lib.ptr(grid), _lib.ptr(z_layers), nl, _lib.ptr(corner_off), n, L, W, int(conv_kind),
             float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), ns, hw)
     if not cuts:
-        _launch("vfa_pipe_boxes_f32", *args, _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(), tag=(n, L, W, nl, ns))
+        _launch("vfa_pipe_boxes_f32", *args, int(terms) & 0xf, _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(),
+                tag=(n, L, W, nl, ns))
         return workspace
     wts = None
     if weights is not None:
@@ -503,7 +506,7 @@ def pipe_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_h
         assert len(weights) == ns and all(tuple(w.shape) == (256, 256 * nl) for w in weights)
         _lib.require_device(*weights)
         wts = _lib.ptr_array(weights)
-    _launch("vfa_pipe_records_f32", *args, wts, _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(),
+    _launch("vfa_pipe_records_f32", *args, wts, int(terms) & 0xf, _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(),
             tag=(n, L, W, nl, ns))
     return workspace
 
@@ -548,10 +551,11 @@ def pipe_workspace_layout(n_views, L, W, n_layers, n_scales):
     """Offsets inside the ``pipe_records`` workspace, for tests and tools."""
     import ctypes
     off = (ctypes.c_size_t * 18)()
-    tiles = (ctypes.c_int * 4)()
+    tiles = (ctypes.c_int * 5)()
     _lib.call("vfa_pipe_workspace_layout", int(n_views), int(L), int(W), int(n_layers), int(n_scales), off, tiles)
     names = ("live", "hdrs", "recs", "wfrag")
     out = {nm: [int(off[4 * k + i]) for k in range(n_scales)] for i, nm in enumerate(names)}
     out.update(tickets=int(off[12]), globs=int(off[17]), chunks=int(off[13]), ranks=int(off[14]), diag=int(off[15]), total=int(off[16]),
-               tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]))
+               tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]),
+               max_slots_3piece=int(tiles[4]))
     return out

@@ -216,14 +216,18 @@ def pipe_frame_ok(mods, n_views, tensors=()):
     return not any(p.requires_grad for p in params)
 
 
-def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0, integrals=None):
+def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0, integrals=None,
+               terms=None):
     """All scales, all cameras and all z-layers of one frame: ``out (L*W, 256) (+)= sum_scale sum_view relu(collapse_scale(vox))``
     (reference vfa_op.py:61-125 for every camera and scale, vfanet.py:79, 82).
 
     mods / features: one ``VFA`` and one (n,256,Hf,Wf) lateral batch per scale.  Integral images (one launch pair for all
     scales), ``ops.pipe_records`` (geometry once per frame, on a second stream beside them) and ``ops.pipe_collapse`` (everything
     else, one persistent kernel).  Inference only; needs ``pipe_frame_ok``.  Frames whose geometry workspace would exceed
-    ``PIPE_WS_LIMIT`` are processed in bands of grid rows (the bands are independent: every output row belongs to one)."""
+    ``PIPE_WS_LIMIT`` are processed in bands of grid rows (the bands are independent: every output row belongs to one).
+    ``terms``: product variant (default ``COLLAPSE_TERMS``; 6 = three bf16 pieces per operand, the arithmetic width of the reference's
+    fp32 ``nn.Linear``, at twice the matrix work)."""
+    terms = COLLAPSE_TERMS if terms is None else int(terms)
     if integrals is not None:
         features = [i.permute(0, 3, 1, 2)[:, :, 1:-1, 1:-1] for i in integrals]  # views: only their shapes are read below
     _lib.require_device(calibs, grid, *features)
@@ -262,13 +266,13 @@ def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumu
                 side.wait_stream(cur)  # (the previous band's kernel has read the workspace)
             with torch.cuda.stream(side):
                 ops.pipe_records(calibs, band, z_layers, corner_off, conv_kind, (img_w, img_h), feat_hws, weights=weights,
-                                 crange=crange, workspace=ws)
+                                 crange=crange, workspace=ws, terms=terms)
             if integrals is None:
                 integrals = ops.integral_images(features)  # all strides in one launch pair, beside the geometry
             if side is not cur:
                 cur.wait_stream(side)
             ops.pipe_collapse(integrals, biases, ws, (r1 - r0, width), nl, out=out[r0 * width:r1 * width], accumulate=accumulate,
-                              terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
+                              terms=terms, reserved_cus=reserved_cus)
         if side is not cur:
             ws.record_stream(side)
     return out
