@@ -211,11 +211,14 @@ class Leg:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def timed(self, steps, timer=None, lead_in=0):
+    def timed(self, steps, timer=None, lead_in=0, min_ms=0.0, max_blocks=40):
         """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks.  `lead_in`: untimed frames
         queued right in front of the opening bracket -- an MI355X that has been idle for a few milliseconds (the host-side
         garbage collection below is enough) runs its next ~50 ms of work ~10 % below its steady clock, and a short timed
-        region would measure that ramp instead of the path."""
+        region would measure that ramp instead of the path.  `min_ms`: the bracketed block of `steps` steps is REPEATED (each
+        repetition bracketed the same way) until the blocks add up to at least this much; returns the MEDIAN block (a 12 ms
+        region is at the mercy of one host hiccup) and leaves all of them in `self.blocks` (seconds; GPU-side times of the same
+        blocks from HIP events in `self.blocks_gpu`)."""
         torch = self.torch
         self.drain()
         self.fence()
@@ -224,25 +227,44 @@ class Leg:
         # longer than the work queued ahead of it -- seen as a 2 x outlier of a 100-step leg about once in six runs)
         gc.collect()
         gc.disable()
+        blocks, blocks_gpu = [], []
         try:
             for _ in range(lead_in):
                 self.step()
             self.drain()
             self.fence()
             with ctx:
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    self.step()
-                self.drain()
-                self.fence()
-                dt = time.perf_counter() - t0
+                while True:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0 = time.perf_counter()
+                    e0.record()
+                    for _ in range(steps):
+                        self.step()
+                    self.drain()
+                    e1.record()
+                    self.fence()
+                    dt = time.perf_counter() - t0
+                    if self.world > 1:
+                        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+                        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                        dt = t.item()
+                    blocks.append(dt)
+                    blocks_gpu.append(e0.elapsed_time(e1) * 1e-3)
+                    if sum(blocks) * 1e3 >= min_ms or len(blocks) >= max_blocks:
+                        break
         finally:
             gc.enable()
-        if self.world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            dt = t.item()
-        return dt
+        self.blocks, self.blocks_gpu = blocks, blocks_gpu
+        return sorted(blocks)[len(blocks) // 2]
+
+    def block_stats(self, steps):
+        b, g = sorted(self.blocks), sorted(self.blocks_gpu)
+        return {"blocks": len(b), "steps_per_block": steps, "timed_ms_total": 1e3 * sum(b),
+                "ms_per_step_min": 1e3 * b[0] / steps, "ms_per_step_median": 1e3 * b[len(b) // 2] / steps,
+                "ms_per_step_max": 1e3 * b[-1] / steps, "gpu_event_ms_per_step_median": 1e3 * g[len(g) // 2] / steps,
+                "note": "every block = exactly `steps` steps between barrier + synchronize brackets (host clock; MAX over ranks); the "
+                        "block is repeated until >= 100 ms are timed, `value` / `ms_per_step` are the MEDIAN block; "
+                        "gpu_event_*: the same blocks between two HIP events on the launch stream"}
 
 
 class _Null:
@@ -256,13 +278,14 @@ class _Null:
 # entry point -> the kernel that does the work, for the roofline label
 KERNEL_NAMES = {"vfa_project_gather_f32": {"tap_cache": "gather_cached_kernel", "direct": "gather_kernel<4, true>"},
                 "vfa_pool_windows_f32": {"windows": "pool_windows_kernel"},
-                "vfa_pool_collapse_relu_sum_f32": {"fused": "pool_collapse_kernel"}}
+                "vfa_pool_collapse_relu_sum_f32": {"fused": "pool_collapse_kernel"},
+                "vfa_pipe_collapse_relu_sum_f32": {"pipe": "pipe_kernel"}}
 ROOFLINE_ENTRY_POINTS = tuple(KERNEL_NAMES)
 
 
 def committed_traffic(workload, kernel_substr):
     """HBM bytes per dispatch from the committed PMC passes of this command (profiles/rNN_pmc_traffic.json), or None."""
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         tpath = os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")
         if workload == PRIMARY and os.path.exists(tpath):
             for name, rec in json.load(open(tpath))["kernels"].items():
@@ -276,34 +299,80 @@ def traffic_note(src):
             "not measured in this run)") if src else None
 
 
-def roofline_fused(g, workload):
+def live_products(leg, ops, _lib):
+    """32 x 256 x 256 products the fused kernels actually issue on this leg's frame: the (view, tile, layer, scale) items with
+    a live box (the kernels skip the others: a fully masked item contributes relu(bias), no product) -- counted once, outside
+    every timed region, from the headers of the frame's geometry."""
+    import numpy as np
+    import torch
+    m0 = leg.mods[0]
+    n = len(leg.cams)
+    if n == 0:
+        return 0, 0
+    zl, co = m0._kernel_geometry(leg.dev)
+    hws = [tuple(f.shape[-2:]) for f in leg.sets[0]]
+    L, W, nl = leg.L, leg.W, leg.nl
+    rows = L
+    while rows > 4 and ops.pipe_workspace_bytes(n, rows, W, nl, len(hws)) > (3 << 30):
+        rows = max(4, ((rows + 1) // 2 + 3) // 4 * 4)
+    live = total = 0
+    with torch.no_grad():
+        for r0 in range(0, L, rows):
+            band = leg.grid[0, r0:min(L, r0 + rows)]
+            ws = ops.pipe_records(leg.calibs, band, zl, co, _lib.CONV_KIND[leg.wl["args"].data], leg.wl["args"].image_size[::-1], hws,
+                                  cuts=False)
+            lay = ops.pipe_workspace_layout(n, band.shape[0], W, nl, len(hws))
+            items = lay["tiles_l"] * lay["tiles_w"] * nl * n
+            for s in range(len(hws)):
+                flags = ws[lay["hdrs"][s]:lay["hdrs"][s] + items * 32].view(torch.int32).view(-1, 8)[:, 0]
+                live += int((flags & 1).sum().item())
+                total += items
+            del ws
+    return live, total
+
+
+def roofline_fused(g, workload, entry, live=None, pieces=2, products=3):
     """Roofline of the fused pooling + collapse kernel (the bound becomes the matrix pipe).  One launch
-    covers every (view, scale) of the frame.  flops = the bf16 MFMA flops the kernel issues: each fp32 product of the
-    reference's sgemm is three bf16 products of an exact hi/lo split, so 3 * 2*M*K*N, priced against the dense bf16 peak;
-    the fp32 flops of the reference's product (2*M*K*N) against the fp32 matrix peak are reported beside it.  The HBM side
-    (integral images read once, BEV map written once, records read once) is reported as `hbm_*`."""
-    flops = bytes_alg = 0.0
-    frames = 0  # the entry point may be called in two stages per frame ("rows": the pre-pass, "main": the rest): one "launch" = one frame
-    for (nv, L, W, hws, *stage), rec in g["by_tag"].items():
-        if stage and stage[0] == "rows":
-            continue
-        per = len(hws) * nv * L * W * 2.0 * 256 * 256
-        flops += rec["launches"] * per
+    covers every (view, scale, layer) of the frame (or of one band of grid rows).  `achieved` = the bf16 MFMA flops the
+    kernel ISSUES per launch / mean launch time: `products` bf16 products (3 of a two-piece split, 6 of a three-piece split)
+    per fp32 product of the reference's sgemm, over the LIVE 32-row items only (`live`: counted from the frame's
+    geometry -- fully masked (view, tile, layer, scale) items are skipped by the kernel), priced against the dense bf16 peak;
+    the reference's own fp32 flops (2*M*K*N over every row, masked ones included) against the fp32 matrix peak beside it.  The HBM
+    side (integral images read once, BEV map written once) is reported as `hbm_*`."""
+    ref_flops = bytes_alg = 0.0
+    frames = 0  # the serial kernel's entry point may be called in two stages per frame ("rows": the pre-pass, "main": the rest)
+    pipe = entry == "vfa_pipe_collapse_relu_sum_f32"
+    for tag, rec in g["by_tag"].items():
+        if pipe:
+            nv, L, W, nl, hws = tag
+        else:
+            (nv, L, W, hws, *stage), nl = tag, 1
+            if stage and stage[0] == "rows":
+                continue
+        ref_flops += rec["launches"] * len(hws) * nv * L * W * nl * 2.0 * 256 * 256
         frames += rec["launches"]
-        bytes_alg += rec["launches"] * (sum(nv * (h + 2) * (w + 2) * 256 * 4 for h, w in hws) + L * W * 256 * 4 +
-                                        L * W * 12 + nv * 48)
+        bytes_alg += rec["launches"] * (sum(nv * (h + 2) * (w + 2) * 256 * 4 for h, w in hws) + L * W * 256 * 4 + L * W * 12 + nv * 48)
     g = dict(g, launches=frames)
     avg_s = g["ms"] / g["launches"] * 1e-3
-    per_launch = flops / g["launches"]
-    achieved = 3 * per_launch / avg_s / 1e12
-    traffic, src = committed_traffic(workload, "pool_collapse_kernel<3, false, false>")
-    return {"bound": "mfma", "kernel": "vfa_pool_collapse_relu_sum_f32: pool_collapse_kernel<3, false, false> (persistent, one launch per "
-            "frame: box pooling of 7 views x 3 scales from LDS tap windows -> bf16-split MFMA collapse -> bias + ReLU + view/scale "
-            "sum); the HIP events bracket the call that launches it (+ the empty launch for direct items without a row slot, ~5 us). "
-            "Its pre-pass pool_rows_kernel (the 4 % of items whose window exceeds LDS, ~28 us) is a separate, untimed call of the "
-            "entry point when the geometry runs on a side stream (the default), and inside the timed call otherwise", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+    per_launch = ref_flops / g["launches"]
+    live_frac = (live[0] / live[1]) if live and live[1] else 1.0
+    issued = products * per_launch * live_frac
+    achieved = issued / avg_s / 1e12
+    kname = ("pipe_kernel<%d, false> (persistent; 8 matrix waves + 4 pooling waves per CU: box pooling from LDS tap windows beside "
+             "the bf16-split MFMA collapse of the previous 64 rows x 64 channels; accumulators of four views in registers across "
+             "all z-layers; bias + ReLU + view / scale sum)" % (6 if products == 6 else 3)) if pipe else \
+            ("pool_collapse_kernel<3, false, false> (persistent, one launch per frame: box pooling of all views x scales from LDS "
+             "tap windows -> bf16-split MFMA collapse -> bias + ReLU + view / scale sum); the HIP events bracket the call that "
+             "launches it (+ the empty launch for direct items without a row slot, ~5 us); its pre-pass pool_rows_kernel (the 4 % "
+             "of items whose window exceeds LDS, ~28 us) is a separate, untimed call of the entry point")
+    traffic, src = committed_traffic(workload, "pipe_kernel<3, false>" if pipe else "pool_collapse_kernel<3, false, false>")
+    if products == 6:
+        traffic, src = None, None
+    return {"bound": "mfma", "kernel": entry + ": " + kname, "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note(src),
-            "avg_launch_us": avg_s * 1e6, "mfma_flops_per_launch": 3 * per_launch,
+            "avg_launch_us": avg_s * 1e6, "mfma_flops_per_launch": issued,
+            "flops_note": f"{products} bf16 products per fp32 product ({pieces}-piece split) x the {live_frac:.3f} of the 32-row items "
+                          "that have a live box (the kernel skips the rest)",
             "fp32_flops_per_launch": per_launch, "fp32_equivalent_tflops": per_launch / avg_s / 1e12,
             "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": per_launch / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             "hbm_algorithmic_bytes_per_launch": bytes_alg / g["launches"],
@@ -311,13 +380,14 @@ def roofline_fused(g, workload):
             "launches": g["launches"]}
 
 
-def roofline_of(ks, ops, workload):
+def roofline_of(ks, ops, workload, live=None, products=3):
     """Roofline of the dominant kernel of the step.  Fused path: see `roofline_fused`.  Unfused paths: the pooling kernel
     (HBM-bound by SURVEY.md 8d): algorithmic bytes of one launch = integral images read once + voxel features written once
     + grid + calibs; achieved = those bytes / mean launch time from HIP events recorded on the launch stream inside the
     timed loop."""
-    if ks.get("vfa_pool_collapse_relu_sum_f32", {}).get("launches"):
-        return roofline_fused(ks["vfa_pool_collapse_relu_sum_f32"], workload)
+    for entry in ("vfa_pipe_collapse_relu_sum_f32", "vfa_pool_collapse_relu_sum_f32"):
+        if ks.get(entry, {}).get("launches"):
+            return roofline_fused(ks[entry], workload, entry, live, 3 if products == 6 else 2, products)
     entry = "vfa_pool_windows_f32" if ks.get("vfa_pool_windows_f32", {}).get("launches") else "vfa_project_gather_f32"
     g = ks.get(entry, dict(launches=0, ms=0.0, by_tag={}))
     if not g["launches"]:
@@ -370,7 +440,7 @@ def main():
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
 
     import vfa_amd
-    from vfa_amd import ops, vfa_op
+    from vfa_amd import _lib, ops, vfa_op
 
     torch.backends.cuda.matmul.allow_tf32 = False
     if a.tune_gemm:
@@ -398,12 +468,18 @@ def main():
     # (every 8th launch: 25 samples spread over the 200 default steps, 3 of a 20-step run.  A timed launch costs two event
     # records in the queue and, on the host, two event creations: in a short region, where the launching thread is barely
     # ahead of the GPU, a sample cost the step ~40 us; every launch of a long one ~1 %)
-    kt = ops.KernelTimer(only=ROOFLINE_ENTRY_POINTS, every=8 if a.steps >= 16 else 1)
-    dt = leg.timed(a.steps, kt, lead_in=conditioning)
+    # (a sampled launch costs two event records in the queue and two event creations on the host: every 4th launch, and the
+    # K-step block is repeated until >= 100 ms are timed, so also the driver's 20-step run collects >= 10 samples)
+    min_ms = 100.0 if a.steps > 0 else 0.0
+    kt = ops.KernelTimer(only=ROOFLINE_ENTRY_POINTS, every=4 if a.steps >= 8 else 1)
+    dt = leg.timed(a.steps, kt, lead_in=conditioning, min_ms=min_ms)
+    timing = leg.block_stats(a.steps)
     ks = kt.summary()
-    roofline = roofline_of(ks, ops, a.workload)
+    live = live_products(leg, ops, _lib)
+    roofline = roofline_of(ks, ops, a.workload, live)
     if roofline is not None:
-        roofline["sampled"] = f"HIP events around every {kt.every}th launch of the timed region" if kt.every > 1 else "HIP events around every launch of the timed region"
+        roofline["sampled"] = (f"HIP events around every {kt.every}th launch of the timed region ({roofline['launches']} samples over "
+                               f"{timing['blocks']} blocks of {a.steps} steps)")
     ks_all = kt_warm.summary() if a.warmup > 0 else ks
     def calls_per_frame(v):  # (the fused entry point is called twice per frame: "rows" pre-pass + the rest; count frames)
         rows = sum(r["launches"] for t, r in v["by_tag"].items() if isinstance(t, tuple) and t and t[-1] == "rows")
@@ -421,7 +497,7 @@ def main():
         rot.mods = leg.mods
         for _ in range(max(a.rotate, 3)):
             rot.step()
-        dtr = rot.timed(a.steps, lead_in=conditioning)
+        dtr = rot.timed(a.steps, lead_in=conditioning, min_ms=min_ms)
         extra["rotating_inputs"] = {"sets": a.rotate, "ms_per_step": 1e3 * dtr / a.steps,
                                     "value": rot.units_step * a.steps / dtr,
                                     "note": "the primary value re-reads the same lateral maps every step (what a frame "
@@ -436,11 +512,34 @@ def main():
         try:
             for _ in range(3):
                 leg.step()
-            dtf = leg.timed(a.fp32_steps, lead_in=conditioning // 3)
+            dtf = leg.timed(a.fp32_steps, lead_in=conditioning // 3, min_ms=min_ms)
         finally:
             vfa_op.COLLAPSE_KERNEL = saved
         extra["collapse_fp32_ms_per_step"] = 1e3 * dtf / a.fp32_steps
         extra["collapse_fp32_value"] = leg.units_step * a.fp32_steps / dtf
+    # ---- the pipelined kernel (vfa_pipe.hip) on this workload: as it is used on multi-layer grids (three products of a
+    # two-piece split), and with THREE bf16 pieces per operand / six products: the collapse product at the arithmetic width of
+    # the reference's fp32 nn.Linear (<= 5e-7 normwise against float64), fused like the default -- each with its own roofline
+    if a.fp32_steps > 0 and a.channels == 256 and len(leg.cams) > 0 and vfa_op.COLLAPSE_KERNEL != "library":
+        saved = (vfa_op.PIPE, vfa_op.PIPE_SINGLE_LAYER, vfa_op.COLLAPSE_TERMS)
+        try:
+            for key, terms in (("pipelined_kernel", 3), ("fused_fp32_equiv", 6)):
+                vfa_op.PIPE, vfa_op.PIPE_SINGLE_LAYER, vfa_op.COLLAPSE_TERMS = True, True, terms
+                if key == "pipelined_kernel" and roofline is not None and "vfa_pipe_" in roofline["kernel"]:
+                    continue  # (the primary leg already ran this kernel)
+                for _ in range(3):
+                    leg.step()
+                ktp = ops.KernelTimer(only=ROOFLINE_ENTRY_POINTS, every=4)
+                dtp = leg.timed(a.fp32_steps, ktp, lead_in=conditioning // 3, min_ms=min_ms)
+                rp = roofline_of(ktp.summary(), ops, a.workload, live, products=6 if terms == 6 else 3)
+                extra[key + "_ms_per_step"] = 1e3 * dtp / a.fp32_steps
+                extra[key] = {"ms_per_step": 1e3 * dtp / a.fp32_steps, "value": leg.units_step * a.fp32_steps / dtp,
+                              "timing": leg.block_stats(a.fp32_steps), "roofline": rp,
+                              "arithmetic": ("three bf16 pieces per operand (x = p0 + p1 + p2 to 2^-25), six MFMA products, fp32 accumulation: "
+                                             "1e-7 ... 3e-7 normwise against float64 (tests/test_pipe_frame.py), the class of an fp32 sgemm")
+                              if terms == 6 else "two bf16 pieces per operand, three MFMA products (the default arithmetic)"}
+        finally:
+            vfa_op.PIPE, vfa_op.PIPE_SINGLE_LAYER, vfa_op.COLLAPSE_TERMS = saved
     # ---- BASELINE.json configs[4]: synthetic 8 x 4K -> 512 x 512 x 32, cameras sharded over the ranks
     if a.c5_steps > 0 and a.workload == PRIMARY and a.channels == 256:
         c5 = Leg(C5, a, rank, world, dev, "strong")
@@ -455,10 +554,11 @@ def main():
         del c5
 
     ck = ks_all.get("vfa_collapse_relu_sum_f32")
-    fk = ks_all.get("vfa_pool_collapse_relu_sum_f32")
+    fk = ks_all.get("vfa_pool_collapse_relu_sum_f32") or ks_all.get("vfa_pipe_collapse_relu_sum_f32")
     if fk and fk["launches"]:
         us = 1e3 * fk["ms"] / fk["launches"]
-        collapse_info = {"flops_per_step": gemm_flops, "backend": "fused into vfa_pool_collapse_relu_sum_f32 (pooled rows go "
+        collapse_info = {"flops_per_step": gemm_flops, "backend": "fused into " + ("vfa_pool_collapse_relu_sum_f32" if "vfa_pool_collapse_relu_sum_f32" in ks_all
+                                                                    else "vfa_pipe_collapse_relu_sum_f32") + " (pooled rows go "
                          "from registers to LDS bf16 hi/lo planes to 3xbf16-split MFMA, fp32 accumulate; bias + ReLU + "
                          "view/scale sum in the epilogue; the voxel features never reach HBM)", "avg_us": us,
                          "fp32_equivalent_tflops": gemm_flops / (us * 1e-6) / 1e12,
@@ -486,12 +586,13 @@ def main():
             "metric": "voxels aggregated/sec (7 views->BEV grid)", "value": leg.units_step * a.steps / dt,
             "unit": "voxels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "lead_in_frames": conditioning,  # untimed frames queued in front of the opening barrier + synchronize (clock ramp of an idle device)
-            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / a.steps, "timing": timing, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 in / out and fp32 accumulation everywhere; pre-GEMM stages bit-exact with the reference's CPU path; the "
-                          "collapse product forms each fp32 product from three bf16 MFMA products of an exact hi/lo split "
-                          "(error ~3e-6 of max|out|, tolerance 1e-5); `collapse_fp32_ms_per_step` is the same step with the "
-                          "fp32 library GEMM",
+                          "collapse product forms each fp32 product from three bf16 MFMA products of a two-piece (16-bit) split of "
+                          "both operands (error ~3e-6 of max|out|, the path tolerates 1e-5); `fused_fp32_equiv` is the same fused "
+                          "step with a three-piece split / six products (sgemm-class, 1e-7 ... 3e-7 normwise), "
+                          "`collapse_fp32_ms_per_step` the unfused step with the fp32 library GEMM",
             "config": {"workload": a.workload, "cameras_per_rank": n,
                        "cameras_total": n * world if scaling == "weak" else leg.n_frame, "channels": C,
                        "feature_maps": [list(s) for s in leg.wl["feat_sizes"]], "grid": [L, W, nl],
