@@ -190,12 +190,15 @@ class Leg:
         self.overlap = world > 1 and os.environ.get("VFA_BENCH_SYNC_REDUCE", "0") != "1"
         self.pending = []
         self.k = 0
+        self.collective = True  # (False: the same steps without the collective: per-rank compute time)
 
     def step(self):
         torch, vfa_amd = self.torch, self.vfa_amd
         lats = self.sets[self.k % len(self.sets)]
         self.k += 1
         with torch.no_grad():
+            if not self.collective:
+                return vfa_amd.aggregate_views(*self.mods, *lats, self.calibs, self.grid, distributed=False)
             if not self.overlap:
                 return vfa_amd.aggregate_views(*self.mods, *lats, self.calibs, self.grid, distributed=self.world > 1)
             while self.pending:
@@ -540,6 +543,37 @@ def main():
                               if terms == 6 else "two bf16 pieces per operand, three MFMA products (the default arithmetic)"}
         finally:
             vfa_op.PIPE, vfa_op.PIPE_SINGLE_LAYER, vfa_op.COLLAPSE_TERMS = saved
+    # ---- N > 1: what the collective costs.  The same steps without it (slowest rank's compute), and the three ways of fusing the
+    # map timed alone on a map-sized tensor: all-reduce, reduce -> rank 0, reduce-scatter over BEV rows + 4-row halo
+    if world > 1 and a.steps > 0:
+        from vfa_amd.aggregate import all_reduce_ortho, reduce_ortho, reduce_scatter_ortho
+        leg.collective = False
+        dtc = leg.timed(a.steps, lead_in=conditioning // 3, min_ms=min_ms)
+        leg.collective = True
+        probe = torch.zeros((leg.L * leg.W, 256), dtype=torch.float32, device=dev)
+
+        def coll_ms(fn, reps=10):
+            for _ in range(3):
+                fn()
+            leg.fence()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            leg.fence()
+            t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return 1e3 * t.item()
+        extra["multi_gpu"] = {
+            "ms_compute": 1e3 * dtc / a.steps,
+            "ms_collective_exposed": 1e3 * (dt - dtc) / a.steps,
+            "map_bytes": probe.numel() * 4,
+            "collective_alone_ms": {"all_reduce": coll_ms(lambda: all_reduce_ortho(probe)),
+                                    "reduce_to_rank0": coll_ms(lambda: reduce_ortho(probe, 0)),
+                                    "reduce_scatter_rows_halo4": coll_ms(lambda: reduce_scatter_ortho(probe, leg.L, leg.W, halo=4))},
+            "note": "ms_compute: the same steps with the collective switched off (MAX over ranks); ms_collective_exposed = ms_per_step - "
+                    "ms_compute (the all-reduce of frame i runs beside the projection of frame i + 1); collective_alone_ms: one "
+                    "collective of the map at a time, nothing else on the GPUs"}
+        del probe
     # ---- BASELINE.json configs[4]: synthetic 8 x 4K -> 512 x 512 x 32, cameras sharded over the ranks
     if a.c5_steps > 0 and a.workload == PRIMARY and a.channels == 256:
         c5 = Leg(C5, a, rank, world, dev, "strong")

@@ -36,6 +36,9 @@ def test_bench_spawns_its_own_ranks_and_shards_cameras():
     assert line["config"]["cameras_total"] == 7 and line["config"]["cameras_per_rank"] == 4  # rank 0: cameras 0,2,4,6
     assert line["config"]["units_per_step"] == 7 * 3 * 200 * 200
     assert line["value"] > 0 and line["ms_per_step"] > 0
+    mg = line["multi_gpu"]  # what the collective costs: compute-only time of the slowest rank, and the three collectives alone
+    assert mg["ms_compute"] > 0 and mg["map_bytes"] == 200 * 200 * 256 * 4
+    assert set(mg["collective_alone_ms"]) == {"all_reduce", "reduce_to_rank0", "reduce_scatter_rows_halo4"}
 
 
 def test_bench_refuses_a_world_size_mismatch():
@@ -66,3 +69,10 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["one_thread_value"] > 0 and c["cpu"]
     assert line["collapse_fp32_ms_per_step"] > 0 and line["rotating_inputs"]["ms_per_step"] > 0
+    t = line["timing"]  # the K-step block is repeated until >= 100 ms are timed; the line carries the median block
+    assert t["blocks"] >= 1 and t["timed_ms_total"] >= 100.0 and t["ms_per_step_min"] <= line["ms_per_step"] <= t["ms_per_step_max"]
+    assert r["launches"] >= 10  # HIP-event samples of the roofline kernel
+    # the same fused step at the reference's arithmetic width (three bf16 pieces, six products), with its own roofline
+    f = line["fused_fp32_equiv"]
+    assert f["ms_per_step"] > 0 and f["roofline"]["bound"] == "mfma" and "pipe_kernel<6" in f["roofline"]["kernel"]
+    assert line["pipelined_kernel"]["roofline"]["frac"] > 0

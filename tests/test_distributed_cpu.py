@@ -104,3 +104,41 @@ def test_pending_ortho_async_all_reduce_world2(tmp_path):
     port = _free_port()
     mp.spawn(_async_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def _collective_worker(rank, world, port, out_dir, length, width):
+    """reduce -> rank 0 and reduce_scatter over BEV rows (+ halo) against the plain sum of the parts."""
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vfa_amd.aggregate import reduce_ortho, reduce_scatter_ortho, row_bands
+        C = 8
+        gen = torch.Generator().manual_seed(5)
+        parts = [torch.rand(length * width, C, generator=gen) for _ in range(world)]  # (every rank builds all parts: the expected sum)
+        want = torch.stack(parts).sum(0)
+        got = reduce_ortho(parts[rank].clone(), dst=0)
+        if rank == 0:
+            torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+        for halo in (0, 4):
+            band, (r0, r1), (top, bottom) = reduce_scatter_ortho(parts[rank].clone(), length, width, halo=halo)
+            bands, per = row_bands(length, world)
+            assert (r0, r1) == bands[rank]
+            assert top == (halo if rank > 0 and r1 > r0 else 0) and bottom == (halo if r1 < length and r1 > r0 else 0)
+            ref = want.view(length, width, C)[r0 - top:r1 + bottom].reshape(-1, C)
+            assert band.shape == ref.shape, (band.shape, ref.shape)
+            torch.testing.assert_close(band, ref, rtol=1e-6, atol=1e-6)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,length,width", [(2, 21, 6), (3, 16, 5)])
+def test_reduce_and_reduce_scatter_with_halo(world, length, width, tmp_path):
+    """The two alternatives to the all-reduce SURVEY section 8e names: `reduce` to the rank that runs the heads, and
+    `reduce_scatter` over bands of BEV rows with the 4-row halo of the heads' dilated convolutions
+    (reference vfa/model/vfanet.py:48, :52); ragged row counts (zero-padded shares)."""
+    port = _free_port()
+    mp.spawn(_collective_worker, args=(world, port, str(tmp_path), length, width), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]

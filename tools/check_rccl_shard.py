@@ -29,11 +29,20 @@ def main():
         mine = torch.tensor(vfa_amd.camera_shard(n), dtype=torch.long, device=dev)
         part = vfa_amd.aggregate_views(*mods, *(l[mine] for l in lats), calibs[mine], grid, distributed=True)
         pend = vfa_amd.aggregate_views(*mods, *(l[mine] for l in lats), calibs[mine], grid, distributed="async").wait()
+        red = vfa_amd.aggregate_views(*mods, *(l[mine] for l in lats), calibs[mine], grid, distributed="reduce")
+        band, (r0, r1), (top, bottom) = vfa_amd.aggregate_views(*mods, *(l[mine] for l in lats), calibs[mine], grid,
+                                                                 distributed="reduce_scatter")
     torch.cuda.synchronize()
     scale = full.abs().max().item()
     for name, got in (("sync", part), ("async", pend)):
         err = (got - full).abs().max().item()
         assert err <= 2e-5 * scale, (name, err, scale)
+    if rank == 0:  # reduce: the fused map on rank 0
+        assert (red - full).abs().max().item() <= 2e-5 * scale
+    # reduce_scatter: this rank's band of BEV rows + the 4-row halo of the heads
+    want = full[:, :, r0 - top:r1 + bottom]
+    assert band.shape == want.shape, (band.shape, want.shape)
+    assert (band - want).abs().max().item() <= 2e-5 * scale
     dist.barrier()
     if rank == 0:
         print(f"rccl shard ok: world {world}, max |ortho| {scale:.3f}")

@@ -118,6 +118,73 @@ def all_reduce_ortho(ortho_nhwc, group=None):
     return ortho_nhwc
 
 
+def reduce_ortho(ortho_nhwc, dst=0, group=None):
+    """Sum the partial BEV maps onto rank ``dst`` only (the BEV heads then run on one rank): half the traffic of an
+    all-reduce.  Other ranks get their buffer back with unspecified contents.  Returns the tensor."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(ortho_nhwc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return ortho_nhwc
+
+
+def row_bands(length, world):
+    """BEV rows of every rank for the scattered map: ``world`` bands of equal height (the last ones may be shorter / empty)."""
+    per = (length + world - 1) // world
+    return [(min(length, r * per), min(length, (r + 1) * per)) for r in range(world)], per
+
+
+def reduce_scatter_ortho(ortho_nhwc, length, width, halo=0, group=None):
+    """Sum the partial maps and leave every rank with ONE band of BEV rows (+ ``halo`` rows of its neighbours on either side):
+    the BEV heads are convolutions with a receptive field of a few rows (dilation 4: reference vfa/model/vfanet.py:48, :52), so
+    each rank can run them on its band and only the small head outputs are gathered -- a reduce-scatter moves (p - 1) / p of the
+    map once instead of the all-reduce's twice.
+
+    ortho_nhwc (L*W, C) partial map of this rank.  Returns ``(band, (row0, row1), (top, bottom))``: band ((row1 - row0 + top +
+    bottom) * W, C) holds rows [row0 - top, row1 + bottom) of the fused map; top / bottom <= halo are the halo rows that exist
+    (none beyond the map's edges).  Without a process group the whole map is the band."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return ortho_nhwc, (0, length), (0, 0)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bands, per = row_bands(length, world)
+    c = ortho_nhwc.shape[1]
+    padded = ortho_nhwc
+    if per * world != length:  # reduce_scatter_tensor wants equal shares: pad the map with zero rows
+        padded = ortho_nhwc.new_zeros((per * world * width, c))
+        padded[:length * width] = ortho_nhwc
+    mine = ortho_nhwc.new_empty((per * width, c))
+    if dist.get_backend(group) == "gloo":  # (CPU tests: gloo has no reduce-scatter; same result through an all-reduce)
+        full = padded.clone()
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+        mine.copy_(full[rank * per * width:(rank + 1) * per * width])
+    else:
+        dist.reduce_scatter_tensor(mine, padded, op=dist.ReduceOp.SUM, group=group)
+    r0, r1 = bands[rank]
+    mine = mine[:(r1 - r0) * width]
+    if halo <= 0:
+        return mine, (r0, r1), (0, 0)
+    # halo exchange: every rank publishes its first and last `halo` rows (a few hundred KB), neighbours pick theirs.
+    # (bands shorter than the halo would need rows from two ranks away: refuse instead of returning a wrong halo)
+    assert all(b1 - b0 >= halo or b1 == b0 for b0, b1 in bands), "reduce_scatter_ortho: bands shorter than the halo"
+    edge = ortho_nhwc.new_zeros((2, halo * width, c))
+    h = min(halo, r1 - r0)
+    if h > 0:
+        edge[0, :h * width] = mine[:h * width]
+        edge[1, (halo - h) * width:] = mine[(r1 - r0 - h) * width:]
+    edges = [torch.empty_like(edge) for _ in range(world)]
+    dist.all_gather(edges, edge, group=group)
+    top = halo if (rank > 0 and r0 > 0 and r1 > r0) else 0
+    nxt = next((q for q in range(rank + 1, world) if bands[q][1] > bands[q][0]), None)
+    bottom = halo if (nxt is not None and r1 > r0) else 0
+    prv = next((q for q in range(rank - 1, -1, -1) if bands[q][1] > bands[q][0]), None)
+    parts = []
+    if top:
+        parts.append(edges[prv][1])
+    parts.append(mine)
+    if bottom:
+        parts.append(edges[nxt][0])
+    band = torch.cat(parts) if len(parts) > 1 else mine
+    return band, (r0, r1), (top, bottom)
+
+
 class PendingOrtho:
     """A fused BEV map whose all-reduce is still in flight (``aggregate_views(..., distributed="async")``).
 
@@ -144,7 +211,9 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     -> ortho (1,C,L,W): a permuted view of the channels-last buffer, like the reference returns.
     With ``distributed=True`` the partial sums of all ranks are all-reduced before returning; with
     ``distributed="async"`` (inference) the all-reduce is only launched and a ``PendingOrtho`` is returned, so that
-    the collective of frame i overlaps the projection of frame i+1.
+    the collective of frame i overlaps the projection of frame i+1.  ``distributed="reduce"``: the fused map lands on rank 0
+    only; ``distributed="reduce_scatter"``: every rank gets its band of BEV rows plus the 4-row halo of the heads' dilated
+    convolutions and the call returns ``(band (1,C,rows,W), (row0, row1), (top, bottom))`` (``reduce_scatter_ortho``).
     ``integrals``: the three integral-image batches instead of the lateral maps (producer fusion, inference on the fused frame
     path only; ``lat*`` may then be None).
     """
@@ -209,6 +278,12 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(reduce_group) > 1:
             work = dist.all_reduce(ortho, op=dist.ReduceOp.SUM, group=reduce_group, async_op=True)
         return PendingOrtho(ortho, work, (length, width, c_out))
-    if distributed:
+    if distributed == "reduce":  # the fused map on rank 0 only (the caller runs the heads there)
+        ortho = reduce_ortho(ortho, 0, reduce_group)
+    elif distributed == "reduce_scatter":  # this rank's band of BEV rows + the heads' 4-row halo: (band (1,C,rows,W), rows, halo)
+        band, rows, halo = reduce_scatter_ortho(ortho, length, width, halo=4, group=reduce_group)
+        n_rows = rows[1] - rows[0] + halo[0] + halo[1]
+        return band.view(1, n_rows, width, c_out).permute(0, 3, 1, 2), rows, halo
+    elif distributed:
         ortho = all_reduce_ortho(ortho, reduce_group)
     return ortho.view(1, length, width, c_out).permute(0, 3, 1, 2)
