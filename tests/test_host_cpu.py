@@ -25,10 +25,13 @@ def test_vfanet_builds_with_the_reference_default_arguments(tmp_path, monkeypatc
     from vfa_amd.vfanet import PRETRAINED_ENV, VFANet
     monkeypatch.setenv("TORCH_HOME", str(tmp_path / "empty_home"))
     monkeypatch.delenv(PRETRAINED_ENV, raising=False)
+    with pytest.raises(FileNotFoundError, match="VFA_AMD_PRETRAINED"):  # no network, no local file: loud, not a silent random start
+        VFANet(_args(), grid_height=160, cube_size=(25, 25, 32), angle_range=360, mode="3D", pretrained=True)
+    monkeypatch.setenv(PRETRAINED_ENV, "none")  # ... unless random initialisation is asked for by name
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         net = VFANet(_args(), grid_height=160, cube_size=(25, 25, 32), angle_range=360, mode="3D", pretrained=True)
-    assert any("pretrained" in str(x.message) for x in w)  # no network: says so and goes on, like a cache miss would not
+    assert any("random" in str(x.message) for x in w)
     assert net.vfa8.collapse.weight.shape == (256, 1280)
     # a local checkpoint is loaded by key intersection like the reference's _load_pretrained (resnet.py:170-175)
     ref = {k: torch.full_like(v, 0.5) for k, v in net.base.state_dict().items() if k.startswith("layer1.0")}

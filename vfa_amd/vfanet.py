@@ -47,19 +47,24 @@ def _find_pretrained(base):
 def load_pretrained_trunk(trunk, base):
     """Reference ``_load_pretrained`` (resnet.py:170-175): copy every checkpoint entry whose key exists in the trunk
     (conv weights and the affine parameters the GroupNorm layers share with torchvision's BatchNorm by NAME; running
-    statistics have no counterpart).  Returns the number of tensors loaded; warns and keeps the random initialisation
-    when no local checkpoint is found."""
+    statistics have no counterpart).  Returns the number of tensors loaded.  The reference downloads the checkpoint; a box
+    without network cannot, and training from scratch where ImageNet weights were asked for must not happen silently: without
+    a local checkpoint this RAISES, unless random initialisation is chosen explicitly with ``VFA_AMD_PRETRAINED=none``."""
+    if os.environ.get(PRETRAINED_ENV, "").strip().lower() == "none":
+        warnings.warn(f"VFANet(pretrained=True) with {PRETRAINED_ENV}=none: the trunk keeps its random initialisation")
+        return 0
     path = _find_pretrained(base)
     if path is None:
-        warnings.warn(f"VFANet(pretrained=True): no local {base} ImageNet checkpoint (set {PRETRAINED_ENV} to the .pth "
-                      "file or its directory, or place it in the torch hub cache); continuing from random "
-                      "initialisation -- this box has no network to download it like the reference does")
-        return 0
+        raise FileNotFoundError(
+            f"VFANet(pretrained=True): no local {base} ImageNet checkpoint and no network to download it like the reference "
+            f"does (resnet.py:159).  Set {PRETRAINED_ENV} to the .pth file or its directory, or place it in the torch hub cache; "
+            f"{PRETRAINED_ENV}=none starts from random weights on purpose")
     ckpt = torch.load(path, map_location="cpu")
     own = trunk.state_dict()
     hit = {k: v for k, v in ckpt.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
     own.update(hit)
     trunk.load_state_dict(own)
+    print(f"VFANet: loaded {len(hit)} of {len(own)} trunk tensors from {path}")
     return len(hit)
 
 
