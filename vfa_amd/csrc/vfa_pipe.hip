@@ -695,7 +695,8 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         };
 
         // ---------------------------------------------------------------- pooling of one step (pooling waves)
-        auto unpack = [&](LaneBox &bx, bool &glob, unsigned wp, int j, bool direct) {
+        // returns false when none of the wave's 16 boxes has anything to pool (all masked, none NaN): the wave then writes zeros
+        auto unpack = [&](LaneBox &bx, bool &glob, unsigned wp, int j, bool direct) -> bool {
             const uint4 *rp = reinterpret_cast<const uint4 *>(s_rec + j * kTileBoxes * kRecBytes) + ((pw & 1) * 16 + pb) * (kRecBytes / 16);
             uint4 rv[6];
 #pragma unroll
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                     const unsigned pos = direct ? rw[i] * wp + cl[k] : rw[i] + cl[k]; // pixel of the padded image / slot of the window
                     bx.tb[4 * i + k] = (vis ? pos : 0u) * (direct ? (unsigned)kSlotBytes : (unsigned)kQSlot) + (unsigned)(pi * 16);
                 }
+            return __ballot(vis || bx.scl != bx.scl) != 0ull;
         };
         // the wave's 16 boxes x the 64 channels of quarter q: lane (box pb, piece pi) takes the 16-byte pieces
         // ((pb + m) & 3) * 4 + pi, m = 0..3, of its taps' quarter slots -- the four boxes of an LDS cycle read different 64-byte
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                     const uint4 d1 = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0])[1];
                     const int fw = uniform_i((int)d1.x);
                     live = (fw & kTileLive) != 0;
-                    if (live) unpack(bx, glob, d1.w, j, (fw & kTileDirect) != 0);
+                    if (live) live = unpack(bx, glob, d1.w, j, (fw & kTileDirect) != 0);
                 }
                 if (!live) { // no live box in this layer (or no such sub-tile in the group): the matrix waves multiply zeros
                     const int row = x * 32 + (pw & 1) * 16 + pb;
