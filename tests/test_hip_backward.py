@@ -175,9 +175,14 @@ def test_vfanet_trains_end_to_end():
     target = torch.rand(1, 1, grid.shape[1], grid.shape[2], device=dev)
     opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)
     losses = []
-    for _ in range(6):
+    for it in range(6):
         opt.zero_grad()
-        out = net(images, calibs, grid)
+        with vfa_amd.ops.KernelTimer() as kt:
+            out = net(images, calibs, grid)
+        if it == 0:
+            torch.cuda.synchronize()  # the training forward runs the fused per-frame kernel (2 layers here: the pipelined one), not the vox-through-HBM path
+            ran = set(kt.summary())
+            assert "vfa_pipe_collapse_relu_sum_f32" in ran and "vfa_project_gather_f32" not in ran, sorted(ran)
         loss = ((out["heatmap"] - target) ** 2).mean() + 1e-3 * out["loc_offset"].pow(2).mean()
         loss.backward()
         opt.step()
@@ -187,3 +192,77 @@ def test_vfanet_trains_end_to_end():
     for name in ("base.conv1.weight", "lat8.weight", "vfa8.collapse.weight", "vfa32.collapse.bias", "map_classifier.0.weight"):
         g = dict(net.named_parameters())[name].grad
         assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0, name
+
+
+@pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 3, (24, 40)), ("multiviewc_156x156x5", 2, (16, 24))])
+def test_fused_training_forward_gives_the_gradients_of_the_unfused_path(name, n_cam, crop, monkeypatch):
+    """`_FusedFrameTrain`: fused kernel in the forward, voxel features and pre-activations recomputed in the backward -- against
+    the unfused autograd path (vox and lin saved by autograd) on the same inputs: same map, same gradients of the lateral maps,
+    `collapse.weight` and `collapse.bias` (reference trainer.py:26, 41 trains through exactly these)."""
+    import vfa_amd
+    from vfa_amd import ops, vfa_op
+    from vfa_amd.synthetic import make_workload
+    dev = torch.device("cuda:0")
+    wl = make_workload(name, channels=256, seed=2, n_cam=n_cam)
+    grid = wl["grid"][:, 40:40 + crop[0], 50:50 + crop[1]].contiguous().to(dev)
+    torch.manual_seed(4)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
+    with torch.no_grad():
+        for m in mods:
+            m.collapse.weight.mul_(3.0)
+            m.collapse.bias.uniform_(-0.3, 0.1)
+    calibs = wl["calibs"].to(dev)
+    probe = torch.randn(1, 256, crop[0], crop[1], device=dev)
+    # Integer-valued features: their integral images and box sums are exact in fp32, so the two fp32 paths see the same voxel
+    # features bit for bit whatever the order of their sums.
+    feats = [torch.round(2 * torch.cat([wl["features"][c][s] for c in range(n_cam)])) for s in range(3)]
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(vfa_op, "FUSED_TRAIN", fused)
+        lats = [feats[s].to(dev).requires_grad_(True) for s in range(3)]
+        for m in mods:
+            m.zero_grad()
+        with ops.KernelTimer() as kt:
+            out = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        torch.cuda.synchronize()
+        ran = set(kt.summary())
+        assert (("vfa_pipe_collapse_relu_sum_f32" in ran or "vfa_pool_collapse_relu_sum_f32" in ran) and "vfa_project_gather_f32" not in ran) == fused, sorted(ran)
+        (out * probe).sum().backward()
+        res[fused] = (out.detach().clone(), [l.grad.clone() for l in lats], [m.collapse.weight.grad.clone() for m in mods],
+                      [m.collapse.bias.grad.clone() for m in mods])
+    (o1, gl1, gw1, gb1), (o0, gl0, gw0, gb0) = res[True], res[False]
+
+    # float64 autograd of the same aggregate
+    l64 = [feats[s].double().requires_grad_(True) for s in range(3)]
+    w64 = [m.collapse.weight.detach().cpu().double().requires_grad_(True) for m in mods]
+    b64 = [m.collapse.bias.detach().cpu().double().requires_grad_(True) for m in mods]
+    zl = mods[0].z_corners[:, 0, 0, 2].cpu().double()
+    co = mods[0].corners_offset.cpu().double().reshape(8, 3)
+    want = 0
+    for c in range(n_cam):
+        for k in range(3):
+            want = want + ref.vfa_forward(l64[k][[c]], wl["calibs"][c].double(), grid.cpu().double()[0], w64[k], b64[k], zl, co,
+                                          wl["args"].data, wl["args"].image_size)
+    (want * probe.cpu().double()).sum().backward()
+
+    errs = []
+
+    def close(a, b, what, tol):
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        scale = b.abs().max().item()
+        assert scale > 0, what
+        err = (a - b).abs().max().item() / scale
+        errs.append((what, err, tol))
+    close(o1, o0, "map", 2e-4)
+    close(o1, want, "map vs float64", 2e-4)
+    for k in range(3):
+        close(gl1[k], gl0[k], f"d lat{k}", 2e-3)     # (fp32 atomics in a different order under the two suffix sums)
+        close(gw1[k], gw0[k], f"d weight{k}", 2e-4)  # (a pre-activation within ~1e-6 of zero may take the other side of the ReLU)
+        close(gb1[k], gb0[k], f"d bias{k}", 2e-4)
+        # float64 autograd computes the box corners in float64: a few corners land on the other side of a pixel boundary
+        # (map: 1e-4 of the maximum), a few pre-activations on the other side of zero, and sums of random-sign terms move by
+        # 1-5 % of their maximum -- for BOTH fp32 paths alike (measured).  A guard against gross errors (layouts, scales) only.
+        close(gl1[k], l64[k].grad, f"d lat{k} vs float64", 0.1)
+        close(gw1[k], w64[k].grad, f"d weight{k} vs float64", 0.1)
+        close(gb1[k], b64[k].grad, f"d bias{k} vs float64", 0.1)
+    assert all(e <= t for _, e, t in errs), [x for x in errs if x[1] > x[2]]

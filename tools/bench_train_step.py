@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Forward + backward of the aggregate (training path: unfused kernels, atomics-based backward) on one workload."""
+"""Forward + backward of the aggregate on one workload, both training paths: fused forward + recomputing backward
+(`vfa_op.FUSED_TRAIN`, the default) and the unfused kernels with vox / lin saved by autograd."""
 import argparse
 import os
 import sys
@@ -30,15 +31,23 @@ def step():
     out.sum().backward()
 
 
-for _ in range(2):
-    step()
-torch.cuda.synchronize()
-with ops.KernelTimer() as kt:
+from vfa_amd import vfa_op  # noqa: E402
+
+for fused in (True, False):
+    vfa_op.FUSED_TRAIN = fused
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-print(f"forward+backward {dt * 1e3:.2f} ms/step")
-for k, v in kt.summary().items():
-    print(f"  {k}: {v['launches'] // a.steps} launches/step, {v['ms'] / a.steps:.3f} ms/step")
+    with ops.KernelTimer() as kt:
+        step()
+        torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 1e9
+    torch.cuda.reset_peak_memory_stats()
+    print(f"{a.workload} {'fused forward + recomputing backward' if fused else 'unfused (vox, lin saved)'}: forward+backward {dt * 1e3:.2f} ms/step, peak memory {peak:.2f} GB")
+    for k, v in kt.summary().items():
+        print(f"  {k}: {v['launches']} launches/step, {v['ms']:.3f} ms/step")

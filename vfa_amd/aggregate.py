@@ -230,6 +230,9 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
         ortho = torch.empty((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
         frame = vfa_op.pipe_frame if vfa_op.pipe_frame_ok(mods3, n) else vfa_op.fused_frame
         frame(mods3, None, calibs, grid, crange, out=ortho, reserved_cus=reserved, integrals=list(integrals))
+    elif n > 0 and vfa_op.fused_train_ok(mods3, n, (lat8, lat16, lat32)):
+        # training: the fused kernel in the forward, voxel features and pre-activations recomputed scale by scale in the backward
+        ortho = vfa_op.fused_frame_train(mods3, [lat8, lat16, lat32], calibs, grid, crange, reserved_cus=reserved)
     elif n > 0 and vfa_op.pipe_frame_ok(mods3, n, (lat8, lat16, lat32)):
         # inference, any number of z-layers: geometry once per frame + ONE persistent kernel (pooling waves beside matrix waves)
         ortho = torch.empty((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)

@@ -278,6 +278,121 @@ def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumu
     return out
 
 
+# Training: "1" (default) = the forward of a frame is the fused per-frame kernel (no voxel features, no pre-activations kept);
+# the backward recomputes them scale by scale from the lateral maps.  "0" = the unfused kernels with `vox` / `lin` saved by autograd.
+FUSED_TRAIN = os.environ.get("VFA_AMD_FUSED_TRAIN", "1") == "1"
+
+
+def _frame_kernels_cover(mods, n_views):
+    """Module set / camera count the fused per-frame kernels cover (gradients or not)."""
+    m0 = mods[0]
+    return (COLLAPSE_KERNEL != "library" and 1 <= len(mods) <= 3 and 0 < n_views <= 32
+            and all(m.channel == 256 and m.collapse.out_features == 256 and m.num_grid_layer == m0.num_grid_layer
+                    and m.geometry_key == m0.geometry_key and getattr(m.args, "data", None) == getattr(m0.args, "data", None)
+                    and tuple(m.args.image_size) == tuple(m0.args.image_size) for m in mods))
+
+
+class _FusedFrameTrain(torch.autograd.Function):
+    """The whole frame as ONE autograd node (reference: the camera loop vfanet.py:64-82 around VFA.forward vfa_op.py:61-125,
+    trained through by trainer.py:26, 41).
+
+    forward: the fused per-frame kernel (``pipe_frame`` for any layer count, ``fused_frame`` on single-layer grids): the voxel
+    features never reach HBM and nothing but the INPUTS is kept for the backward.  backward: per scale, in cell chunks, the
+    voxel features are pooled again (bit-identical to what the forward pooled), ``lin = vox . W^T`` is formed again (the ReLU
+    mask), then the usual gradients: d lin = d out * (lin + b > 0), d W += d lin^T . vox, d b, d vox = d lin . W, scattered
+    back through the box pooling (``vfa_project_gather_backward_f32``) and the two cumsums.  Gradients are those of the
+    unfused path up to the rounding of the recomputed product (fp32 library GEMM here, bf16-split MFMA in the forward: a
+    pre-activation within ~1e-6 of zero may take the other side of the ReLU)."""
+
+    @staticmethod
+    def forward(ctx, calibs, grid, crange, meta, reserved_cus, *tensors):
+        mods = meta
+        ns = len(mods)
+        lats, weights, biases = tensors[:ns], tensors[ns:2 * ns], tensors[2 * ns:3 * ns]
+        n = calibs.shape[0]
+        with torch.no_grad():
+            if pipe_frame_ok(mods, n):
+                out = pipe_frame(mods, [l.detach() for l in lats], calibs, grid, crange, reserved_cus=reserved_cus)
+            else:
+                out = fused_frame(mods, [l.detach() for l in lats], calibs, grid, crange, reserved_cus=reserved_cus)
+        ctx.save_for_backward(calibs, grid, *lats, *weights, *biases)
+        ctx.meta = (mods, tuple(float(c) for c in crange))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        mods, crange = ctx.meta
+        ns = len(mods)
+        calibs, grid = ctx.saved_tensors[:2]
+        lats = ctx.saved_tensors[2:2 + ns]
+        weights = ctx.saved_tensors[2 + ns:2 + 2 * ns]
+        biases = ctx.saved_tensors[2 + 2 * ns:2 + 3 * ns]
+        m0 = mods[0]
+        conv_kind = _conv_kind(m0.args)
+        img_h, img_w = (float(v) for v in m0.args.image_size)
+        n = calibs.shape[0]
+        dev = grad_out.device
+        grid_flat = grid.reshape(-1, 3).to(dtype=torch.float32).contiguous()
+        cal = calibs.reshape(n, 12).to(dtype=torch.float32).contiguous()
+        z_layers, corner_off = m0._kernel_geometry(dev)
+        n_cells, nl, C = grid_flat.shape[0], m0.num_grid_layer, 256
+        grad_out = grad_out.contiguous()
+        g_lats, g_ws, g_bs = [], [], []
+        with torch.no_grad():
+            for k, (m, lat, w, b) in enumerate(zip(mods, lats, weights, biases)):
+                need_lat, need_w, need_b = ctx.needs_input_grad[5 + k], ctx.needs_input_grad[5 + ns + k], ctx.needs_input_grad[5 + 2 * ns + k]
+                if not (need_lat or need_w or need_b):
+                    g_lats.append(None), g_ws.append(None), g_bs.append(None)
+                    continue
+                integral = ops.integral_image(lat)
+                w_lm = w.view(C, C, nl).permute(0, 2, 1).reshape(C, nl * C).contiguous()  # column layer * C + c, like the pooled rows
+                g_int = torch.zeros_like(integral) if need_lat else None
+                g_w_lm = torch.zeros_like(w_lm) if need_w else None
+                g_b = torch.zeros_like(b) if need_b else None
+                per_cell = n * nl * C * 4 * 2  # vox and d vox
+                chunk = max(1, min(n_cells, VOX_BYTES_LIMIT // max(per_cell, 1)))
+                for begin in range(0, n_cells, chunk):
+                    count = min(chunk, n_cells - begin)
+                    vox = ops.project_gather(integral, cal, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h), crange,
+                                             cell_begin=begin, cell_count=count)
+                    lin = torch.matmul(vox.view(n * count, nl * C), w_lm.t()).view(n, count, C)
+                    g_lin, g_b_part = ops.relu_mask_backward(grad_out[begin:begin + count], lin, b)
+                    del lin
+                    if need_b:
+                        g_b += g_b_part
+                    g2 = g_lin.view(n * count, C)
+                    if need_w:
+                        g_w_lm.addmm_(g2.t(), vox.view(n * count, nl * C))
+                    if need_lat:
+                        g_vox = torch.matmul(g2, w_lm).view(n, count, nl * C)
+                        ops.project_gather_backward(g_vox, tuple(integral.shape), cal, grid_flat, z_layers, corner_off, conv_kind,
+                                                    (img_w, img_h), crange, cell_begin=begin, cell_count=count, out=g_int,
+                                                    accumulate=True)
+                        del g_vox
+                    del vox, g_lin
+                g_lats.append(ops.integral_image_backward(g_int) if need_lat else None)
+                g_ws.append(g_w_lm.view(C, nl, C).permute(0, 2, 1).reshape(C, C * nl) if need_w else None)
+                g_bs.append(g_b)
+        return (None, None, None, None, None, *g_lats, *g_ws, *g_bs)
+
+
+def fused_frame_train(mods, features, calibs, grid, crange=(-1, 0.95), reserved_cus=0):
+    """``sum_scale sum_view relu(collapse_scale(vox))`` as (L*W, 256) WITH autograd: fused forward, recomputing backward
+    (``_FusedFrameTrain``).  Needs ``_frame_kernels_cover`` and, on single-layer grids, nothing else; see ``FUSED_TRAIN``."""
+    tensors = list(features) + [m.collapse.weight for m in mods] + [m.collapse.bias for m in mods]
+    return _FusedFrameTrain.apply(calibs, grid, tuple(crange), tuple(mods), reserved_cus, *tensors)
+
+
+def fused_train_ok(mods, n_views, features):
+    """Gradients are wanted and the fused per-frame kernels cover the forward."""
+    if not (FUSED_TRAIN and torch.is_grad_enabled() and _frame_kernels_cover(mods, n_views)):
+        return False
+    if not (PIPE or (mods[0].num_grid_layer == 1 and FUSED_POOL)):
+        return False
+    tensors = [p for m in mods for p in (m.collapse.weight, m.collapse.bias)] + [f for f in features if f is not None]
+    return any(t.requires_grad for t in tensors)
+
+
 def window_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumulate=False, reserved_cus=0):
     """Same contract as ``fused_frame``, as separate kernels per scale: geometry once per frame (``ops.frame_records``), then
     per scale the integral images, the LDS-window pooling kernel (``ops.pool_windows``: voxel features in HBM, bit-exact) and
@@ -473,7 +588,9 @@ class VFA(nn.Module):
         length, width = grid.shape[-3], grid.shape[-2]
         if visualize:
             self.visualize_cube(feature, calib, grid, crange)
-        if self.mfma_collapse_ok(feature) or (grid.dim() >= 3 and pipe_frame_ok([self], 1, (feature,))):
+        if grid.dim() >= 3 and fused_train_ok([self], 1, (feature,)):
+            ortho = fused_frame_train([self], [feature], calib.reshape(1, 3, 4), grid, crange)
+        elif self.mfma_collapse_ok(feature) or (grid.dim() >= 3 and pipe_frame_ok([self], 1, (feature,))):
             ortho = self.project_sum(feature, calib.reshape(1, 3, 4), grid, crange)
         else:
             lin = self.project_views(feature, calib.reshape(1, 3, 4), grid, crange)
