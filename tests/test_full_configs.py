@@ -48,10 +48,15 @@ def test_full_size_frame_vs_oracle_windows(oracle, name, win):
     lats = [torch.cat([wl["features"][c][s] for c in range(n)]).to(dev) for s in range(3)]
     calibs, grid = wl["calibs"].to(dev), wl["grid"].to(dev)
     L, W = grid.shape[1:3]
-    with torch.no_grad():
+    with torch.no_grad(), ops.KernelTimer() as kt:
         ortho = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
     torch.cuda.synchronize()
     assert tuple(ortho.shape) == (1, C, L, W) and torch.isfinite(ortho).all()
+    # the product path of every BASELINE config is ONE fused kernel per frame (band): the serial one on single-layer grids, the
+    # pipelined one (groups of views, accumulators in registers over the layers) for K = nl * 256; voxel features never in HBM
+    ran = set(kt.summary())
+    assert ("vfa_pool_collapse_relu_sum_f32" if nl == 1 else "vfa_pipe_collapse_relu_sum_f32") in ran, sorted(ran)
+    assert not ran & {"vfa_project_gather_f32", "vfa_collapse_gemm_f32", "vfa_pool_windows_f32"}, sorted(ran)
     got_map = ortho[0].permute(1, 2, 0).reshape(L * W, C)
 
     n_cells = L * W

@@ -298,11 +298,11 @@ class _FusedFrameTrain(torch.autograd.Function):
 
     forward: the fused per-frame kernel (``pipe_frame`` for any layer count, ``fused_frame`` on single-layer grids): the voxel
     features never reach HBM and nothing but the INPUTS is kept for the backward.  backward: per scale, in cell chunks, the
-    voxel features are pooled again (bit-identical to what the forward pooled), ``lin = vox . W^T`` is formed again (the ReLU
-    mask), then the usual gradients: d lin = d out * (lin + b > 0), d W += d lin^T . vox, d b, d vox = d lin . W, scattered
-    back through the box pooling (``vfa_project_gather_backward_f32``) and the two cumsums.  Gradients are those of the
-    unfused path up to the rounding of the recomputed product (fp32 library GEMM here, bf16-split MFMA in the forward: a
-    pre-activation within ~1e-6 of zero may take the other side of the ReLU)."""
+    voxel features are pooled again from the kept integral images (bit-identical to what the forward pooled), ``lin = vox . W^T``
+    is formed again with the MFMA tile GEMM (the ReLU mask), then the usual gradients: d lin = d out * (lin + b > 0),
+    d W += d lin^T . vox, d b, d vox = d lin . W, scattered back through the box pooling
+    (``vfa_project_gather_backward_f32``) and the two cumsums.  Gradients are those of the unfused path up to the summation
+    order of the recomputed product (a pre-activation within ~1e-6 of zero may take the other side of the ReLU)."""
 
     @staticmethod
     def forward(ctx, calibs, grid, crange, meta, reserved_cus, *tensors):
@@ -311,11 +311,10 @@ class _FusedFrameTrain(torch.autograd.Function):
         lats, weights, biases = tensors[:ns], tensors[ns:2 * ns], tensors[2 * ns:3 * ns]
         n = calibs.shape[0]
         with torch.no_grad():
-            if pipe_frame_ok(mods, n):
-                out = pipe_frame(mods, [l.detach() for l in lats], calibs, grid, crange, reserved_cus=reserved_cus)
-            else:
-                out = fused_frame(mods, [l.detach() for l in lats], calibs, grid, crange, reserved_cus=reserved_cus)
-        ctx.save_for_backward(calibs, grid, *lats, *weights, *biases)
+            integrals = ops.integral_images([l.detach() for l in lats])  # kept: the backward pools from them again
+            frame = pipe_frame if pipe_frame_ok(mods, n) else fused_frame
+            out = frame(mods, None, calibs, grid, crange, reserved_cus=reserved_cus, integrals=integrals)
+        ctx.save_for_backward(calibs, grid, *integrals, *weights, *biases)
         ctx.meta = (mods, tuple(float(c) for c in crange))
         return out
 
@@ -324,7 +323,7 @@ class _FusedFrameTrain(torch.autograd.Function):
         mods, crange = ctx.meta
         ns = len(mods)
         calibs, grid = ctx.saved_tensors[:2]
-        lats = ctx.saved_tensors[2:2 + ns]
+        integrals = ctx.saved_tensors[2:2 + ns]
         weights = ctx.saved_tensors[2 + ns:2 + 2 * ns]
         biases = ctx.saved_tensors[2 + 2 * ns:2 + 3 * ns]
         m0 = mods[0]
@@ -339,12 +338,11 @@ class _FusedFrameTrain(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         g_lats, g_ws, g_bs = [], [], []
         with torch.no_grad():
-            for k, (m, lat, w, b) in enumerate(zip(mods, lats, weights, biases)):
+            for k, (m, integral, w, b) in enumerate(zip(mods, integrals, weights, biases)):
                 need_lat, need_w, need_b = ctx.needs_input_grad[5 + k], ctx.needs_input_grad[5 + ns + k], ctx.needs_input_grad[5 + 2 * ns + k]
                 if not (need_lat or need_w or need_b):
                     g_lats.append(None), g_ws.append(None), g_bs.append(None)
                     continue
-                integral = ops.integral_image(lat)
                 w_lm = w.view(C, C, nl).permute(0, 2, 1).reshape(C, nl * C).contiguous()  # column layer * C + c, like the pooled rows
                 g_int = torch.zeros_like(integral) if need_lat else None
                 g_w_lm = torch.zeros_like(w_lm) if need_w else None
@@ -355,7 +353,8 @@ class _FusedFrameTrain(torch.autograd.Function):
                     count = min(chunk, n_cells - begin)
                     vox = ops.project_gather(integral, cal, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h), crange,
                                              cell_begin=begin, cell_count=count)
-                    lin = torch.matmul(vox.view(n * count, nl * C), w_lm.t()).view(n, count, C)
+                    # (the product of the forward: the same bf16-split MFMA arithmetic decides the ReLU mask)
+                    lin = ops.collapse_gemm(vox.view(n * count, nl * C), w_lm, terms=COLLAPSE_TERMS).view(n, count, C)
                     g_lin, g_b_part = ops.relu_mask_backward(grad_out[begin:begin + count], lin, b)
                     del lin
                     if need_b:
