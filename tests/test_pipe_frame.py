@@ -81,8 +81,8 @@ SINGLE = [  # workload, cameras, grid crop (rows, cols) or None
 
 @pytest.mark.parametrize("name,n_cam,crop", SINGLE)
 def test_pipe_equals_the_serial_fused_kernel_bit_for_bit_on_single_layer_grids(name, n_cam, crop, monkeypatch):
-    """Same pooling arithmetic, same product sequence (k ascending, lo.hi / hi.hi / hi.lo per k-step), same order of the view and
-    scale sums: on nl = 1 the pipelined kernel must reproduce ``vfa_pool_collapse_relu_sum_f32`` exactly."""
+    """Same pooling arithmetic, same product sequence (k ascending, lo.hi / hi.hi / hi.lo per k-step): on nl = 1 the pipelined kernel
+    must reproduce ``vfa_pool_collapse_relu_sum_f32`` up to the association of the view / scale sum."""
     import vfa_amd
     from vfa_amd import ops, vfa_op
     dev = _dev()
@@ -103,21 +103,20 @@ def test_pipe_equals_the_serial_fused_kernel_bit_for_bit_on_single_layer_grids(n
         assert "vfa_pool_collapse_relu_sum_f32" in kt.summary() and PIPE_ENTRY not in kt.summary(), sorted(kt.summary())
         monkeypatch.setattr(vfa_op, "PIPE", True)
         again = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
-        # Both kernels add the parts of a tile that was cut between two workgroups in another association than an uncut tile
-        # (and cut at different places), so bitwise equality holds on the tiles neither of them cut: launch both on 8
-        # workgroups (VFA_FLAG_RESERVED_CUS(248)): at most 7 cut tiles each
+        # Same pooled features, same products; what differs is the association of the sum over views and scales: the serial kernel
+        # adds relu(view) one by one to the tile's running sum, the pipelined one adds a GROUP's views first (((r0 + r1) + r2) +
+        # r3, the running sum is fetched under the group's last step) and the group to the tile.  Also compared on 8 workgroups
+        # (VFA_FLAG_RESERVED_CUS(248): at most 7 tiles cut between workgroups in each kernel).
         p8 = vfa_op.pipe_frame(mods, lats, calibs, grid, reserved_cus=248)
         s8 = vfa_op.fused_frame(mods, lats, calibs, grid, reserved_cus=248)
     assert torch.isfinite(piped).all()
     p = piped[0].permute(1, 2, 0).reshape(L * W, 256)
     s = serial[0].permute(1, 2, 0).reshape(L * W, 256)
     _check(f"{name} pipe vs serial kernel, full launch", p, s.double())
-    tl, tw = (L + 3) // 4, (W + 7) // 8
-    cell = torch.arange(L * W, device=dev)
-    tile_of = (cell // W // 4) * tw + (cell % W) // 8
-    bad_tiles = torch.unique(tile_of[(p8 != s8).any(1)])
-    assert bad_tiles.numel() <= 14, f"{bad_tiles.numel()} of {tl * tw} tiles differ on 8 workgroups: {bad_tiles[:16].tolist()}, " \
-                                    f"max |diff| {(p8 - s8).abs().max().item():.3e}"
+    # <= 21 roundings of partial sums apart (7 views x 3 scales): a few 1e-7 of the largest value
+    for a, b, what in ((p8, s8, "8 workgroups"), (p, s, "full launch")):
+        err = (a - b).abs().max().item() / b.abs().max().item()
+        assert err <= 1.5e-6, f"{name} pipe vs serial kernel, {what}: max |diff| / max = {err:.3e}"
     _check(f"{name} pipe vs serial kernel, 8 workgroups", p8, s8.double())
     assert torch.equal(again, piped)  # deterministic, shared tiles included (fixed addition order of the parts)
 

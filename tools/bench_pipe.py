@@ -17,7 +17,9 @@ from vfa_amd import _lib, ops  # noqa: E402
 from vfa_amd.synthetic import make_workload  # noqa: E402
 
 name = next((a for a in sys.argv[1:] if not a.startswith("--")), "multiviewc_200x200x1")
+terms = int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--terms=")), "0"))  # 0 (= 3), 3, 4, 6 products
 stamps = "--stamps" in sys.argv
+stamp_mask = int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--stamp-mask=")), "0"))  # ablation bits under the stamps
 dev = torch.device("cuda:0")
 wl = make_workload(name, channels=256, seed=0)
 n = wl["n_cam"]
@@ -57,10 +59,10 @@ with torch.no_grad():
     integrals = ops.integral_images(lats)
     weights = [m.collapse.weight for m in mods]
     biases = [m.collapse.bias for m in mods]
-    ws = ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights)
-    t_rec = timed(lambda: ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws))
-    t_box = timed(lambda: ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, workspace=ws, cuts=False))
-    ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws)
+    ws = ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, terms=terms)
+    t_rec = timed(lambda: ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws, terms=terms))
+    t_box = timed(lambda: ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, workspace=ws, cuts=False, terms=terms))
+    ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws, terms=terms)
     t_int = timed(lambda: ops.integral_images(lats))
     out = torch.empty(L * W, 256, device=dev)
     # header statistics
@@ -77,7 +79,7 @@ with torch.no_grad():
               f"window slots mean {slots.mean() if slots.size else 0:.1f} max {slots.max() if slots.size else 0}")
     print(f"{name}: {n} views, {L}x{W}x{nl}, {tiles} tiles | geometry {t_rec:.1f} us (boxes {t_box:.1f}) | integral images {t_int:.1f} us | "
           f"workspace {ws.numel() / 1e6:.0f} MB")
-    t_full = timed(lambda: ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out), reps=20, warm=10)
+    t_full = timed(lambda: ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, terms=terms), reps=20, warm=10)
     flops = items_live * 3 * 2 * 32 * 256 * 256
     print(f"  pipe_collapse           {t_full:9.1f} us   {items_live} live 32x256x256 products: {flops / t_full / 1e6:7.1f} TFLOP/s bf16 issued-equivalent "
           f"({flops / t_full / 1e6 / 2500:.3f} of the dense peak), {t_full * 1e-6 * 2.4e9 * 256 / max(items_live, 1):.0f} CU-cycles @2.4GHz per product")
@@ -90,8 +92,8 @@ with torch.no_grad():
         print(f"  pipe_collapse [{label:>20}] {us:9.1f} us")
     if stamps:
         names = ["step head", "wait for W", "pool / DMA issue", "multiply", "generator + wait for DMA", "tile finish", "barrier", "steps"]
-        for wave in range(12):
-            ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=128 | (wave << 8))
+        for wave in range(16):
+            ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=128 | stamp_mask | (wave << 8))
             torch.cuda.synchronize()
             d = ws[lay["diag"]:lay["diag"] + 512 * 64].cpu().numpy().view(np.uint64).reshape(512, 8).astype(np.float64)
             d = d[d[:, 7] > 0]
@@ -104,7 +106,7 @@ with torch.no_grad():
 
     if "--fit" in sys.argv:
         # Per-workgroup cycles against what the workgroup had to do: the constants of the work-cut cost model (vfa_pipe_seq.h).
-        ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws)
+        ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws, terms=terms)
         ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=128 | (8 << 8))
         torch.cuda.synchronize()
         host = ws.cpu().numpy()

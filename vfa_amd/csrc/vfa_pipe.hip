@@ -42,7 +42,11 @@ constexpr int kQSlot = 256;                     // ... and the 64-channel quarte
 constexpr int kWinSlots = 108;                  // LDS tap window of a (tile, view, layer, scale), in quarter slots: four of them (two being
                                                 // pooled, two arriving); 27 KiB each
 constexpr int kWinSlots3 = 92;                  // ... of the three-piece variant (VFA_FLAG_TERMS 6): a third bf16 plane takes 17 KiB of LDS
-constexpr int kMatWaves = 8, kPoolWaves = 4, kThreads = 64 * (kMatWaves + kPoolWaves);
+// 8 matrix waves + 8 pooling waves (four waves per SIMD, 128 registers); the six-product variant keeps 4 pooling waves (three per
+// SIMD, 168 registers: its third weight plane and third fragment do not fit into 128, and it is bound by the matrix pipe anyway)
+constexpr int kMatWaves = 8;
+constexpr int pool_waves_of(int terms) { return terms == 6 ? 4 : 8; }
+constexpr int threads_of(int terms) { return 64 * (kMatWaves + pool_waves_of(terms)); }
 constexpr int kStepRows = 64;                   // rows of a step: two sub-tiles
 // A tile of a step in LDS, per bf16 plane: 8 chunks (16 bytes = 8 k) x 64 rows x 16 bytes, chunk stride padded by 32 bytes
 // (the pooling waves' 8-byte stores of neighbouring chunks then fall into different banks)
@@ -334,12 +338,42 @@ __device__ __forceinline__ float4 sample4(float4 nw, float4 ne, float4 sw, float
     return v;
 }
 
+// Tap reads of the pooling waves, by hand: four 16-byte taps (one corner of the box) per instruction group, counted waits.  Eight
+// taps are in flight at most -- a corner's registers take the corner after the next once it is consumed --: 32 tap registers
+// instead of 64 is what lets two boxes per lane live at 128 registers (four waves per SIMD).  LDS
+// operations return in order; a scalar load the compiler puts in between only makes a counted wait more conservative.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_read4(f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4 &t3, unsigned p0, unsigned p1, unsigned p2, unsigned p3)
+{
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4 &t3)
+{
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "n"(N));
+}
+// the same for a box pooled straight from the integral image in L2: 32-bit byte offsets from the image address in scalar registers
+__device__ __forceinline__ void glob_read4(f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4 &t3, const char *img, unsigned p0, unsigned p1, unsigned p2, unsigned p3)
+{
+    asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\tglobal_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %8"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(img) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void glob_wait4(f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4 &t3)
+{
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "n"(N));
+}
+__device__ __forceinline__ float4 as_float4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
+
 // box of one pooling lane for a whole layer: the 16 rounded tap weights, the scale (RN(1 / area), or the masked value) and the
-// 16 tap positions (byte offsets inside the tap window, or inside the view's integral image for a direct item)
+// tap positions as 4 row + 4 column byte offsets (tap (i, k) sits at rowb[i] + colb[k] inside the tap window, or inside the
+// view's integral image for a direct item): eight registers instead of sixteen -- two boxes per lane must fit beside sixteen
+// taps in flight at 128 registers
 struct LaneBox {
     float wt[16];
     float scl;
-    unsigned tb[16];
+    unsigned rowb[4], colb[4];
 };
 
 // A fragments of one k-step for the two row blocks of a step (hi / lo planes): immediate offsets from one LDS address.
@@ -354,6 +388,20 @@ __device__ __forceinline__ void read_frags(unsigned pa, bf16x8 &h0, bf16x8 &l0, 
                  : "v"(pa), "n"(KS * 2 * kChunkStride), "n"(KS * 2 * kChunkStride + kPlaneBytes), "n"(KS * 2 * kChunkStride + 512),
                    "n"(KS * 2 * kChunkStride + 512 + kPlaneBytes)
                  : "memory");
+}
+// one plane (0 = hi, 1 = lo) of both row blocks of a k-step, and the counted wait for a pair (LDS reads return in order)
+template <int KS, int PLANE>
+__device__ __forceinline__ void read_pair(unsigned pa, bf16x8 &f0, bf16x8 &f1)
+{
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                 : "=&v"(f0), "=&v"(f1)
+                 : "v"(pa), "n"(KS * 2 * kChunkStride + PLANE * kPlaneBytes), "n"(KS * 2 * kChunkStride + 512 + PLANE * kPlaneBytes)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_pair(bf16x8 &f0, bf16x8 &f1)
+{
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N));
 }
 template <int N>
 __device__ __forceinline__ void wait_frags(bf16x8 &h0, bf16x8 &l0, bf16x8 &h1, bf16x8 &l1)
@@ -374,7 +422,7 @@ __device__ __forceinline__ void read_frags3(unsigned pa, bf16x8 &p0, bf16x8 &p1,
 }
 
 template <int TERMS, bool DIAG>
-__global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
+__global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 {
     // separate objects: one per role of the data (hipcc orders LDS-DMA against every LDS access it cannot prove disjoint)
     constexpr int kPieces = TERMS == 6 ? 3 : 2;                             // bf16 pieces of an operand
@@ -434,16 +482,21 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
     auto run = [&](auto role_tag) {
         constexpr bool POOL = decltype(role_tag)::value;
         const int r = lane & 31, h = lane >> 5;           // matrix waves: row / column of the 32 x 32 block, k half
-        const int pw = wave - kMatWaves;                  // pooling waves: 0..3
+        const int pw = wave - kMatWaves;                  // pooling waves: 0..7
+        constexpr bool W16 = pool_waves_of(TERMS) == 8;
+        // ... sub-tile of the set, its upper / lower 16 boxes, and -- eight pooling waves: two waves per 16 boxes -- which of the
+        // four 16-byte pieces: m = mpar, mpar + mstep, ...
+        const int px = W16 ? pw >> 2 : pw >> 1, phalf = W16 ? (pw >> 1) & 1 : pw & 1, mpar = W16 ? pw & 1 : 0;
+        constexpr int mstep = W16 ? 2 : 1, mcount = W16 ? 2 : 4;
+        const int dw = W16 ? pw : wave;                   // the waves that fetch (step_dma): 0..7
         const int pb = lane >> 2, pi = lane & 3;          // ... box 0..15 of the wave's half sub-tile, 16-byte piece 0..3
 
         // ---------------------------------------------------------------- matrix-wave state
-        f32x16 acc[4], sum;
+        f32x16 acc[4];
         Frag3 wq[4]; // (lo2: the three-piece variant only)
         float bc[kMaxScales];
+        bool tile_open = false; // an earlier group of this workgroup left the tile's running sum in the workspace
         if constexpr (!POOL) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -497,11 +550,18 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         };
         auto empty_tiles = [&](int t0, int t1) { // tiles without a group inside this workgroup's range
             if constexpr (!POOL) {
-                f32x16 none = {};
-                for (int t2 = t0; t2 < t1; ++t2) write_tile(t2, none, false);
+                for (int t2 = t0; t2 < t1; ++t2) write_tile(t2, acc[0], false);
             }
         };
 
+        unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+        auto tick = [&](int k) {
+            if (DIAG) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                stamp[k] += now - t_prev;
+                t_prev = now;
+            }
+        };
         // ---------------------------------------------------------------- tables and DMA
         // Control is organised so that NO wave does scalar work that the others repeat: twelve waves share the CU's one scalar
         // unit, and ~40 scalar instructions at the head of a step in every wave cost 600-1000 cycles per step.  Every phase has
@@ -555,10 +615,11 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                 d[1] = make_uint4(fw, (unsigned)wsl, (unsigned)(wsl >> 32), (unsigned)(Wf + 2));
             }
         };
-        // Tap window (and, at the first quarter of a layer, the box records) of ONE sub-tile of step i: waves 0-3 fetch for the
-        // first sub-tile of the set, waves 4-7 for the second.  Addresses stay in vector registers (the same value in every lane).
+        // Tap window (and, at the first quarter of a layer, the box records) of ONE sub-tile of step i: pooling waves 0-3 fetch for
+        // the first sub-tile of the set, 4-7 for the second (the matrix waves are the longer role at four waves per SIMD: the fetch
+        // cost each of them 1 500-2 400 cycles per step).  Addresses stay in vector registers (the same value in every lane).
         auto step_dma = [&](int i) {
-            const int n = i >> 3, k = i & 7, x = wave >> 2, wq4 = wave & 3, j = 2 * (k & 1) + x;
+            const int n = i >> 3, k = i & 7, x = dw >> 2, wq4 = dw & 3, j = 2 * (k & 1) + x;
             const uint4 *dp = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0]);
             const uint4 d0 = dp[0], d1 = dp[1];
             const uint4 *hp = reinterpret_cast<const uint4 *>(&s_hdr[n & 3][j * 8]);
@@ -614,10 +675,18 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             constexpr bool reload = SET == 1;
             const int q = k >> 1;
             const bool grp_first = ph.layer() == 0 && q == 0, grp_last = ph.layer() == a.nl - 1 && q == 3;
-            if (grp_first) {
+            if (q == 0) {
+                // The bias rides in the accumulator: at the first step of a group both accumulators of the set restart from it.  A
+                // SELECT (on the first quarter of every layer), not an assignment under `grp_first`: the assignment made the
+                // allocator keep the old and the new accumulators in different registers and copy all 32 at the join.
                 const float b0 = ph.scale() == 0 ? bc[0] : (ph.scale() == 1 ? bc[1] : bc[2]);
+                int first = grp_first ? 1 : 0;
+                asm volatile("" : "+v"(first)); // (opaque: keeps the compiler from turning the selects back into that assignment)
+                f32x16 bv;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { acc[2 * SET][i] = b0; acc[2 * SET + 1][i] = b0; } // (the bias rides in the accumulator)
+                for (int i = 0; i < 16; ++i) bv[i] = b0;
+                acc[2 * SET] = first ? bv : acc[2 * SET];
+                acc[2 * SET + 1] = first ? bv : acc[2 * SET + 1];
             }
             const bool work = 2 * SET < ph.nj() && !(DIAG && (a.debug & 4)); // (set 1 of a group of one or two views is empty)
             // A fragments: lane (r, h) of row block rb reads chunk 2 ks + h, row 32 rb + r (read_frags)
@@ -626,12 +695,12 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             // ONE set of fragment registers: the reads of k-step ks + 1 are issued behind the MFMAs of ks (which latched their A
             // operands when they issued) and land under them and under the partner wave's MFMAs; a second set for reading ahead
             // does not fit beside four accumulators, the tile sums and the weight slice (168 registers at three waves per SIMD)
-            bf16x8 fh0, fl0, fh1, fl1; // row block 0, row block 1
+            bf16x8 h0, h1, l0, l1; // row blocks 0 / 1 of the hi and of the lo plane: one k-step ahead of the MFMAs
             // Both row blocks, always: a sub-tile without a live box in this layer was ZEROED by its pooling wave, and the rows
             // of a sub-tile the group does not have feed an accumulator nobody reads.
             auto kstep = [&](auto ks_tag) {
                 constexpr int KS = decltype(ks_tag)::value;
-                if (work) {
+                {
                     if constexpr (TERMS == 6) {
                         // three pieces per operand, the six products down to 2^-16 of the largest (x = p0 + p1 + p2 to 2^-25:
                         // p0 p0, p0 p1, p1 p0, p0 p2, p2 p0, p1 p1; what is dropped is <= 2^-23 of the product): sgemm-class
@@ -655,49 +724,85 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                         acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     } else {
-                    read_frags<KS>(pa, fh0, fl0, fh1, fl1);
-                    wait_frags<0>(fh0, fl0, fh1, fl1);
+                    // the hi pair of this k-step was requested behind the hi MFMAs of the last one, the lo pair behind its lo MFMAs
+                    wait_pair<2>(h0, h1);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
-                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
-                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
-                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
-                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
-                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
+                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
+                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (KS < 3) { read_pair<KS + 1, 0>(pa, h0, h1); wait_pair<2>(l0, l1); } // (the MFMAs latched h0, h1 at issue)
+                    else wait_pair<0>(l0, l1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
+                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
                     if (TERMS >= 4) {
-                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
-                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
+                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (KS < 3) read_pair<KS + 1, 1>(pa, l0, l1);
                     __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                if (reload && work) w_load(KS); // the next slice (w_addr), k-step by k-step, into the registers just used
+                if (reload) w_load(KS); // the next slice (w_addr), k-step by k-step, into the registers just used
             };
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (no scalar load may be pending beside the waits of read_frags)
-            kstep(std::integral_constant<int, 0>{});
-            kstep(std::integral_constant<int, 1>{});
-            kstep(std::integral_constant<int, 2>{});
-            kstep(std::integral_constant<int, 3>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tick(2);
+            if (work) { // (one branch around the whole step: the fragment registers live across the k-steps)
+                if constexpr (TERMS != 6) { read_pair<0, 0>(pa, h0, h1); read_pair<0, 1>(pa, l0, l1); }
+                kstep(std::integral_constant<int, 0>{});
+                kstep(std::integral_constant<int, 1>{});
+                kstep(std::integral_constant<int, 2>{});
+                kstep(std::integral_constant<int, 3>{});
+            }
+            tick(3);
             // A group of one or two views has nothing in set 1: that step is a barrier and little else, too short to cover a weight
             // load.  The next slice is then requested HERE, behind set 0 (whole, not interleaved: its registers are free now).
             if (SET == 0 && ph.nj() <= 2 && next_chunk) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) w_load(ks);
             }
-            if (grp_last && 2 * SET < ph.nj()) { // vfa_op.py:124; vfanet.py:79, 82: views in index order
+        };
+        // A group ends: relu and the view sum, vfa_op.py:124; vfanet.py:79, 82.  The tile's running sum lives in the WORKSPACE between
+        // the groups (slot 2 of the workgroup: written and read back by the same lane) -- sixteen registers for the whole kernel do
+        // not fit at four waves per SIMD.  No exposed round trip: in front of the group's LAST step (set 1 of the last quarter;
+        // the accumulators of set 0 are complete) r0 + r1 moves into acc[0] and the running sum is requested into the registers of
+        // acc[1]; behind the step, tile = s + (((r0 + r1) + r2) + r3), views in index order inside the group.
+        auto group_begin = [&](const PhaseRec &ph) {
+            const float *slot = a.partial + (((size_t)lb * 3 + 2) * 8 + wave) * 16 * 64 + lane;
+            const bool two = ph.nj() > 1;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[2 * SET][i]);
-                if (2 * SET + 1 < ph.nj()) {
+            for (int i = 0; i < 16; ++i) {
+                const float r0 = relu_t(acc[0][i]), r1 = relu_t(acc[1][i]);
+                acc[0][i] = two ? r0 + r1 : r0;
+            }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[2 * SET + 1][i]);
-                }
+            for (int i = 0; i < 16; ++i) acc[1][i] = slot[i * 64]; // (always: what an unopened tile's slot holds is never used)
+        };
+        auto group_end = [&](const PhaseRec &ph) {
+            float *slot = a.partial + (((size_t)lb * 3 + 2) * 8 + wave) * 16 * 64 + lane;
+            const bool three = ph.nj() > 2, four = ph.nj() > 3, more = ph.more(), open = tile_open;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float g = acc[0][i];
+                const float r2 = relu_t(acc[2][i]), r3 = relu_t(acc[3][i]);
+                g = three ? g + r2 : g;
+                g = four ? g + r3 : g;
+                const float s0 = open ? acc[1][i] : 0.0f;
+                acc[0][i] = s0 + g;
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) slot[i * 64] = acc[0][i];
             }
         };
 
         // ---------------------------------------------------------------- pooling of one step (pooling waves)
         // returns false when none of the wave's 16 boxes has anything to pool (all masked, none NaN): the wave then writes zeros
         auto unpack = [&](LaneBox &bx, bool &glob, unsigned wp, int j, bool direct) -> bool {
-            const uint4 *rp = reinterpret_cast<const uint4 *>(s_rec + j * kTileBoxes * kRecBytes) + ((pw & 1) * 16 + pb) * (kRecBytes / 16);
+            const uint4 *rp = reinterpret_cast<const uint4 *>(s_rec + j * kTileBoxes * kRecBytes) + (phalf * 16 + pb) * (kRecBytes / 16);
             uint4 rv[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) rv[k] = rp[k];
@@ -712,13 +817,13 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             unsigned rw[4] = {rv[4].z & 0xffffu, rv[4].z >> 16, rv[4].w & 0xffffu, rv[4].w >> 16};
             unsigned cl[4] = {rv[5].x & 0xffffu, rv[5].x >> 16, rv[5].y & 0xffffu, rv[5].y >> 16};
             glob = direct;
+            // pixel of the padded image (direct) / slot of the window = row part + column part; a masked box reads slot / pixel 0
+            const unsigned unit = direct ? (unsigned)kSlotBytes : (unsigned)kQSlot;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned pos = direct ? rw[i] * wp + cl[k] : rw[i] + cl[k]; // pixel of the padded image / slot of the window
-                    bx.tb[4 * i + k] = (vis ? pos : 0u) * (direct ? (unsigned)kSlotBytes : (unsigned)kQSlot) + (unsigned)(pi * 16);
-                }
+            for (int i = 0; i < 4; ++i) {
+                bx.rowb[i] = (vis ? (direct ? rw[i] * wp : rw[i]) : 0u) * unit;
+                bx.colb[i] = (vis ? cl[i] : 0u) * unit + (unsigned)(pi * 16);
+            }
             return __ballot(vis || bx.scl != bx.scl) != 0ull;
         };
         // the wave's 16 boxes x the 64 channels of quarter q: lane (box pb, piece pi) takes the 16-byte pieces
@@ -731,29 +836,52 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             const char *img = nullptr;
             if constexpr (GLOB) { // (image address of (view, quarter): descriptor of the step)
                 const uint4 d0 = reinterpret_cast<const uint4 *>(&s_desc[(i >> 3) & 3][k][x][0])[0];
-                img = reinterpret_cast<const char *>((size_t)((unsigned long long)d0.y << 32 | d0.x));
+                img = reinterpret_cast<const char *>((size_t)((unsigned long long)(unsigned)uniform_i((int)d0.y) << 32 | (unsigned)uniform_i((int)d0.x)));
             }
-            const int row = x * 32 + (pw & 1) * 16 + pb;
+            const int row = x * 32 + phalf * 16 + pb;
             unsigned char *planes = s_planes + set * kPieces * kPlaneBytes;
             // All sixteen taps of a 16-byte piece are requested at once and consumed as they arrive (counted waits).  A hand-made
             // software pipeline across the four pieces (the next piece's taps requested as soon as half of this piece's were
             // consumed) measured 35 % SLOWER (4 900 against 3 620 cycles per step): more registers, spills, and the
             // scheduling barriers it needs keep the compiler from interleaving arithmetic and reads.
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int mm = 0; mm < mcount; ++mm) {
+                const int m = mpar + mstep * mm; // (eight pooling waves: the partner wave, same boxes, takes the other two)
                 const unsigned piece = (unsigned)((pb + m) & 3);
                 const unsigned rot = piece << 6;
-                float4 t[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if constexpr (GLOB) t[k] = *reinterpret_cast<const float4 *>(img + (size_t)(bx.tb[k] + rot));
-                    else t[k] = *reinterpret_cast<const float4 *>(win + (bx.tb[k] + rot));
-                }
+                float4 lt, rb, rt, lb2;
                 // taps: index 4 * row + col over {top, top + 1, bottom, bottom + 1} x {left, left + 1, right, right + 1}
-                const float4 lt = sample4(t[0], t[1], t[4], t[5], bx.wt[0], bx.wt[1], bx.wt[2], bx.wt[3]);
-                const float4 rb = sample4(t[10], t[11], t[14], t[15], bx.wt[4], bx.wt[5], bx.wt[6], bx.wt[7]);
-                const float4 rt = sample4(t[2], t[3], t[6], t[7], bx.wt[8], bx.wt[9], bx.wt[10], bx.wt[11]);
-                const float4 lb2 = sample4(t[8], t[9], t[12], t[13], bx.wt[12], bx.wt[13], bx.wt[14], bx.wt[15]);
+                {
+                    unsigned wbase = rot;
+                    if constexpr (!GLOB) wbase += (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)win;
+                    unsigned colr[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) colr[k] = bx.colb[k] + wbase;
+                    auto read4 = [&](f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4 &t3, unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
+                        if constexpr (GLOB) glob_read4(t0, t1, t2, t3, img, p0, p1, p2, p3);
+                        else lds_read4(t0, t1, t2, t3, p0, p1, p2, p3);
+                    };
+                    auto wait4 = [&](auto n_tag, f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4 &t3) {
+                        constexpr int N = decltype(n_tag)::value;
+                        if constexpr (GLOB) glob_wait4<N>(t0, t1, t2, t3);
+                        else lds_wait4<N>(t0, t1, t2, t3);
+                    };
+                    using W4 = std::integral_constant<int, 4>;
+                    using W0 = std::integral_constant<int, 0>;
+                    f32x4 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3;
+                    read4(a0, a1, a2, a3, bx.rowb[0] + colr[0], bx.rowb[0] + colr[1], bx.rowb[1] + colr[0], bx.rowb[1] + colr[1]);
+                    read4(b0, b1, b2, b3, bx.rowb[2] + colr[2], bx.rowb[2] + colr[3], bx.rowb[3] + colr[2], bx.rowb[3] + colr[3]);
+                    wait4(W4{}, a0, a1, a2, a3);
+                    lt = sample4(as_float4(a0), as_float4(a1), as_float4(a2), as_float4(a3), bx.wt[0], bx.wt[1], bx.wt[2], bx.wt[3]);
+                    read4(c0, c1, c2, c3, bx.rowb[0] + colr[2], bx.rowb[0] + colr[3], bx.rowb[1] + colr[2], bx.rowb[1] + colr[3]);
+                    wait4(W4{}, b0, b1, b2, b3);
+                    rb = sample4(as_float4(b0), as_float4(b1), as_float4(b2), as_float4(b3), bx.wt[4], bx.wt[5], bx.wt[6], bx.wt[7]);
+                    read4(d0, d1, d2, d3, bx.rowb[2] + colr[0], bx.rowb[2] + colr[1], bx.rowb[3] + colr[0], bx.rowb[3] + colr[1]);
+                    wait4(W4{}, c0, c1, c2, c3);
+                    rt = sample4(as_float4(c0), as_float4(c1), as_float4(c2), as_float4(c3), bx.wt[8], bx.wt[9], bx.wt[10], bx.wt[11]);
+                    wait4(W0{}, d0, d1, d2, d3);
+                    lb2 = sample4(as_float4(d0), as_float4(d1), as_float4(d2), as_float4(d3), bx.wt[12], bx.wt[13], bx.wt[14], bx.wt[15]);
+                }
                 // (((lt + rb) - rt) - lb) * RN(1 / area)                                              (A.6)
                 float4 v = make_float4(lt.x + rb.x, lt.y + rb.y, lt.z + rb.z, lt.w + rb.w);
                 v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
@@ -778,7 +906,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         };
         auto pool_step = [&](auto set_tag, int i) {
             constexpr int SET = decltype(set_tag)::value;
-            const int n = i >> 3, k = i & 7, x = pw >> 1, j = 2 * SET + x;
+            const int n = i >> 3, k = i & 7, x = px, j = 2 * SET + x;
             auto one = [&](LaneBox &bx, bool &glob, bool &live) { // (called with the registers of the step's set)
                 if ((k >> 1) == 0) { // first quarter of the layer: this wave's 16 boxes for the whole layer
                     const uint4 d1 = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0])[1];
@@ -787,10 +915,11 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                     if (live) live = unpack(bx, glob, d1.w, j, (fw & kTileDirect) != 0);
                 }
                 if (!live) { // no live box in this layer (or no such sub-tile in the group): the matrix waves multiply zeros
-                    const int row = x * 32 + (pw & 1) * 16 + pb;
+                    const int row = x * 32 + phalf * 16 + pb;
                     unsigned char *planes = s_planes + SET * kPieces * kPlaneBytes;
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
+                    for (int mm = 0; mm < mcount; ++mm) {
+                        const int m = mpar + mstep * mm;
                         const int off = (2 * m + (pi >> 1)) * kChunkStride + row * 16 + (pi & 1) * 8;
                         *reinterpret_cast<uint2 *>(planes + off) = make_uint2(0u, 0u);
                         *reinterpret_cast<uint2 *>(planes + kPlaneBytes + off) = make_uint2(0u, 0u);
@@ -807,7 +936,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         };
 
         // ---------------------------------------------------------------- a workgroup's part of a tile is complete
-        auto finish_tile = [&](int tile, int next_tile) {
+        auto finish_tile = [&](int tile, int next_tile, const f32x16 &sum) {
             if (__builtin_expect(!shared_tile(tile), 1)) {
                 if constexpr (!POOL) write_tile(tile, sum, true);
             } else {
@@ -816,7 +945,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                 // drained, then one ticket per workgroup (guide: inter-workgroup visibility, valid forms).
                 const int which = (tile == t_begin && k_begin > 0) ? 0 : 1;
                 if constexpr (!POOL) {
-                    float *pp = a.partial + (((size_t)lb * 2 + which) * 8 + wave) * 16 * 64 + lane;
+                    float *pp = a.partial + (((size_t)lb * 3 + which) * 8 + wave) * 16 * 64 + lane;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) __hip_atomic_store(pp + i * 64, sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -848,7 +977,7 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                             range_of(j, tb, kb, te, ke);
                             if (tb > te || (tb == te && kb >= ke)) continue;
                             const int wj = (tile == tb && kb > 0) ? 0 : 1;
-                            const float *pp = a.partial + (((size_t)j * 2 + wj) * 8 + wave) * 16 * 64 + lane;
+                            const float *pp = a.partial + (((size_t)j * 3 + wj) * 8 + wave) * 16 * 64 + lane;
 #pragma unroll
                             for (int i = 0; i < 16; ++i) tot[i] += __hip_atomic_load(pp + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
@@ -856,22 +985,10 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                     }
                 }
             }
-            if constexpr (!POOL) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
-            }
             empty_tiles(tile + 1, next_tile);
         };
 
         // ---------------------------------------------------------------- the loop
-        unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
-        auto tick = [&](int k) {
-            if (DIAG) {
-                const unsigned long long now = __builtin_amdgcn_s_memtime();
-                stamp[k] += now - t_prev;
-                t_prev = now;
-            }
-        };
         auto lds_fence_barrier = [&]() {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -891,8 +1008,8 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
         lds_fence_barrier();
         if (wave == 0) make_desc(0);
         lds_fence_barrier();
+        if constexpr (POOL == W16) step_dma(0);
         if constexpr (!POOL) {
-            step_dma(0);
             w_addr(0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) w_load(ks);
@@ -908,13 +1025,18 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
             tick(0);
             if constexpr (POOL) {
                 if (m == 0 && i > 0) rec = phase_rec(i >> 3);
+                // the next step's windows first, so that they land under this step's pooling -- except at the first step of a phase,
+                // where this wave still has to read its boxes out of the record buffer the fetch of step i + 1 shares (the compiler
+                // drains the DMA in front of any LDS read of the same object)
+                if (W16 && m != 0 && (live & 4u)) step_dma(i + 1);
                 if (live & 2u) pool_step(std::integral_constant<int, PSET>{}, i);
+                if (W16 && m == 0 && (live & 4u)) step_dma(i + 1);
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 tick(2);
             } else {
                 // the weight slice requested during the last step (and tile stores).  The BUILTIN, not assembly: it tells the
                 // compiler's wait-count model that nothing is pending; otherwise it waits for those loads itself -- vmcnt(0) in front
-                // of the first MFMA, behind the DMA issued below: a memory round trip per step
+                // of the first MFMA: a memory round trip per step
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 tick(1);
                 if (m == 1 && i > 1) rec = phase_rec((i - 1) >> 3);
@@ -923,23 +1045,25 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                     else if (m == 5) hdr_dma((i >> 3) + 1);
                     else if (m == 6) make_desc((i >> 3) + 1);
                 }
-                // The two matrix waves of a SIMD take their two jobs in opposite order: waves 0-3 request the next step's window
-                // and then multiply, waves 4-7 multiply first -- one of the pair is on the matrix pipe while the other does its
-                // address arithmetic.
+                // Twelve-wave layout: the matrix waves fetch.  The two matrix waves of a SIMD take their two jobs in opposite order
+                // (waves 0-3 request the next step's window and then multiply, waves 4-7 multiply first).
                 const bool dma_first = wave < 4;
-                if (dma_first && (live & 4u)) step_dma(i + 1);
-                tick(2);
+                if (!W16 && dma_first && (live & 4u)) step_dma(i + 1);
+                // (step i - 1 ends its group: the last quarter of the last layer, set 1 -- `rec` is still that step's phase)
+                const bool group_ends = MSET == 1 && ((i - 1) & 7) == 7 && (live & 1u) && rec.layer() == a.nl - 1;
                 if (live & 1u) {
+                    if (MSET == 1 && group_ends) group_begin(rec);
                     // the slice of the next chunk: behind the k-steps of set 1 (steps i - 1 = set 1, i = set 0 of the next chunk), or,
                     // when set 1 of the group is empty, already behind set 0 (steps i - 1 = set 0, i = set 1, i + 1 = the next chunk)
                     bool next_chunk = false;
                     if (MSET == 1 && (live & 2u)) { w_addr(i); next_chunk = true; }
                     if (MSET == 0 && rec.nj() <= 2 && (live & 4u)) { w_addr(i + 1); next_chunk = true; }
                     multiply(std::integral_constant<int, MSET>{}, rec, (i - 1) & 7, MSET, next_chunk);
+                    if (MSET == 1 && group_ends) group_end(rec);
                 }
-                tick(3);
-                if (!dma_first && (live & 4u)) step_dma(i + 1);
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // windows / records / headers of the next step have landed
+                if (!W16 && !dma_first && (live & 4u)) step_dma(i + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (wave 0: the tables; the header DMA is waited for below)
+                if (!W16 || (wave == 0 && m == 5)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (what this wave fetched has landed)
                 tick(4);
             }
             if constexpr (MSET == 1) { // (step i - 1 was the last of its phase's quarter 3?)
@@ -950,13 +1074,16 @@ __global__ __launch_bounds__(kThreads) void pipe_kernel(PipeArgs a)
                         const PhaseRec prev = phase_rec((i - 1) >> 3);
                         if (prev.layer() == a.nl - 1 && !prev.more()) {
                             const PhaseRec nxt = phase_rec(((i - 1) >> 3) + 1);
-                            finish_tile(prev.tile, nxt.valid() ? nxt.tile : t_end);
+                            finish_tile(prev.tile, nxt.valid() ? nxt.tile : t_end, acc[0]);
                         }
                     }
                 } else {
-                    if (__builtin_expect(((i - 1) & 7) == 7 && (live & 1u) && pr.layer() == a.nl - 1 && !pr.more(), 0)) {
-                        const PhaseRec nxt = phase_rec(((i - 1) >> 3) + 1);
-                        finish_tile(pr.tile, nxt.valid() ? nxt.tile : t_end);
+                    if (__builtin_expect(((i - 1) & 7) == 7 && (live & 1u) && pr.layer() == a.nl - 1, 0)) {
+                        tile_open = pr.more();
+                        if (!pr.more()) {
+                            const PhaseRec nxt = phase_rec(((i - 1) >> 3) + 1);
+                            finish_tile(pr.tile, nxt.valid() ? nxt.tile : t_end, acc[0]);
+                        }
                     }
                 }
             }
@@ -1025,7 +1152,7 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
     }
     w.chunks = off;  off = align_up(off + (kChunks + 1) * sizeof(int), 256);
     w.ranks = off;   off = align_up(off + (kChunks + 1) * sizeof(int), 256);
-    w.partial = off; off = align_up(off + (size_t)kMaxBlocks * 2 * 8 * 16 * 64 * sizeof(float), 256);
+    w.partial = off; off = align_up(off + (size_t)kMaxBlocks * 3 * 8 * 16 * 64 * sizeof(float), 256);
     w.diag = off;    off = align_up(off + (size_t)kMaxBlocks * 8 * sizeof(unsigned long long), 256);
     w.total = off;
     return w;
@@ -1203,13 +1330,13 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *c
     const hipError_t e = hipMemsetAsync(a.tickets, 0, (size_t)lay.n_tiles * 4, s);
     if (e != hipSuccess) return (int)e;
     if (debug)
-        hipLaunchKernelGGL((pipe_kernel<3, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((pipe_kernel<3, true>), dim3(nblk), dim3(threads_of(3)), 0, s, a);
     else if (terms == 4)
-        hipLaunchKernelGGL((pipe_kernel<4, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((pipe_kernel<4, false>), dim3(nblk), dim3(threads_of(4)), 0, s, a);
     else if (terms == 6)
-        hipLaunchKernelGGL((pipe_kernel<6, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((pipe_kernel<6, false>), dim3(nblk), dim3(threads_of(6)), 0, s, a);
     else
-        hipLaunchKernelGGL((pipe_kernel<3, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((pipe_kernel<3, false>), dim3(nblk), dim3(threads_of(3)), 0, s, a);
     return (int)hipGetLastError();
 }
 
