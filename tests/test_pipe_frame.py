@@ -308,7 +308,7 @@ def test_pipe_work_cuts_match_the_serial_restatement():
             while left > 0:
                 nj = min(left, 4)
                 sets = (nj + 1) // 2
-                out.append(4 * nl * (76 * sets + 49 * (2 - sets)) + 16 + ((27 + 4 * 66 * int(globs[t])) if not out else 0))
+                out.append(4 * nl * (69 * sets + 46 * (2 - sets)) + 14 + ((36 + 4 * 35 * int(globs[t])) if not out else 0))
                 left -= nj
         return out
 

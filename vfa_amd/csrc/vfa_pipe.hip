@@ -148,7 +148,9 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
                 }
                 n_slots = cwid * (top_rows + bot_rows);
             }
-            const bool direct = n_slots > a.win_slots; // pooled straight from the integral image: pixel coordinates in the record
+            // pooled straight from the integral image (pixel coordinates in the record): the window does not fit, or the padded
+            // image has 2^24 pixels or more (the window fetch of the frame kernel works out its addresses with 24-bit multiplies)
+            const bool direct = n_slots > a.win_slots || (long long)(Hf + 2) * (Wf + 2) >= (1ll << 24);
             auto slot_row = [&](int y) { return y < t0 + top_rows ? y - t0 : top_rows + (y - b0); };
             unsigned rows[4], cols[4];
 #pragma unroll
@@ -489,6 +491,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         const int px = W16 ? pw >> 2 : pw >> 1, phalf = W16 ? (pw >> 1) & 1 : pw & 1, mpar = W16 ? pw & 1 : 0;
         constexpr int mstep = W16 ? 2 : 1, mcount = W16 ? 2 : 4;
         const int dw = W16 ? pw : wave;                   // the waves that fetch (step_dma): 0..7
+        // The wave that runs the generator and fills the tables: matrix wave 0.  (On the last pooling wave -- they wait ~1 500 cycles
+        // per step at the barrier -- the generator's scalar state no longer fits the scalar registers; what is spilled from them takes
+        // vector registers of BOTH roles and the matrix loop spills: 23 scratch operations per step.)
+        const bool table_wave = wave == 0;
         const int pb = lane >> 2, pi = lane & 3;          // ... box 0..15 of the wave's half sub-tile, 16-byte piece 0..3
 
         // ---------------------------------------------------------------- matrix-wave state
@@ -640,9 +646,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             unsigned char *dst = s_win + ((k & 1) * 2 + x) * kWinBytes;
             for (int f = wq4; f < n_fill; f += 4) { // four quarter slots per instruction, 16 lanes each
                 const int slot = min(4 * f + (lane >> 4), n_slots - 1);
-                const int wr = (slot * inv) >> 16, wc = slot - wr * cw;
+                // (24-bit multiplies, full rate -- a 32-bit one is a quarter-rate instruction: slot < 2^7, inv <= 2^16, the pixel
+                // index < 2^24 (larger images are pooled directly: pipe_records_kernel))
+                const int wr = (int)(__umul24((unsigned)slot, (unsigned)inv) >> 16), wc = slot - (int)__umul24((unsigned)wr, (unsigned)cw);
                 const int y = wr < top ? t0 + wr : b0 + (wr - top), xx = x0 + wc;
-                const unsigned long long src = img + (unsigned long long)(unsigned)((y + 1) * wpad + (xx + 1)) * kSlotBytes;
+                const unsigned long long src = img + (unsigned long long)(__umul24((unsigned)(y + 1), (unsigned)wpad) + (unsigned)(xx + 1)) * kSlotBytes;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)(dst + f * 1024), 16, 0, 0);
             }
@@ -995,7 +1003,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             asm volatile("" ::: "memory");
         };
         // prologue: phase 0's record, headers, descriptors; the windows / records and the weight slice of step 0
-        if (wave == 0) {
+        if (table_wave) {
             sq.masks = masks;
             sq.begin(a.n_scales, a.nl, t_begin, k_begin, t_end, k_end);
             gen_phase(0);
@@ -1004,9 +1012,9 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         PhaseRec rec = phase_rec(0); // matrix waves: the phase of the step being multiplied; pooling waves: of the step being pooled
         empty_tiles(k_begin == 0 ? t_begin : t_begin + 1, rec.valid() ? rec.tile : t_end);
         if (!rec.valid()) return;
-        if (wave == 0) hdr_dma(0);
+        if (table_wave) hdr_dma(0);
         lds_fence_barrier();
-        if (wave == 0) make_desc(0);
+        if (table_wave) make_desc(0);
         lds_fence_barrier();
         if constexpr (POOL == W16) step_dma(0);
         if constexpr (!POOL) {
@@ -1040,7 +1048,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 tick(1);
                 if (m == 1 && i > 1) rec = phase_rec((i - 1) >> 3);
-                if (wave == 0) { // the tables of the next phase (see `tables and DMA`)
+                if (table_wave) { // the tables of the next phase (see `tables and DMA`)
                     if (m == 4) gen_phase((i >> 3) + 1);
                     else if (m == 5) hdr_dma((i >> 3) + 1);
                     else if (m == 6) make_desc((i >> 3) + 1);
@@ -1063,7 +1071,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 }
                 if (!W16 && !dma_first && (live & 4u)) step_dma(i + 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (wave 0: the tables; the header DMA is waited for below)
-                if (!W16 || (wave == 0 && m == 5)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (what this wave fetched has landed)
+                if (!W16 || (table_wave && m == 5)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (what this wave fetched has landed)
                 tick(4);
             }
             if constexpr (MSET == 1) { // (step i - 1 was the last of its phase's quarter 3?)

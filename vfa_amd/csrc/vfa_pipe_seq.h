@@ -176,11 +176,12 @@ struct Sequencer {
 
 // ------------------------------------------------------------------------------------------------
 // work cuts: the groups of the frame in (tile, scale, view) order, cut into `n_chunks` pieces of equal estimated cost.
-// Cost model in units of 64 cycles, fitted to the per-workgroup cycle counts of the diagnostic build on the bench frame
-// (tools/bench_pipe.py --fit): a step with work 76, a step of an empty set 49 (it still waits for the next step's window), a
-// sub-tile pooled from L2 instead of an LDS window + 66 per step, + 16 per group (weight reloads), + 27 per tile (its store).
+// Cost model in units of 64 cycles, fitted to the per-workgroup cycle counts of the diagnostic build of the sixteen-wave kernel on
+// the bench frame and three multi-layer frames (tools/bench_pipe.py --fit): a step with work 69, a step of an empty set 46 (it
+// still waits for the next step's window), a sub-tile pooled from L2 instead of an LDS window + 35 per step, + 14 per group
+// (weight reloads, the running sum), + 36 per tile (its store).
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned kStepCost = 76, kEmptyStepCost = 49, kGlobStepCost = 66, kGroupCost = 16, kTileCost = 27, kEmptyCost = 1;
+constexpr unsigned kStepCost = 69, kEmptyStepCost = 46, kGlobStepCost = 35, kGroupCost = 14, kTileCost = 36, kEmptyCost = 1;
 
 VFA_SEQ_HD unsigned group_cost(int nj, int nl)
 {
