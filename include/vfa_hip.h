@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VFA_ABI_VERSION 3
+#define VFA_ABI_VERSION 4
 
 /* world-unit conversion of the grid, reference vfa_op.py:23-44 (chosen by args.data) */
 #define VFA_CONV_MULTIVIEWC 0 /* x / 1.0                                   */
@@ -100,6 +100,25 @@ int vfa_affine_relu_integral_image_f32(const float *x, const float *scale, const
  * launch of the large one instead of paying a launch pair each.   replaces the three vfa_op.py:110 calls of vfanet.py:76-78 */
 int vfa_integral_images_f32(const float *const *features, const float *const *scales, const float *const *shifts,
                             float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream);
+
+/* The same for CHANNELS-LAST inputs features_hwc[s] (n_views, H_s, W_s, C) -- what vfa_lateral_conv_f32 writes --: no NCHW copy of the
+ * lateral convolution exists.  C a multiple of 64.  Bit-identical to vfa_integral_images_f32 of the permuted input. */
+int vfa_integral_images_hwc_f32(const float *const *features_hwc, const float *const *scales, const float *const *shifts,
+                                float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream);
+
+/* The lateral branch of one feature scale, as far as the integral image needs it:
+ *   y = conv1x1(feat) + bias            feat (n_views, K, Hf, Wf) NCHW (the trunk's output), weight (256, K) = lat.weight.view(256, K)
+ *   out_hwc (n_views, Hf, Wf, 256) = y, channels-last;   scale, shift (n_views, 256): the nn.GroupNorm(16, 256) affine of y,
+ *   scale = gamma * rstd(group), shift = beta - mean(group) * scale   (biased variance, eps inside the root)
+ * so that relu(y * scale + shift) = relu(bn(lat(feat))) -- applied by vfa_integral_images_hwc_f32 while it scans the rows.
+ * The product runs on v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain over k (sgemm arithmetic); the statistics are gathered in
+ * the epilogue (double partial sums, added in a fixed order: the same bits on every run).  K a multiple of 32.
+ * workspace: vfa_lateral_conv_workspace_bytes(n_views, Hf, Wf).
+ *   replaces vfa/model/vfanet.py:37-42, 72-74 (self.lat8/16/32 + self.bn8/16/32; the ReLU rides in the integral image) */
+size_t vfa_lateral_conv_workspace_bytes(int n_views, int Hf, int Wf);
+int vfa_lateral_conv_f32(const float *feat, const float *weight, const float *bias, const float *gamma, const float *beta, float eps,
+                         float *out_hwc, float *scale, float *shift, void *workspace, size_t workspace_bytes, int n_views, int K,
+                         int Hf, int Wf, void *stream);
 
 /* Cube corners -> world units -> 3x4 projection -> normalise/clamp -> 2-D bounding box, area and
  * visibility of every (view, layer, cell).                      replaces vfa_op.py:64-88, 104-106

@@ -103,6 +103,22 @@ def gather(integral, box, area, visible):
     return vox
 
 
+def lateral(feat, weight, bias, gamma, beta, eps=1e-5, groups=16):
+    """The lateral branch in front of the path, restated in float64 numpy: relu(GroupNorm(conv1x1(feat)))   (reference
+    vfa/model/vfanet.py:37-42, 72-74: nn.Conv2d(K, 256, 1), nn.GroupNorm(16, 256), F.relu).  feat (K, h, w), weight (256, K)
+    -> (y (256, h, w) = the convolution, lat (256, h, w) = the normalised, rectified map), both float64.  Pinned by
+    tests/golden/laterals_*.npz (a real VFANet.forward of the reference)."""
+    f = np.asarray(feat, np.float64)
+    K, h, w = f.shape
+    y = np.asarray(weight, np.float64).reshape(-1, K) @ f.reshape(K, h * w) + np.asarray(bias, np.float64)[:, None]
+    co = y.shape[0]
+    g = y.reshape(groups, -1)
+    mean, var = g.mean(1, keepdims=True), g.var(1, keepdims=True)  # biased, like nn.GroupNorm
+    norm = ((g - mean) / np.sqrt(var + eps)).reshape(co, h * w)
+    out = norm * np.asarray(gamma, np.float64)[:, None] + np.asarray(beta, np.float64)[:, None]
+    return y.reshape(co, h, w), np.maximum(out, 0.0).reshape(co, h, w)
+
+
 def collapse_relu(vox, weight, bias):
     """relu(vox @ weight.T + bias) -> (M, N).  vfa_op.py:123-125."""
     vox, weight, bias = _f32(vox), _f32(weight), _f32(bias)

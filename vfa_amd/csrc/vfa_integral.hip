@@ -94,6 +94,55 @@ __global__ __launch_bounds__(kWave) void rows_batched_kernel(MapArgs a)
     }
 }
 
+// pass 1 for a CHANNELS-LAST input (n_views, H, W, C) -- the lateral convolution of vfa_lateral.hip writes that --: lane = channel,
+// the row is walked left to right with the loads eight pixels ahead; every load and store of the wave is one 256-byte piece of a
+// pixel.  No LDS, no transpose.  Same arithmetic as above, element for element.
+template <bool AFFINE>
+__global__ __launch_bounds__(kWave) void rows_hwc_kernel(MapArgs a)
+{
+    const int lane = threadIdx.x;
+    unsigned b = blockIdx.x;
+    int mi = 0;
+    while (mi + 1 < a.n_maps && b >= a.m[mi].row_blocks) { b -= a.m[mi].row_blocks; ++mi; }
+    const MapDesc &m = a.m[mi];
+    const int H = m.H, W = m.W, C = a.C, cblocks = C / kWave;
+    const int y = (int)(b % (unsigned)H);
+    const unsigned rest = b / (unsigned)H;
+    const int c0 = (int)(rest % (unsigned)cblocks) * kWave, v = (int)(rest / (unsigned)cblocks);
+    const float *src = m.feat + (((size_t)v * H + y) * W) * C + c0 + lane;
+    float *dst = m.out + (((size_t)v * (H + 2) + (y + 1)) * (W + 2)) * C + c0 + lane;
+    dst[0] = 0.0f;
+    dst[(size_t)(W + 1) * C] = 0.0f;
+    float sa = 1.0f, sb = 0.0f;
+    if (AFFINE) {
+        sa = m.scale[(size_t)v * C + c0 + lane];
+        sb = m.shift[(size_t)v * C + c0 + lane];
+    }
+    auto act = [&](float x) {
+        if (!AFFINE) return x;
+        float t = x * sa;
+        t = t + sb;
+        return (t < 0.0f) ? 0.0f : t; // NaN stays NaN
+    };
+    constexpr int U = 8;
+    double acc = 0.0;
+    int x = 0;
+    for (; x + U <= W; x += U) {
+        float t[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) t[k] = src[(size_t)(x + k) * C];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            acc += (double)act(t[k]);
+            dst[(size_t)(x + k + 1) * C] = (float)acc;
+        }
+    }
+    for (; x < W; ++x) {
+        acc += (double)act(src[(size_t)x * C]);
+        dst[(size_t)(x + 1) * C] = (float)acc;
+    }
+}
+
 // pass 2: cumsum along H, in place, plus the zero top and bottom border rows.  One thread owns four channels of one padded
 // column of one view of one map; its loads do not depend on the running sum and are issued eight rows ahead.
 __global__ __launch_bounds__(256) void cols_batched_kernel(MapArgs a, unsigned long long total)
@@ -145,6 +194,38 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 extern "C" {
 
+static int integral_images_launch(const float *const *features, const float *const *scales, const float *const *shifts,
+                                  float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, bool hwc, void *stream)
+{
+    MapArgs a = {};
+    a.n_maps = n_maps; a.n_views = n_views; a.C = C;
+    unsigned long long row_blocks = 0, col_vecs = 0;
+    for (int s = 0; s < n_maps; ++s) {
+        MapDesc &m = a.m[s];
+        m.feat = features[s]; m.out = integrals[s];
+        m.scale = scales ? scales[s] : nullptr; m.shift = shifts ? shifts[s] : nullptr;
+        m.H = feat_hw[2 * s]; m.W = feat_hw[2 * s + 1];
+        const unsigned long long rb = (unsigned long long)m.H * (C / kWave) * n_views;
+        if (rb >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
+        m.row_blocks = (unsigned)rb;
+        m.col_vecs = (unsigned long long)n_views * (m.W + 2) * C / 4;
+        row_blocks += rb; col_vecs += m.col_vecs;
+    }
+    if (row_blocks >= (1ull << 31) || (col_vecs + 255) / 256 >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (hwc) {
+        if (scales) hipLaunchKernelGGL((rows_hwc_kernel<true>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
+        else hipLaunchKernelGGL((rows_hwc_kernel<false>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
+    } else {
+        if (scales) hipLaunchKernelGGL((rows_batched_kernel<true>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
+        else hipLaunchKernelGGL((rows_batched_kernel<false>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
+    }
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    hipLaunchKernelGGL(cols_batched_kernel, dim3((unsigned)((col_vecs + 255) / 256)), dim3(256), 0, st, a, col_vecs);
+    return (int)hipGetLastError();
+}
+
 int vfa_integral_images_f32(const float *const *features, const float *const *scales, const float *const *shifts,
                             float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream)
 {
@@ -167,30 +248,23 @@ int vfa_integral_images_f32(const float *const *features, const float *const *sc
         }
         return 0;
     }
-    MapArgs a = {};
-    a.n_maps = n_maps; a.n_views = n_views; a.C = C;
-    unsigned long long row_blocks = 0, col_vecs = 0;
+    return integral_images_launch(features, scales, shifts, integrals, n_views, C, n_maps, feat_hw, false, stream);
+}
+
+int vfa_integral_images_hwc_f32(const float *const *features_hwc, const float *const *scales, const float *const *shifts,
+                                float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream)
+{
+    if (!features_hwc || !integrals || !feat_hw || n_views < 0 || C <= 0 || n_maps < 0) return VFA_ERR_BAD_ARGUMENT;
+    if ((scales == nullptr) != (shifts == nullptr)) return VFA_ERR_BAD_ARGUMENT;
     for (int s = 0; s < n_maps; ++s) {
-        MapDesc &m = a.m[s];
-        m.feat = features[s]; m.out = integrals[s];
-        m.scale = scales ? scales[s] : nullptr; m.shift = shifts ? shifts[s] : nullptr;
-        m.H = feat_hw[2 * s]; m.W = feat_hw[2 * s + 1];
-        const unsigned long long rb = (unsigned long long)m.H * (C / kWave) * n_views;
-        if (rb >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
-        m.row_blocks = (unsigned)rb;
-        m.col_vecs = (unsigned long long)n_views * (m.W + 2) * C / 4;
-        row_blocks += rb; col_vecs += m.col_vecs;
+        if (feat_hw[2 * s] <= 0 || feat_hw[2 * s + 1] <= 0 || !features_hwc[s] || !integrals[s]) return VFA_ERR_BAD_ARGUMENT;
+        if (scales && (!scales[s] || !shifts[s])) return VFA_ERR_BAD_ARGUMENT;
     }
-    if (row_blocks >= (1ull << 31) || (col_vecs + 255) / 256 >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    if (scales)
-        hipLaunchKernelGGL((rows_batched_kernel<true>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
-    else
-        hipLaunchKernelGGL((rows_batched_kernel<false>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
-    int e = (int)hipGetLastError();
-    if (e) return e;
-    hipLaunchKernelGGL(cols_batched_kernel, dim3((unsigned)((col_vecs + 255) / 256)), dim3(256), 0, st, a, col_vecs);
-    return (int)hipGetLastError();
+    if (n_views == 0 || n_maps == 0) return 0;
+    if (C % kWave != 0 || n_maps > kMaxMaps) return VFA_ERR_UNSUPPORTED;
+    for (int s = 0; s < n_maps; ++s)
+        if (!aligned16(integrals[s])) return VFA_ERR_UNSUPPORTED; // (the column pass works on float4)
+    return integral_images_launch(features_hwc, scales, shifts, integrals, n_views, C, n_maps, feat_hw, true, stream);
 }
 
 } // extern "C"

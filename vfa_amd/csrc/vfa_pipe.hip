@@ -682,7 +682,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             constexpr int SET = decltype(set_tag)::value;
             constexpr bool reload = SET == 1;
             const int q = k >> 1;
-            const bool grp_first = ph.layer() == 0 && q == 0, grp_last = ph.layer() == a.nl - 1 && q == 3;
+            const bool grp_first = ph.layer() == 0 && q == 0;
             if (q == 0) {
                 // The bias rides in the accumulator: at the first step of a group both accumulators of the set restart from it.  A
                 // SELECT (on the first quarter of every layer), not an assignment under `grp_first`: the assignment made the

@@ -95,24 +95,55 @@ def affine_relu_integral_image(x, scale, shift):
     return integral
 
 
-def integral_images(features, scales=None, shifts=None):
+def integral_images(features, scales=None, shifts=None, channels_last=False):
     """The integral images of every feature map of a frame in one launch pair (``vfa_integral_images_f32``): features = one
     (n,C,H_s,W_s) batch per stride -> one (n,H_s+2,W_s+2,C) image per stride, bit-identical to ``integral_image`` of each.
-    ``scales`` / ``shifts`` (one (n,C) tensor per map): the fused GroupNorm affine + ReLU of ``affine_relu_integral_image``."""
+    ``scales`` / ``shifts`` (one (n,C) tensor per map): the fused GroupNorm affine + ReLU of ``affine_relu_integral_image``.
+    ``channels_last``: the inputs are (n,H_s,W_s,C) (``lateral_conv``'s output; ``vfa_integral_images_hwc_f32``)."""
     features = [_f32c(f) for f in features]
     _lib.require_device(*features)
-    n, C = features[0].shape[:2]
-    assert all(f.shape[0] == n and f.shape[1] == C for f in features)
-    outs = [torch.empty((n, f.shape[2] + 2, f.shape[3] + 2, C), dtype=torch.float32, device=f.device) for f in features]
+    n = features[0].shape[0]
+    C = features[0].shape[3 if channels_last else 1]
+    sizes = [tuple(f.shape[1:3]) if channels_last else tuple(f.shape[2:]) for f in features]
+    assert all(f.shape[0] == n and f.shape[3 if channels_last else 1] == C for f in features)
+    outs = [torch.empty((n, h + 2, w + 2, C), dtype=torch.float32, device=f.device) for f, (h, w) in zip(features, sizes)]
     affine = scales is not None
     if affine:
         scales, shifts = [_f32c(t) for t in scales], [_f32c(t) for t in shifts]
         assert all(tuple(t.shape) == (n, C) for t in scales + shifts)
-    hw = _lib.int_array([v for f in features for v in f.shape[2:]])
-    _launch("vfa_integral_images_f32", _lib.ptr_array(features), _lib.ptr_array(scales) if affine else None,
-            _lib.ptr_array(shifts) if affine else None, _lib.ptr_array(outs), n, C, len(features), hw,
-            _lib.current_stream_handle(), tag=(n, C, tuple(tuple(f.shape[2:]) for f in features), affine))
+    hw = _lib.int_array([v for hw_ in sizes for v in hw_])
+    _launch("vfa_integral_images_hwc_f32" if channels_last else "vfa_integral_images_f32", _lib.ptr_array(features),
+            _lib.ptr_array(scales) if affine else None, _lib.ptr_array(shifts) if affine else None, _lib.ptr_array(outs), n, C,
+            len(features), hw, _lib.current_stream_handle(), tag=(n, C, tuple(sizes), affine))
     return outs
+
+
+_lateral_ws = {}
+
+
+def lateral_conv(feat, weight, bias, gamma, beta, eps=1e-5):
+    """The lateral branch of one scale as far as the integral image needs it (``vfa_lateral_conv_f32``): feat (n,K,h,w) NCHW,
+    weight (256,K) or (256,K,1,1), bias / gamma / beta (256) -> y (n,h,w,256) = conv1x1(feat) + bias CHANNELS-LAST, and the
+    nn.GroupNorm(16, 256) affine of y as scale, shift (n,256): relu(y * scale + shift) = relu(bn(lat(feat))) (reference
+    vfanet.py:72-74).  fp32 FMA chain on the matrix pipe; statistics gathered in the epilogue."""
+    _lib.require_device(feat, weight, bias, gamma, beta)
+    feat, weight = _f32c(feat), _f32c(weight.reshape(weight.shape[0], -1))
+    bias, gamma, beta = _f32c(bias), _f32c(gamma), _f32c(beta)
+    n, K, h, w = feat.shape
+    assert tuple(weight.shape) == (256, K) and bias.numel() == 256 and gamma.numel() == 256 and beta.numel() == 256
+    dev = feat.device
+    out = torch.empty((n, h, w, 256), dtype=torch.float32, device=dev)
+    scale = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    shift = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    need = _lib.lib().vfa_lateral_conv_workspace_bytes(n, h, w)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, need)
+    ws = _lateral_ws.get(key)  # (one per (device, stream, size): the three scales of a frame are in flight on one stream together)
+    if ws is None:
+        ws = _lateral_ws[key] = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+    _launch("vfa_lateral_conv_f32", _lib.ptr(feat), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+            _lib.ptr(out), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(ws), ws.numel(), n, K, h, w, _lib.current_stream_handle(),
+            tag=(n, K, h, w))
+    return out, scale, shift
 
 
 def box_params(calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, feat_hw, crange=(-1, 0.95)):
@@ -462,8 +493,7 @@ def frame_workspace_layout(n_views, L, W, n_scales):
     out["overflow"] = [int(off[17 + k]) for k in range(n_scales)]
     out.update(diag=int(off[15]), total=int(off[16]), counter=int(off[20]), rows=int(off[21]), rows_cap=int(off[22]),
                chunks=int(off[23]), ranks=int(off[24]),
-               tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]),
-               max_slots_3piece=int(tiles[4]))
+               tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]))
     return out
 
 

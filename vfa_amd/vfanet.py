@@ -156,20 +156,16 @@ class VFANet(nn.Module):
 
     def lateral_integrals(self, images):
         """images (n,3,iH,iW) -> the three zero-bordered channels-last integral images of the lateral maps, without
-        materialising those maps: 1x1 conv (MIOpen), GroupNorm statistics (two small reductions), then the affine + ReLU inside
-        the row scan of the integral image (reference vfanet.py:72-74 + vfa_op.py:110, 172-173)."""
+        materialising those maps (reference vfanet.py:72-74 + vfa_op.py:110, 172-173).  Per scale ONE hand-written kernel for
+        the 1x1 convolution (``ops.lateral_conv``: fp32 on the matrix pipe, channels-last output, GroupNorm statistics in its
+        epilogue) + a tiny statistics kernel; then one launch pair for the three integral images, whose row scan applies the
+        GroupNorm affine and the ReLU (``vfa_integral_images_hwc_f32``).  No NCHW lateral tensor exists."""
         x = (images - self.mean.view(3, 1, 1)) / self.std.view(3, 1, 1)
         ys, scales, shifts = [], [], []
         for feat, conv, gn in zip(self.base(x), (self.lat8, self.lat16, self.lat32), (self.bn8, self.bn16, self.bn32)):
-            y = conv(feat)
-            n, c = y.shape[:2]
-            var, mean = torch.var_mean(y.reshape(n, gn.num_groups, -1), dim=2, unbiased=False)          # (n, groups)
-            rstd = torch.rsqrt(var + gn.eps)
-            per = c // gn.num_groups
-            scale = gn.weight.view(1, c) * rstd.repeat_interleave(per, dim=1)                            # gamma * rstd
-            shift = gn.bias.view(1, c) - mean.repeat_interleave(per, dim=1) * scale                      # beta - mean * scale
+            y, scale, shift = ops.lateral_conv(feat, conv.weight, conv.bias, gn.weight, gn.bias, gn.eps)
             ys.append(y), scales.append(scale), shifts.append(shift)
-        return ops.integral_images(ys, scales, shifts)
+        return ops.integral_images(ys, scales, shifts, channels_last=True)
 
     def ortho_features(self, images, calibs, grid, distributed=False):
         """The fused BEV map (1,256,L,W) entering the heads (reference vfanet.py:64-82, 131)."""
@@ -177,8 +173,9 @@ class VFANet(nn.Module):
             mine = camera_shard(images.shape[0])
             idx = torch.tensor(mine, dtype=torch.long, device=images.device)
             images, calibs = images[idx], calibs[idx]
+        mods3 = [self.vfa8, self.vfa16, self.vfa32]
         if (FUSE_PRODUCER and not torch.is_grad_enabled() and images.is_cuda and images.shape[0]
-                and vfa_op.fused_frame_ok([self.vfa8, self.vfa16, self.vfa32], images.shape[0])):
+                and (vfa_op.fused_frame_ok(mods3, images.shape[0]) or vfa_op.pipe_frame_ok(mods3, images.shape[0]))):
             return aggregate_views(self.vfa8, self.vfa16, self.vfa32, None, None, None, calibs, grid, (-1, 0.95),
                                    distributed=distributed, integrals=self.lateral_integrals(images))
         lat8, lat16, lat32 = self.laterals(images) if images.shape[0] else (images.new_zeros(0, 256, 1, 1),) * 3
