@@ -45,6 +45,7 @@ constexpr int kWinSlots3 = 92;                  // ... of the three-piece varian
 // 8 matrix waves + 8 pooling waves (four waves per SIMD, 128 registers); the six-product variant keeps 4 pooling waves (three per
 // SIMD, 168 registers: its third weight plane and third fragment do not fit into 128, and it is bound by the matrix pipe anyway)
 constexpr int kMatWaves = 8;
+constexpr int kGroupRing = 128; // group records in LDS (2 KB); a tile has at most 3 * 8 groups
 constexpr int pool_waves_of(int terms) { return terms == 6 ? 4 : 8; }
 constexpr int threads_of(int terms) { return 64 * (kMatWaves + pool_waves_of(terms)); }
 constexpr int kStepRows = 64;                   // rows of a step: two sub-tiles
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
     __shared__ unsigned s_misc[16];
     __shared__ __align__(16) unsigned s_phase[4][4];                        // phase records (wave 0): [phase & 3]{tile, views, w, -}
+    __shared__ __align__(16) unsigned s_groups[kGroupRing][4];              // group records (wave 0), a ring: {tile, views, scale | nj << 15 | more << 20, -}
     __shared__ __align__(16) unsigned s_desc[4][8][2][8];                   // fetch descriptors (wave 0): [phase & 3][step of the phase][sub-tile]
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63;
 
@@ -576,11 +578,66 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         //   s_phase  the generator's record of the phase                                    (at step 4 of the phase before)
         //   s_hdr    the window headers of the group's sub-tiles at the phase's layer: DMA   (at step 5)
         //   s_desc   per (step, sub-tile): image / record / weight addresses, flags, slots   (at step 6; first used at step 7)
-        Sequencer<DevMasks> sq;
-        auto gen_phase = [&](int n) { // (wave 0)
-            const Phase ph = sq.next_phase();
-            const unsigned w = (unsigned)ph.scale | ((unsigned)ph.layer << 2) | ((unsigned)ph.nj << 15) | (ph.more_in_tile ? 1u << 20 : 0u);
-            if (lane == 0) *reinterpret_cast<uint4 *>(&s_phase[n & 3][0]) = make_uint4((unsigned)ph.tile, ph.views, w, 0u);
+        // The generator (vfa_pipe_seq.h: tiles -> scales -> groups of <= 4 live views -> layers), in the kernel as VECTOR code: the
+        // scalar state machine with its three dependent scalar loads per tile sat on matrix wave 0 for ~1 400 cycles in three
+        // steps of every phase, and every wave waits for wave 0 at the barrier.  Now lane = tile: 64 tiles of the workgroup's range
+        // at a time are expanded into a ring of group records in LDS (view masks by vector loads, a lane scan for the positions,
+        // the cut at both ends of the range by rank); a phase is then a counter and one LDS read.
+        int gen_t = t_begin, gen_filled = 0, gen_next = 0, gen_layer = 0; // next tile to expand; groups written / handed out; layer
+        const int gen_t_lim = k_end > 0 ? t_end + 1 : t_end;
+        auto fill_groups = [&]() { // (table wave, all lanes)
+            const int t = gen_t + lane;
+            const bool on = t < gen_t_lim;
+            const unsigned m0 = on ? (a.sc[0].live[t] & view_mask) : 0u;
+            const unsigned m1 = (on && a.n_scales > 1) ? (a.sc[1].live[t] & view_mask) : 0u;
+            const unsigned m2 = (on && a.n_scales > 2) ? (a.sc[2].live[t] & view_mask) : 0u;
+            const int gt = groups_of(m0) + groups_of(m1) + groups_of(m2);
+            const int lo = t == t_begin ? k_begin : 0;
+            const int hi = min(t == t_end ? k_end : gt, gt);
+            const int cnt = on ? max(hi - lo, 0) : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const int cap = kGroupRing - 8 - (gen_filled - gen_next); // (the groups of the phases in flight stay untouched)
+            const bool take = on && incl <= cap;
+            const int tiles_taken = __popcll(__ballot(take)); // (a prefix of the lanes: incl does not decrease)
+            const int groups_taken = tiles_taken > 0 ? __shfl(incl, tiles_taken - 1) : 0;
+            if (take && cnt > 0) {
+                int r = 0;
+                const int base = gen_filled + incl - cnt - lo;
+#pragma unroll
+                for (int s2 = 0; s2 < kMaxScales; ++s2) {
+                    unsigned rest = s2 == 0 ? m0 : (s2 == 1 ? m1 : m2);
+                    while (rest) {
+                        unsigned views = 0;
+                        int nj = 0;
+                        for (; nj < kGroupViews && rest; ++nj) {
+                            views |= (unsigned)__builtin_ctz(rest) << (8 * nj);
+                            rest &= rest - 1u;
+                        }
+                        if (r >= lo && r < hi) {
+                            const unsigned w = (unsigned)s2 | ((unsigned)nj << 15) | (r + 1 < hi ? 1u << 20 : 0u);
+                            *reinterpret_cast<uint4 *>(&s_groups[(base + r) & (kGroupRing - 1)][0]) = make_uint4((unsigned)t, views, w, 0u);
+                        }
+                        ++r;
+                    }
+                }
+            }
+            gen_filled += uniform_i(groups_taken);
+            gen_t += uniform_i(tiles_taken);
+            if (gen_t >= gen_t_lim && lane == 0) // the end of the sequence
+                *reinterpret_cast<uint4 *>(&s_groups[gen_filled & (kGroupRing - 1)][0]) = make_uint4(0xffffffffu, 0u, 0u, 0u);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        auto gen_phase = [&](int n) { // (table wave)
+            while (gen_layer == 0 && gen_next == gen_filled && gen_t < gen_t_lim) fill_groups(); // (tiles without a live view add none)
+            const uint4 g = *reinterpret_cast<const uint4 *>(&s_groups[gen_next & (kGroupRing - 1)][0]);
+            const bool end = uniform_i((int)g.x) < 0;
+            if (lane == 0) *reinterpret_cast<uint4 *>(&s_phase[n & 3][0]) = make_uint4(g.x, g.y, g.z | ((unsigned)gen_layer << 2), 0u);
+            if (!end && ++gen_layer == a.nl) { gen_layer = 0; ++gen_next; }
         };
         auto scale_ptr = [&](int scale, const void *p0, const void *p1, const void *p2) { // (per-lane select: no scalar branches)
             return (unsigned long long)(size_t)(scale == 0 ? p0 : (scale == 1 ? p1 : p2));
@@ -1004,8 +1061,6 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         };
         // prologue: phase 0's record, headers, descriptors; the windows / records and the weight slice of step 0
         if (table_wave) {
-            sq.masks = masks;
-            sq.begin(a.n_scales, a.nl, t_begin, k_begin, t_end, k_end);
             gen_phase(0);
         }
         lds_fence_barrier();
