@@ -458,6 +458,9 @@ def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=Fa
     if out is None and stage != "rows":
         out = torch.empty((L * W, 256), dtype=torch.float32, device=integrals[0].device)
         accumulate = False
+    # (the kernel gets a raw pointer)
+    assert out is None or (out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (L * W, 256)), \
+        "out must be a contiguous fp32 (L*W, 256) tensor"
     biases = [None if b is None else _f32c(b) for b in (biases if biases is not None else [None] * ns)]
     hw = _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)])
     _launch("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array(biases), _lib.ptr(workspace),
