@@ -1091,9 +1091,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 // the next step's windows first, so that they land under this step's pooling -- except at the first step of a phase,
                 // where this wave still has to read its boxes out of the record buffer the fetch of step i + 1 shares (the compiler
                 // drains the DMA in front of any LDS read of the same object)
-                if (W16 && m != 0 && (live & 4u)) step_dma(i + 1);
-                if (live & 2u) pool_step(std::integral_constant<int, PSET>{}, i);
-                if (W16 && m == 0 && (live & 4u)) step_dma(i + 1);
+                const bool bare = DIAG && (a.debug & 64); // (diagnostic 64: the loop, the tables and the barrier only)
+                if (W16 && m != 0 && (live & 4u) && !bare) step_dma(i + 1);
+                if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i);
+                if (W16 && m == 0 && (live & 4u) && !bare) step_dma(i + 1);
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 tick(2);
             } else {
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 if (!W16 && dma_first && (live & 4u)) step_dma(i + 1);
                 // (step i - 1 ends its group: the last quarter of the last layer, set 1 -- `rec` is still that step's phase)
                 const bool group_ends = MSET == 1 && ((i - 1) & 7) == 7 && (live & 1u) && rec.layer() == a.nl - 1;
-                if (live & 1u) {
+                if ((live & 1u) && !(DIAG && (a.debug & 64))) {
                     if (MSET == 1 && group_ends) group_begin(rec);
                     // the slice of the next chunk: behind the k-steps of set 1 (steps i - 1 = set 1, i = set 0 of the next chunk), or,
                     // when set 1 of the group is empty, already behind set 0 (steps i - 1 = set 0, i = set 1, i + 1 = the next chunk)
