@@ -543,6 +543,40 @@ def main():
                               if terms == 6 else "two bf16 pieces per operand, three MFMA products (the default arithmetic)"}
         finally:
             vfa_op.PIPE, vfa_op.PIPE_SINGLE_LAYER, vfa_op.COLLAPSE_TERMS = saved
+    # ---- the producer in front of the path, NOT part of `value` (the path starts at lateral maps resident in HBM):
+    # trunk outputs -> the three integral images through the hand-written lateral branch (fp32-MFMA 1x1 convolution, channels-last,
+    # GroupNorm statistics in its epilogue; affine + ReLU inside the row scan) and through the library's operations
+    if a.fp32_steps > 0 and a.channels == 256 and len(leg.cams) > 0 and a.workload == PRIMARY:
+        import torch.nn.functional as F
+        n = len(leg.cams)
+        gen = torch.Generator(device="cpu").manual_seed(7)
+        shapes = [(k,) + tuple(leg.sets[0][i].shape[-2:]) for i, k in enumerate((128, 256, 512))]
+        feats = [torch.randn(n, k, h, w, generator=gen).to(dev) for k, h, w in shapes]
+        convs = [torch.nn.Conv2d(k, 256, 1).to(dev) for k, _, _ in shapes]
+        gns = [torch.nn.GroupNorm(16, 256).to(dev) for _ in shapes]
+
+        def hand():
+            parts = [ops.lateral_conv(f, c.weight, c.bias, g.weight, g.bias, g.eps) for f, c, g in zip(feats, convs, gns)]
+            return ops.integral_images([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts], channels_last=True)
+
+        def library():
+            return ops.integral_images([F.relu(g(c(f))) for f, c, g in zip(feats, convs, gns)])
+
+        def ms_of(fn, reps=20):
+            with torch.no_grad():
+                for _ in range(5):
+                    fn()
+                leg.fence()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                leg.fence()
+            return 1e3 * (time.perf_counter() - t0) / reps
+
+        extra["producer_f3"] = {"hand_written_ms_per_frame": ms_of(hand), "library_ms_per_frame": ms_of(library), "cameras": n,
+                                "note": "trunk outputs (n, 128/256/512, h, w) -> three integral images: vfa_lateral_conv_f32 x 3 + "
+                                        "vfa_integral_images_hwc_f32, against MIOpen conv + torch GroupNorm + ReLU x 3 + "
+                                        "vfa_integral_images_f32; outside the timed region of `value`"}
     # ---- N > 1: what the collective costs.  The same steps without it (slowest rank's compute), and the three ways of fusing the
     # map timed alone on a map-sized tensor: all-reduce, reduce -> rank 0, reduce-scatter over BEV rows + 4-row halo
     if world > 1 and a.steps > 0:

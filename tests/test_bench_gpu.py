@@ -76,3 +76,5 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     f = line["fused_fp32_equiv"]
     assert f["ms_per_step"] > 0 and f["roofline"]["bound"] == "mfma" and "pipe_kernel<6" in f["roofline"]["kernel"]
     assert line["pipelined_kernel"]["roofline"]["frac"] > 0
+    pf = line["producer_f3"]  # the producer in front of the path (f3): hand-written lateral branch against the library's operations
+    assert 0 < pf["hand_written_ms_per_frame"] < pf["library_ms_per_frame"] and pf["cameras"] == 7
