@@ -1161,11 +1161,82 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             if (((i + 2) & 7) == 0 && next_live) next_live = uniform_i((int)s_phase[((i + 2) >> 3) & 3][0]) >= 0 ? 1u : 0u;
             live = (live >> 1) | (next_live << 2);
         };
+        if constexpr (W16 && !POOL) {
+            // Matrix role, sixteen-wave layout: the loop by PHASE.  Iteration (n, j) multiplies step j of phase n while the pooling
+            // waves are one step ahead (their loop is `body` below; both roles pass 8 P + 1 step barriers for P phases, and the
+            // hand-off barriers of a shared tile in the same iteration).  With j static the set, the quarter, the table wave's job
+            // and the end of the group are facts of the code position; the phase record is read once per phase, the weight-slice
+            // address comes from it by scalar arithmetic instead of an LDS read per chunk.
+            auto w_set = [&](int scale, int layer, int q) {
+                const unsigned long long p = scale_ptr(scale, a.sc[0].wfrag, a.sc[1].wfrag, a.sc[2].wfrag) +
+                                             (unsigned long long)(((unsigned)layer * 8u * kSteps + (unsigned)q * 4u) * (unsigned)kWPlanes * 64u) * 16u;
+                w_lo = (unsigned)uniform_i((int)(unsigned)p); w_hi = (unsigned)uniform_i((int)(unsigned)(p >> 32));
+            };
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier(); // (iteration 0: the pooling waves pool step 0)
+            asm volatile("" ::: "memory");
+            int n = 0;
+            for (;;) {
+                PhaseRec nx = rec;
+                auto iter = [&](auto j_tag) {
+                    constexpr int J = decltype(j_tag)::value, SET = J & 1;
+                    tick(0);
+                    __builtin_amdgcn_s_waitcnt(0x0f70); // the weight slice requested during the last step (see `body`)
+                    tick(1);
+                    if (table_wave) { // the tables of the next phase (steps 4, 5, 6 of this one: see `tables and DMA`)
+                        if constexpr (J == 3) gen_phase(n + 1);
+                        if constexpr (J == 4) hdr_dma(n + 1);
+                        if constexpr (J == 5) make_desc(n + 1);
+                    }
+                    if constexpr (J == 6) nx = phase_rec(n + 1); // (written at J == 3, behind two barriers by now)
+                    const bool group_ends = J == 7 && rec.layer() == a.nl - 1;
+                    if (!(DIAG && (a.debug & 64))) {
+                        if (J == 7 && group_ends) group_begin(rec);
+                        // the slice of the next chunk: behind the k-steps of set 1, or, when set 1 of the group is empty, already
+                        // behind set 0; the chunk after quarter 3 is the next phase's first
+                        bool next_chunk = false;
+                        if (SET == 1 || rec.nj() <= 2) {
+                            const int jn = SET == 1 ? J + 1 : J + 2; // first step of the next chunk
+                            if (jn < 8) { w_set(rec.scale(), rec.layer(), jn >> 1); next_chunk = true; }
+                            else if (nx.valid()) { w_set(nx.scale(), nx.layer(), 0); next_chunk = true; }
+                        }
+                        multiply(std::integral_constant<int, SET>{}, rec, J, SET, next_chunk);
+                        if (J == 7 && group_ends) group_end(rec);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (table_wave && J == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the header DMA has landed)
+                    tick(4);
+                    if constexpr (J == 7) {
+                        if (__builtin_expect(group_ends, 0)) {
+                            tile_open = rec.more();
+                            if (!rec.more()) finish_tile(rec.tile, nx.valid() ? nx.tile : t_end, acc[0]);
+                        }
+                    }
+                    tick(5);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    tick(6);
+                    if (DIAG) stamp[7] += 1;
+                };
+                iter(std::integral_constant<int, 0>{});
+                iter(std::integral_constant<int, 1>{});
+                iter(std::integral_constant<int, 2>{});
+                iter(std::integral_constant<int, 3>{});
+                iter(std::integral_constant<int, 4>{});
+                iter(std::integral_constant<int, 5>{});
+                iter(std::integral_constant<int, 6>{});
+                iter(std::integral_constant<int, 7>{});
+                if (!nx.valid()) break;
+                rec = nx;
+                ++n;
+            }
+        } else {
         for (int i = 0;; i += 2) {
             if (!(live & 3u)) break;
             body(std::integral_constant<int, 0>{}, i); // (steps 0, 2, ... are pooled here: set 0)
             if (!(live & 3u)) break;
             body(std::integral_constant<int, 1>{}, i + 1);
+        }
         }
         if (DIAG && a.diag && (a.debug & 0x80) && tid == ((a.debug >> 8) & 15) * 64)
             for (int k = 0; k < 8; ++k) a.diag[(size_t)blockIdx.x * 8 + k] = stamp[k];
