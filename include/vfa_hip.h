@@ -220,6 +220,14 @@ size_t vfa_collapse_gemm_workspace_bytes(int K, int N);
 int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, void *workspace, size_t workspace_bytes, size_t M,
                           int K, int N, int flags, void *stream);
 
+/* Training backward behind the fused forward (which kept no pre-activations): the same product, recomputed, with the ReLU mask as
+ * its epilogue --  grad_lin (n_views, cells, 256) = (vox . weight^T + bias > 0) ? grad_out[cell] : 0,  grad_bias (256) += column
+ * sums (atomics; may be NULL).  `lin` is never written.  vox (n_views * cells, K), weight (256, K), grad_out (cells, 256).
+ *   replaces the autograd of vfa_op.py:123-124 (Linear + ReLU) for the gradient w.r.t. the pre-activation; trainer.py:41 */
+int vfa_collapse_gemm_relu_backward_f32(const float *vox, const float *weight, const float *bias, const float *grad_out,
+                                        float *grad_lin, float *grad_bias, void *workspace, size_t workspace_bytes, int n_views,
+                                        size_t cells, int K, int N, int flags, void *stream);
+
 /* ---- single-layer grids (nl = 1), C = c_out = 256, inference: the whole frame in two launches ------------------------------
  *
  * vfa_frame_records_f32: geometry ONCE per frame.  Every (view, cell) cube is projected once (vfa_op.py:64-88,

@@ -266,3 +266,23 @@ def test_fused_training_forward_gives_the_gradients_of_the_unfused_path(name, n_
         close(gw1[k], w64[k].grad, f"d weight{k} vs float64", 0.1)
         close(gb1[k], b64[k].grad, f"d bias{k} vs float64", 0.1)
     assert all(e <= t for _, e, t in errs), [x for x in errs if x[1] > x[2]]
+
+
+@pytest.mark.parametrize("n,cells,K", [(3, 1000, 256), (2, 333, 1280), (1, 128, 256)])
+def test_relu_mask_epilogue_equals_product_then_mask(n, cells, K):
+    """`vfa_collapse_gemm_relu_backward_f32` (the ReLU mask and d b as the epilogue of the recomputed product: the pre-activations
+    are never written) against `vfa_collapse_gemm_f32` + `vfa_relu_mask_backward_f32`: d lin BITWISE (same product, same
+    comparison), d b up to the order of its atomics."""
+    from vfa_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n * 7 + K)
+    vox = torch.relu(torch.randn(n, cells, K, generator=g)).to(dev)
+    w = (torch.randn(256, K, generator=g) / K ** 0.5).to(dev)
+    b = (torch.randn(256, generator=g) * 0.2).to(dev)
+    gout = torch.randn(cells, 256, generator=g).to(dev)
+    glin, gb = ops.collapse_gemm_relu_backward(vox, w, b, gout, terms=3)
+    lin = ops.collapse_gemm(vox.view(n * cells, K), w, terms=3).view(n, cells, 256)
+    want_glin, want_gb = ops.relu_mask_backward(gout, lin, b)
+    assert torch.equal(glin, want_glin)
+    assert 0.2 < (glin != 0).float().mean().item() < 0.8
+    torch.testing.assert_close(gb, want_gb, rtol=1e-4, atol=1e-4 * want_gb.abs().max().item())

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vfa_scale_view_sum_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _vp],
     "vfa_collapse_gemm_workspace_bytes": [_c_int, _c_int],
     "vfa_collapse_gemm_f32": [_vp, _vp, _vp, _vp, _c_size_t, _c_size_t, _c_int, _c_int, _c_int, _vp],
+    "vfa_collapse_gemm_relu_backward_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_size_t, _c_int, _c_int, _c_int, _vp],
     "vfa_collapse_relu_sum_f32": [_vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_integral_images_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp],
     "vfa_integral_images_hwc_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp],

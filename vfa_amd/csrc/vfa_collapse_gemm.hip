@@ -71,9 +71,19 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float *__restri
     ws[base + 64] = lo.u;
 }
 
-template <int TERMS>
+// MASK: the epilogue of the training backward (vfa_collapse_gemm_relu_backward_f32).  The product is the recomputed pre-activation;
+// instead of storing it the kernel stores  d lin = (lin + bias > 0) ? d out[cell] : 0  (row m = view * cells + cell: the gradient
+// of the view sum reaches every view alike) and adds the column sums of d lin to d bias -- `lin` never exists in memory.
+struct MaskArgs {
+    const float *bias;   // (256) or NULL
+    const float *grad;   // (cells, 256): d out
+    float *gbias;        // (256), accumulated with atomics (like vfa_relu_mask_backward_f32), or NULL
+    long long cells;
+};
+
+template <int TERMS, bool MASK>
 __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__restrict__ vox, const uint4 *__restrict__ ws,
-                                                               float *__restrict__ lin, long long M, int K)
+                                                               float *__restrict__ lin, long long M, int K, MaskArgs ma)
 {
     extern __shared__ __align__(16) unsigned char planes[]; // [buffer][hi / lo][128 rows][256 B]
     int *live = reinterpret_cast<int *>(planes + 2 * 2 * kPlane); // [item % 3][row block]: the chunk has a non-zero element there
@@ -165,6 +175,8 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
     load_w(w1, 0, 1);
     __syncthreads();
     int buf = 0, slot = 0;
+    float bias_c = 0.0f, gb = 0.0f; // MASK: this lane's column (32 wave + r): its bias, its running column sum of d lin
+    if constexpr (MASK) bias_c = ma.bias ? ma.bias[wave * 32 + r] : 0.0f;
     for (; tile < n_tiles; tile += gridDim.x) {
 #pragma unroll
         for (int rb = 0; rb < kRowBlocks; ++rb)
@@ -192,11 +204,33 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
         for (int rb = 0; rb < kRowBlocks; ++rb) {
             const long long row0 = tile * kTileRows + rb * 32;
             float *orow = lin + (size_t)row0 * kN + wave * 32 + r;
+            // MASK: the cell of the block's first row, once per block and in scalar registers (row0 is the same in every lane); a
+            // row then adds its offset and wraps at most once (cells >= 32: the host checks) -- a 64-bit modulo per element cost
+            // more than the product at K = 256
+            long long cell0 = 0;
+            if constexpr (MASK) cell0 = (long long)__builtin_amdgcn_readfirstlane((int)(row0 % ma.cells));
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (row0 + row < M) orow[(size_t)row * kN] = acc[rb][i];
+                if (row0 + row < M) {
+                    if constexpr (MASK) {
+                        long long cell = cell0 + row;
+                        cell = cell >= ma.cells ? cell - ma.cells : cell;
+                        const float g = ma.grad[(size_t)cell * kN + wave * 32 + r];
+                        const float o = (acc[rb][i] + bias_c > 0.0f) ? g : 0.0f;
+                        orow[(size_t)row * kN] = o;
+                        gb += o;
+                    } else {
+                        orow[(size_t)row * kN] = acc[rb][i];
+                    }
+                }
             }
+        }
+    }
+    if constexpr (MASK) {
+        if (ma.gbias) {
+            gb += __shfl_xor(gb, 32); // the two row halves of the column
+            if (h == 0) unsafeAtomicAdd(ma.gbias + wave * 32 + r, gb);
         }
     }
 }
@@ -209,8 +243,8 @@ extern "C" size_t vfa_collapse_gemm_workspace_bytes(int K, int N)
     return (size_t)K * (size_t)N * 4;
 }
 
-extern "C" int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, void *workspace, size_t workspace_bytes,
-                                     size_t M, int K, int N, int flags, void *stream)
+static int collapse_gemm_launch(const float *vox, const float *weight, float *out, void *workspace, size_t workspace_bytes, size_t M,
+                                int K, int N, int flags, const MaskArgs *mask, void *stream)
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
     if (flags & ~(VFA_FLAG_TERMS_MASK | 0xff00)) return VFA_ERR_BAD_ARGUMENT;
@@ -221,10 +255,12 @@ extern "C" int vfa_collapse_gemm_f32(const float *vox, const float *weight, floa
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false; // idempotent: a race only repeats the call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)collapse_gemm_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)collapse_gemm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        if (e != hipSuccess) return (int)e;
+        const void *fns[4] = {(const void *)collapse_gemm_kernel<3, false>, (const void *)collapse_gemm_kernel<4, false>,
+                              (const void *)collapse_gemm_kernel<3, true>, (const void *)collapse_gemm_kernel<4, true>};
+        for (const void *fn : fns) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
     int n_cu = 256;
@@ -248,11 +284,38 @@ extern "C" int vfa_collapse_gemm_f32(const float *vox, const float *weight, floa
     long long wgs = (n_tiles + rounds - 1) / rounds;
     if (wgs > n_cu) wgs = n_cu;
     const unsigned blocks = (unsigned)wgs;
-    if (terms == 4)
-        hipLaunchKernelGGL((collapse_gemm_kernel<4>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, lin,
-                           (long long)M, K);
-    else
-        hipLaunchKernelGGL((collapse_gemm_kernel<3>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, lin,
-                           (long long)M, K);
+    const MaskArgs none = {nullptr, nullptr, nullptr, 1};
+    if (mask) {
+        if (terms == 4)
+            hipLaunchKernelGGL((collapse_gemm_kernel<4, true>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, out,
+                               (long long)M, K, *mask);
+        else
+            hipLaunchKernelGGL((collapse_gemm_kernel<3, true>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, out,
+                               (long long)M, K, *mask);
+    } else {
+        if (terms == 4)
+            hipLaunchKernelGGL((collapse_gemm_kernel<4, false>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, out,
+                               (long long)M, K, none);
+        else
+            hipLaunchKernelGGL((collapse_gemm_kernel<3, false>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, out,
+                               (long long)M, K, none);
+    }
     return (int)hipGetLastError();
+}
+
+extern "C" int vfa_collapse_gemm_f32(const float *vox, const float *weight, float *lin, void *workspace, size_t workspace_bytes,
+                                     size_t M, int K, int N, int flags, void *stream)
+{
+    return collapse_gemm_launch(vox, weight, lin, workspace, workspace_bytes, M, K, N, flags, nullptr, stream);
+}
+
+extern "C" int vfa_collapse_gemm_relu_backward_f32(const float *vox, const float *weight, const float *bias, const float *grad_out,
+                                                   float *grad_lin, float *grad_bias, void *workspace, size_t workspace_bytes,
+                                                   int n_views, size_t cells, int K, int N, int flags, void *stream)
+{
+    if (n_views < 0 || !grad_out || !grad_lin) return VFA_ERR_BAD_ARGUMENT;
+    if (n_views == 0 || cells == 0) return 0;
+    if (cells < 32 || cells >= (1ull << 31)) return VFA_ERR_UNSUPPORTED; // (a 32-row block wraps over the cells at most once)
+    const MaskArgs ma = {bias, grad_out, grad_bias, (long long)cells};
+    return collapse_gemm_launch(vox, weight, grad_lin, workspace, workspace_bytes, (size_t)n_views * cells, K, N, flags, &ma, stream);
 }

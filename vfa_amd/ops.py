@@ -386,6 +386,29 @@ def collapse_gemm(vox2d, weight, out=None, terms=0, reserved_cus=0):
     return out
 
 
+def collapse_gemm_relu_backward(vox, weight, bias, grad_out, terms=0, reserved_cus=0):
+    """Training backward behind the fused forward: vox (n, cells, K), weight (256, K) (columns in the order of vox), bias (256) or
+    None, grad_out (cells, 256) -> (grad_lin (n, cells, 256) = (vox . W^T + b > 0) ? grad_out : 0, grad_bias (256)) with the ReLU mask
+    as the epilogue of the recomputed product (``vfa_collapse_gemm_relu_backward_f32``): the pre-activations never reach memory."""
+    _lib.require_device(vox, weight, bias, grad_out)
+    vox, weight, grad_out = _f32c(vox), _f32c(weight), _f32c(grad_out)
+    n, cells, K = vox.shape
+    assert tuple(weight.shape) == (256, K) and tuple(grad_out.shape) == (cells, 256)
+    bias = None if bias is None else _f32c(bias)
+    dev = vox.device
+    glin = torch.empty((n, cells, 256), dtype=torch.float32, device=dev)
+    gbias = torch.zeros(256, dtype=torch.float32, device=dev)
+    need = _lib.lib().vfa_collapse_gemm_workspace_bytes(K, 256)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _gemm_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _gemm_ws[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    _launch("vfa_collapse_gemm_relu_backward_f32", _lib.ptr(vox), _lib.ptr(weight), _lib.ptr(bias) if bias is not None else None,
+            _lib.ptr(grad_out), _lib.ptr(glin), _lib.ptr(gbias), _lib.ptr(ws), ws.numel(), n, cells, K, 256,
+            _lib.collapse_flags(terms, reserved_cus), _lib.current_stream_handle(), tag=(n, cells, K))
+    return glin, gbias
+
+
 def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_hws, weights=None, crange=(-1, 0.95),
                   workspace=None, row_slots=None, cuts=True):
     """Geometry of one frame for the fused inference kernel (``pool_collapse``): box records of every (view, cell) for each

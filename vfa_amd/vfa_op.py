@@ -353,10 +353,14 @@ class _FusedFrameTrain(torch.autograd.Function):
                     count = min(chunk, n_cells - begin)
                     vox = ops.project_gather(integral, cal, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h), crange,
                                              cell_begin=begin, cell_count=count)
-                    # (the product of the forward: the same bf16-split MFMA arithmetic decides the ReLU mask)
-                    lin = ops.collapse_gemm(vox.view(n * count, nl * C), w_lm, terms=COLLAPSE_TERMS).view(n, count, C)
-                    g_lin, g_b_part = ops.relu_mask_backward(grad_out[begin:begin + count], lin, b)
-                    del lin
+                    # (the product of the forward -- the same bf16-split MFMA arithmetic decides the ReLU mask -- with the mask as its
+                    # epilogue: d lin and d b come out, the pre-activations are never written)
+                    if count >= 32:
+                        g_lin, g_b_part = ops.collapse_gemm_relu_backward(vox, w_lm, b, grad_out[begin:begin + count], terms=COLLAPSE_TERMS)
+                    else:  # (fewer than 32 cells in the chunk: product, then the mask kernel)
+                        lin = ops.collapse_gemm(vox.view(n * count, nl * C), w_lm, terms=COLLAPSE_TERMS).view(n, count, C)
+                        g_lin, g_b_part = ops.relu_mask_backward(grad_out[begin:begin + count], lin, b)
+                        del lin
                     if need_b:
                         g_b += g_b_part
                     g2 = g_lin.view(n * count, C)
