@@ -52,6 +52,9 @@ def parse():
     p.add_argument("--workload", default=PRIMARY,
                    help="named workload of vfa_amd.synthetic.WORKLOADS (default: BASELINE.json configs[1])")
     p.add_argument("--channels", type=int, default=256)
+    p.add_argument("--collective", choices=["reduce", "all_reduce"], default="reduce",
+                   help="N > 1: how the partial BEV maps are fused: `reduce` onto rank 0, the rank that runs the heads (north_star: "
+                        "'an RCCL reduce over xGMI to form the fused voxel grid'; half the traffic), or `all_reduce`")
     p.add_argument("--scaling", choices=["weak", "strong"], default=None,
                    help="strong (default for N > 1): the frame's cameras are split over ranks; weak: n_cam cameras per rank")
     p.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 disables)")
@@ -191,6 +194,7 @@ class Leg:
         self.pending = []
         self.k = 0
         self.collective = True  # (False: the same steps without the collective: per-rank compute time)
+        self.mode = getattr(a, "collective", "reduce")  # "reduce" -> rank 0 or "all_reduce"
 
     def step(self):
         torch, vfa_amd = self.torch, self.vfa_amd
@@ -200,10 +204,12 @@ class Leg:
             if not self.collective:
                 return vfa_amd.aggregate_views(*self.mods, *lats, self.calibs, self.grid, distributed=False)
             if not self.overlap:
-                return vfa_amd.aggregate_views(*self.mods, *lats, self.calibs, self.grid, distributed=self.world > 1)
+                how = ("reduce" if self.mode == "reduce" else True) if self.world > 1 else False
+                return vfa_amd.aggregate_views(*self.mods, *lats, self.calibs, self.grid, distributed=how)
             while self.pending:
                 self.pending.pop().wait()  # frame i-1 is fused before frame i's collective is queued
-            self.pending.append(vfa_amd.aggregate_views(*self.mods, *lats, self.calibs, self.grid, distributed="async"))
+            self.pending.append(vfa_amd.aggregate_views(*self.mods, *lats, self.calibs, self.grid,
+                                                        distributed="async_reduce" if self.mode == "reduce" else "async"))
 
     def drain(self):
         while self.pending:
@@ -605,7 +611,7 @@ def main():
                                     "reduce_to_rank0": coll_ms(lambda: reduce_ortho(probe, 0)),
                                     "reduce_scatter_rows_halo4": coll_ms(lambda: reduce_scatter_ortho(probe, leg.L, leg.W, halo=4))},
             "note": "ms_compute: the same steps with the collective switched off (MAX over ranks); ms_collective_exposed = ms_per_step - "
-                    "ms_compute (the all-reduce of frame i runs beside the projection of frame i + 1); collective_alone_ms: one "
+                    "ms_compute (the collective of frame i -- config.collective -- runs beside the projection of frame i + 1); collective_alone_ms: one "
                     "collective of the map at a time, nothing else on the GPUs"}
         del probe
     # ---- BASELINE.json configs[4]: synthetic 8 x 4K -> 512 x 512 x 32, cameras sharded over the ranks
@@ -666,9 +672,11 @@ def main():
                        "feature_maps": [list(s) for s in leg.wl["feat_sizes"]], "grid": [L, W, nl],
                        "units_per_step": leg.units_step,
                        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-                       "parallelism": (f"camera-sharded dp{world} ({scaling}), RCCL all-reduce of the BEV map"
+                       "parallelism": (f"camera-sharded dp{world} ({scaling}), RCCL "
+                                       + ("reduce of the BEV map onto rank 0" if leg.mode == "reduce" else "all-reduce of the BEV map")
                                        + (" overlapped with the next frame" if leg.overlap else "")) if world > 1
-                       else "single GPU"},
+                       else "single GPU",
+                       **({"collective": leg.mode} if world > 1 else {})},
             "bev_cells_per_s": nl * L * W * a.steps / dt,
             "roofline": roofline,
             "kernels": kernels,

@@ -31,7 +31,7 @@ def test_bench_spawns_its_own_ranks_and_shards_cameras():
     p = _run(["--gpus", "2"] + FAST, env={} if two_gpus else {"VFA_BENCH_BACKEND": "gloo"})
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["collective"] == "reduce"
     assert line["scaling"] == "strong" and line["config"]["workload"] == "multiviewc_200x200x1"
     assert line["config"]["cameras_total"] == 7 and line["config"]["cameras_per_rank"] == 4  # rank 0: cameras 0,2,4,6
     assert line["config"]["units_per_step"] == 7 * 3 * 200 * 200

@@ -95,6 +95,16 @@ def _async_worker(rank, world, port, out_dir):
             assert tuple(got.shape) == (1, 4, 2, 3)
             assert torch.all(got == sum(r + 1 + 10 * frame for r in range(world)))
             assert p.wait() is not None  # idempotent
+        # distributed="async_reduce": the sum lands on rank 0 only (what bench.py --gpus N uses by default)
+        maps = []
+        for frame in range(3):
+            part = torch.full((6, 4), float(rank + 1 + 10 * frame))
+            work = dist.reduce(part, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+            maps.append(PendingOrtho(part, work, (2, 3, 4)))
+        for frame, p in enumerate(maps):
+            got = p.wait()
+            if rank == 0:
+                assert torch.all(got == sum(r + 1 + 10 * frame for r in range(world)))
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

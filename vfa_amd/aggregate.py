@@ -211,7 +211,7 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     -> ortho (1,C,L,W): a permuted view of the channels-last buffer, like the reference returns.
     With ``distributed=True`` the partial sums of all ranks are all-reduced before returning; with
     ``distributed="async"`` (inference) the all-reduce is only launched and a ``PendingOrtho`` is returned, so that
-    the collective of frame i overlaps the projection of frame i+1.  ``distributed="reduce"``: the fused map lands on rank 0
+    the collective of frame i overlaps the projection of frame i+1 (``"async_reduce"``: the same with a reduce onto rank 0).  ``distributed="reduce"``: the fused map lands on rank 0
     only; ``distributed="reduce_scatter"``: every rank gets its band of BEV rows plus the 4-row halo of the heads' dilated
     convolutions and the call returns ``(band (1,C,rows,W), (row0, row1), (top, bottom))`` (``reduce_scatter_ortho``).
     ``integrals``: the three integral-image batches instead of the lateral maps (producer fusion, inference on the fused frame
@@ -276,10 +276,16 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     else:  # a rank without cameras (8 GPUs, 7 cameras) contributes zeros
         ortho = torch.zeros((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
     c_out = vfa8.collapse.out_features
-    if distributed == "async":
+    if distributed in ("async", "async_reduce"):
+        # ("async_reduce": the sum lands on rank 0 only -- the rank that runs the heads --, half the traffic of the all-reduce; the
+        # other ranks' maps are unspecified after the wait)
         work = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(reduce_group) > 1:
-            work = dist.all_reduce(ortho, op=dist.ReduceOp.SUM, group=reduce_group, async_op=True)
+            if distributed == "async":
+                work = dist.all_reduce(ortho, op=dist.ReduceOp.SUM, group=reduce_group, async_op=True)
+            else:
+                dst = dist.get_global_rank(reduce_group, 0) if reduce_group is not None else 0
+                work = dist.reduce(ortho, dst=dst, op=dist.ReduceOp.SUM, group=reduce_group, async_op=True)
         return PendingOrtho(ortho, work, (length, width, c_out))
     if distributed == "reduce":  # the fused map on rank 0 only (the caller runs the heads there)
         ortho = reduce_ortho(ortho, 0, reduce_group)
