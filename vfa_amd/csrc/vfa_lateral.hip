@@ -11,7 +11,8 @@
 // operands (bench frame: 11.5 GFLOP = 75 us against 225 MB = 28 us), so nothing cheaper is worth its rounding.
 //
 // Tiling: a workgroup of four waves takes 128 consecutive pixels of one view; wave w owns pixels 32 w .. 32 w + 31 and ALL 256
-// output channels (eight 32 x 32 accumulators = 128 registers) -- or, on the small maps, 64 / 32 pixels with the channels split
+// output channels (eight 32 x 32 accumulators = 128 registers; the CHANNELS are the rows of the MFMA, so that a lane ends up with
+// four consecutive channels of one pixel per register quad: 16-byte channels-last stores) -- or, on the small maps, 64 / 32 pixels with the channels split
 // over two / four waves (lateral_conv_kernel<PXW>).  A operands come straight from HBM: the NCHW input is
 // k-major, so lane (pixel p, k half) loads feat[k][p] -- 32 consecutive floats per half wave, no LDS, no transpose.  B operands
 // (the weight, reference layout (256, K)) are staged through LDS in chunks of 32 k, transposed on the way in ([k][co], so that a
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kThreads, 2) void lateral_conv_kernel(LateralArgs a
             }
             __builtin_amdgcn_sched_barrier(0); // (the scheduler otherwise sinks every read to just in front of its MFMA)
 #pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk], bcur[cb], acc[cb], 0, 0, 0);
+            for (int cb = 0; cb < CBW; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bcur[cb], areg[kk], acc[cb], 0, 0, 0); // D[channel][pixel]
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < CBW; ++cb) bcur[cb] = bnxt[cb];
@@ -124,37 +125,43 @@ __global__ __launch_bounds__(kThreads, 2) void lateral_conv_kernel(LateralArgs a
     }
 
     // epilogue: + bias, channels-last store, GroupNorm partial sums (double: the variance is a difference of two of them).
-    // Register i of lane (col, kh) of block cb is pixel p0 + (i & 3) + 8 (i >> 2) + 4 kh, channel 32 cb + col.
-    float *orow = a.out + (size_t)v * a.HW * kCo;
+    // The weight is the MFMA's row operand, so lane (col, kh) holds PIXEL p0 + col and register i of block cb is channel
+    // 32 cb + (i & 3) + 8 (i >> 2) + 4 kh: four consecutive channels per i >> 2 -- one 16-byte store each (with the pixels as rows a
+    // lane held one channel of 16 pixels and stored 4 bytes at a time: 70 of the 255 us of the stride-8 map).
+    const int p = p0 + col;
+    const bool on = p < a.HW;
+    float *orow = a.out + ((size_t)v * a.HW + (on ? p : 0)) * kCo;
     const int parts = a.blocks * PXW;
 #pragma unroll
     for (int cbi = 0; cbi < CBW; ++cbi) {
         const int cb = cb0 + cbi;
-        const float bc = a.bias[cb * 32 + col];
-        double s1 = 0.0, s2 = 0.0;
+        double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0}; // the block's two groups: channels 0..15 (i < 8) and 16..31
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int p = p0 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-            const float y = acc[cbi][i] + bc;
-            if (p < a.HW) {
-                orow[(size_t)p * kCo + cb * 32 + col] = y;
-                s1 += (double)y;
-                s2 += (double)y * (double)y;
+        for (int g = 0; g < 4; ++g) {
+            const int c = cb * 32 + 8 * g + 4 * kh;
+            const float4 bc = *reinterpret_cast<const float4 *>(a.bias + c);
+            const float4 y = make_float4(acc[cbi][4 * g + 0] + bc.x, acc[cbi][4 * g + 1] + bc.y, acc[cbi][4 * g + 2] + bc.z,
+                                         acc[cbi][4 * g + 3] + bc.w);
+            if (on) {
+                *reinterpret_cast<float4 *>(orow + c) = y;
+                s1[g >> 1] += ((double)y.x + (double)y.y) + ((double)y.z + (double)y.w);
+                s2[g >> 1] += ((double)y.x * (double)y.x + (double)y.y * (double)y.y) + ((double)y.z * (double)y.z + (double)y.w * (double)y.w);
             }
         }
-        // the 16 channels of a group are 16 neighbouring lanes; then the two k halves (lanes l and l + 32 hold different pixels)
+        // over the wave's 32 pixels x 2 channel halves: a fixed butterfly
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            s1 += __shfl_xor(s1, d);
-            s2 += __shfl_xor(s2, d);
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                s1[q] += __shfl_xor(s1[q], d);
+                s2[q] += __shfl_xor(s2[q], d);
+            }
         }
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if ((lane & 15) == 0 && kh == 0) {
-            const int g = cb * 2 + (col >> 4);
+        if (lane < 2) {
+            const int g = cb * 2 + lane;
             double *pp = a.partial + (((size_t)v * kGroups + g) * (size_t)parts + (size_t)blk * PXW + pbw) * 2;
-            pp[0] = s1;
-            pp[1] = s2;
+            pp[0] = lane == 0 ? s1[0] : s1[1];
+            pp[1] = lane == 0 ? s2[0] : s2[1];
         }
     }
 }
@@ -167,24 +174,26 @@ struct FinalArgs {
     double count;              // H * W * 16
     float eps;
 };
-// one workgroup per view, thread = channel: the 16 threads of a group share out its partial sums (thread j takes parts j, j + 16,
-// ...: the loads of the 16 chains overlap -- ONE chain of 452 dependent loads per thread took 200 us on the bench frame), then a
-// fixed butterfly over the 16 lanes (no atomics: the same bits on every run), then scale = gamma * rstd,
-// shift = beta - mean * scale (the affine of nn.GroupNorm, vfanet.py:40-42)
-__global__ __launch_bounds__(kCo) void lateral_stats_kernel(FinalArgs a)
+// one wave per (view, group): lane j adds the partial sums j, j + 64, ... (64 chains in flight: ONE chain of 452 dependent loads per
+// thread took 200 us on the bench frame, 16 chains per group 15), then a fixed butterfly (no atomics: the same bits on every run), then
+// lanes 0..15 write scale = gamma * rstd, shift = beta - mean * scale of the group's channels (the affine of nn.GroupNorm,
+// vfanet.py:40-42)
+__global__ __launch_bounds__(kWave) void lateral_stats_kernel(FinalArgs a)
 {
-    const int v = blockIdx.x, c = threadIdx.x, g = c >> 4, j = c & 15;
+    const int v = blockIdx.x / kGroups, g = blockIdx.x % kGroups, j = threadIdx.x;
     const double *pp = a.partial + ((size_t)v * kGroups + g) * (size_t)a.parts * 2;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = j; i < a.parts; i += 16) {
+    for (int i = j; i < a.parts; i += kWave) {
         s1 += pp[2 * i];
         s2 += pp[2 * i + 1];
     }
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
+    for (int d = 1; d < kWave; d <<= 1) {
         s1 += __shfl_xor(s1, d);
         s2 += __shfl_xor(s2, d);
     }
+    if (j >= kCo / kGroups) return;
+    const int c = g * (kCo / kGroups) + j;
     const double mean = s1 / a.count;
     double var = s2 / a.count - mean * mean; // (biased, like nn.GroupNorm)
     if (var < 0.0) var = 0.0;
@@ -220,7 +229,8 @@ int vfa_lateral_conv_f32(const float *feat, const float *weight, const float *bi
 {
     if (!feat || !weight || !bias || !gamma || !beta || !out_hwc || !scale || !shift || n_views < 0 || K <= 0 || H <= 0 || W <= 0)
         return VFA_ERR_BAD_ARGUMENT;
-    if (K % kKc != 0 || (reinterpret_cast<uintptr_t>(weight) & 15) != 0) return VFA_ERR_UNSUPPORTED; // (ResNet laterals: K = 128, 256, 512)
+    if (K % kKc != 0 || ((reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(out_hwc)) & 15) != 0)
+        return VFA_ERR_UNSUPPORTED; // (ResNet laterals: K = 128, 256, 512; 16-byte loads / stores)
     if (n_views == 0) return 0;
     if ((long long)H * W >= (1ll << 31) - kTilePx || n_views > 65535) return VFA_ERR_UNSUPPORTED;
     const size_t need = vfa_lateral_conv_workspace_bytes(n_views, H, W);
@@ -239,7 +249,7 @@ int vfa_lateral_conv_f32(const float *feat, const float *weight, const float *bi
     FinalArgs f;
     f.partial = a.partial; f.gamma = gamma; f.beta = beta; f.scale = scale; f.shift = shift;
     f.parts = a.blocks * pxw; f.count = (double)a.HW * (kCo / kGroups); f.eps = eps;
-    hipLaunchKernelGGL(lateral_stats_kernel, dim3((unsigned)n_views), dim3(kCo), 0, s, f);
+    hipLaunchKernelGGL(lateral_stats_kernel, dim3((unsigned)n_views * kGroups), dim3(kWave), 0, s, f);
     return (int)hipGetLastError();
 }
 
