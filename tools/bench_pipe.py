@@ -100,7 +100,8 @@ with torch.no_grad():
             steps = d[:, 7]
             per = d[:, :7].sum(0) / steps.sum()
             role = "pool" if wave >= 8 else "matrix"
-            print(f"  wave {wave:2d} ({role}): cycles per step " + ", ".join(f"{names[k]} {per[k]:.0f}" for k in range(7) if wave < 8 or k not in (1, 3, 4))
+            pool_names = ["step head", "window requests + pooling", "waiting for the requests to land", "", "", "tile finish", "barrier"]
+            print(f"  wave {wave:2d} ({role}): cycles per step " + ", ".join(f"{(names if wave < 8 else pool_names)[k]} {per[k]:.0f}" for k in range(7) if wave < 8 or k not in (3, 4))
                   + f" | total {per.sum():.0f}, steps per workgroup {steps.mean():.0f} (max/mean {steps.max() / steps.mean():.3f}), "
                   f"cycles per workgroup max/mean {d[:, :7].sum(1).max() / d[:, :7].sum(1).mean():.3f}")
 

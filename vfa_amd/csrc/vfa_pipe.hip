@@ -1095,6 +1095,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 if (W16 && m != 0 && (live & 4u) && !bare) step_dma(i + 1);
                 if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i);
                 if (W16 && m == 0 && (live & 4u) && !bare) step_dma(i + 1);
+                tick(1); // (pooling waves: slot 1 = requests + pooling, slot 2 = waiting for the next step's windows to land)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 tick(2);
             } else {
