@@ -105,6 +105,16 @@ with torch.no_grad():
                   + f" | total {per.sum():.0f}, steps per workgroup {steps.mean():.0f} (max/mean {steps.max() / steps.mean():.3f}), "
                   f"cycles per workgroup max/mean {d[:, :7].sum(1).max() / d[:, :7].sum(1).mean():.3f}")
 
+    if "--barrier" in sys.argv:
+        # diagnostic 32: cycles a wave waits at the step barrier, by the position of the step in its phase (i & 7)
+        for wave in (0, 1, 4, 8, 12, 15):
+            ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=128 | 32 | (wave << 8))
+            torch.cuda.synchronize()
+            d = ws[lay["diag"]:lay["diag"] + 512 * 64].cpu().numpy().view(np.uint64).reshape(512, 8).astype(np.float64)
+            d = d[d.sum(1) > 0]
+            print(f"  wave {wave:2d}: barrier wait per workgroup by step position 0..7 (thousand cycles): "
+                  + " ".join(f"{v / 1e3:.0f}" for v in d.mean(0)) + f" | total {d.sum(1).mean() / 1e3:.0f}")
+
     if "--fit" in sys.argv:
         # Per-workgroup cycles against what the workgroup had to do: the constants of the work-cut cost model (vfa_pipe_seq.h).
         ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws, terms=terms)

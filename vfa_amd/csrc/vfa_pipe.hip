@@ -432,9 +432,14 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     constexpr int kWinBytes = (TERMS == 6 ? kWinSlots3 : kWinSlots) * kQSlot;
     __shared__ __align__(16) unsigned char s_win[4 * kWinBytes];            // tap windows: [step parity][sub-tile of the set]
     __shared__ __align__(16) unsigned char s_planes[2 * kPieces * kPlaneBytes]; // A tiles: [step parity][piece]
-    __shared__ __align__(16) unsigned char s_rec[4 * kTileBoxes * kRecBytes]; // box records of the group's sub-tiles, one layer
+    // box records of the group's sub-tiles, one layer: one OBJECT per set (sub-tiles 0, 1 / 2, 3) -- while the pooling waves read the
+    // boxes of set 0 at the first step of a phase, the records of set 1 arrive by DMA, and the compiler drains every DMA in front of
+    // an LDS read of an object the DMA may write
+    __shared__ __align__(16) unsigned char s_rec0[2 * kTileBoxes * kRecBytes];
+    __shared__ __align__(16) unsigned char s_rec1[2 * kTileBoxes * kRecBytes];
     __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
     __shared__ unsigned s_misc[16];
+    __shared__ __align__(16) unsigned s_sc[kMaxScales][12];                 // per scale: integral, recs, wfrag, hdrs (lo, hi each), Hf, Wf, nl * n_views, -
     __shared__ __align__(16) unsigned s_phase[4][4];                        // phase records (wave 0): [phase & 3]{tile, views, w, -}
     __shared__ __align__(16) unsigned s_groups[kGroupRing][4];              // group records (wave 0), a ring: {tile, views, scale | nj << 15 | more << 20, -}
     __shared__ __align__(16) unsigned s_desc[4][8][2][8];                   // fetch descriptors (wave 0): [phase & 3][step of the phase][sub-tile]
@@ -483,6 +488,19 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 
     // The loop below exists twice, once per role (`POOL`): a wave never changes its role, and inside ONE loop the registers of
     // both roles would be live at once.  Both copies take the same steps, hence the same barriers.
+    // Per-scale constants in LDS: the kernel arguments live in memory (the scalar registers are full), and a table job that picks
+    // one of three pointers by scale became a chain of dependent scalar loads -- make_desc alone took ~4 000 cycles on the wave
+    // every other wave waits for.  One vector read of this table instead.
+    if (tid < kMaxScales) {
+        const int s3 = tid < a.n_scales ? tid : 0;
+        unsigned *d = &s_sc[tid][0];
+        const unsigned long long p0 = (unsigned long long)(size_t)a.sc[s3].integral, p1 = (unsigned long long)(size_t)a.sc[s3].recs,
+                                 p2 = (unsigned long long)(size_t)a.sc[s3].wfrag, p3 = (unsigned long long)(size_t)a.sc[s3].hdrs;
+        d[0] = (unsigned)p0; d[1] = (unsigned)(p0 >> 32); d[2] = (unsigned)p1; d[3] = (unsigned)(p1 >> 32);
+        d[4] = (unsigned)p2; d[5] = (unsigned)(p2 >> 32); d[6] = (unsigned)p3; d[7] = (unsigned)(p3 >> 32);
+        d[8] = (unsigned)a.sc[s3].Hf; d[9] = (unsigned)a.sc[s3].Wf; d[10] = (unsigned)(a.nl * a.n_views); d[11] = (unsigned)a.n_views;
+    }
+    __syncthreads();
     auto run = [&](auto role_tag) {
         constexpr bool POOL = decltype(role_tag)::value;
         const int r = lane & 31, h = lane >> 5;           // matrix waves: row / column of the 32 x 32 block, k half
@@ -496,7 +514,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // The wave that runs the generator and fills the tables: matrix wave 0.  (On the last pooling wave -- they wait ~1 500 cycles
         // per step at the barrier -- the generator's scalar state no longer fits the scalar registers; what is spilled from them takes
         // vector registers of BOTH roles and the matrix loop spills: 23 scratch operations per step.)
-        const bool table_wave = wave == 0;
+        const bool table_wave = W16 ? wave == kMatWaves + 7 : wave == 0; // (sixteen waves: the LAST pooling wave -- the pooling
+        // waves wait 1 300-7 000 cycles at every step barrier, the matrix waves are the longer role)
         const int pb = lane >> 2, pi = lane & 3;          // ... box 0..15 of the wave's half sub-tile, 16-byte piece 0..3
 
         // ---------------------------------------------------------------- matrix-wave state
@@ -563,8 +582,18 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         };
 
         unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+        int dbg_pos = 0; // position of the current step in its phase (i & 7)
         auto tick = [&](int k) {
             if (DIAG) {
+                if (a.debug & 32) { // (diagnostic 32: only the wait at the step barrier, by position of the step in its phase)
+                    if (k == 5) t_prev = __builtin_amdgcn_s_memtime();
+                    else if (k == 6) {
+                        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_prev;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) stamp[q] += dbg_pos == q ? dt : 0ull; // (no dynamic index: the array stays in registers)
+                    }
+                    return;
+                }
                 const unsigned long long now = __builtin_amdgcn_s_memtime();
                 stamp[k] += now - t_prev;
                 t_prev = now;
@@ -649,8 +678,9 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             int j = lane >> 3;
             j = j < nj ? j : nj - 1;
             const int view = (int)((v.y >> (8 * j)) & 0xffu);
-            const unsigned long long item = (unsigned long long)((tile * a.nl + layer) * a.n_views + view);
-            const unsigned long long p = scale_ptr(scale, a.sc[0].hdrs, a.sc[1].hdrs, a.sc[2].hdrs) + item * kHdrBytes + (unsigned)(lane & 7) * 4u;
+            const uint4 c1 = *reinterpret_cast<const uint4 *>(&s_sc[scale][4]), c2 = *reinterpret_cast<const uint4 *>(&s_sc[scale][8]);
+            const unsigned long long item = (unsigned long long)((unsigned)tile * c2.z + (unsigned)layer * c2.w + (unsigned)view);
+            const unsigned long long p = ((unsigned long long)c1.w << 32 | c1.z) + item * kHdrBytes + (unsigned)(lane & 7) * 4u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                              (__attribute__((address_space(3))) void *)(&s_hdr[n & 3][0]), 4, 0, 0);
         };
@@ -663,13 +693,14 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const int jj = j < nj ? j : 0;
             const int view = (int)((v.y >> (8 * jj)) & 0xffu);
             const unsigned flags = s_hdr[n & 3][jj * 8 + 0], n_slots = s_hdr[n & 3][jj * 8 + 1];
-            const int Hf = scale == 0 ? a.sc[0].Hf : (scale == 1 ? a.sc[1].Hf : a.sc[2].Hf);
-            const int Wf = scale == 0 ? a.sc[0].Wf : (scale == 1 ? a.sc[1].Wf : a.sc[2].Wf);
-            const unsigned long long item = (unsigned long long)((tile * a.nl + layer) * a.n_views + view);
-            const unsigned long long img = scale_ptr(scale, a.sc[0].integral, a.sc[1].integral, a.sc[2].integral) +
+            const uint4 c0 = *reinterpret_cast<const uint4 *>(&s_sc[scale][0]), c1 = *reinterpret_cast<const uint4 *>(&s_sc[scale][4]),
+                        c2 = *reinterpret_cast<const uint4 *>(&s_sc[scale][8]);
+            const int Hf = (int)c2.x, Wf = (int)c2.y;
+            const unsigned long long item = (unsigned long long)((unsigned)tile * c2.z + (unsigned)layer * c2.w + (unsigned)view);
+            const unsigned long long img = ((unsigned long long)c0.y << 32 | c0.x) +
                                            (unsigned long long)view * (unsigned)((Hf + 2) * (Wf + 2)) * kSlotBytes + (unsigned)(q * kQSlot);
-            const unsigned long long rec = scale_ptr(scale, a.sc[0].recs, a.sc[1].recs, a.sc[2].recs) + item * (kTileBoxes * kRecBytes);
-            const unsigned long long wsl = scale_ptr(scale, a.sc[0].wfrag, a.sc[1].wfrag, a.sc[2].wfrag) +
+            const unsigned long long rec = ((unsigned long long)c0.w << 32 | c0.z) + item * (kTileBoxes * kRecBytes);
+            const unsigned long long wsl = ((unsigned long long)c1.y << 32 | c1.x) +
                                            (unsigned long long)(((unsigned)layer * 8u * kSteps + (unsigned)q * 4u) * (unsigned)kWPlanes * 64u) * 16u;
             const unsigned fw = j < nj ? ((flags & 0xffu) | (n_slots << 8)) : 0u;
             if (lane < 16) {
@@ -681,8 +712,9 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // Tap window (and, at the first quarter of a layer, the box records) of ONE sub-tile of step i: pooling waves 0-3 fetch for
         // the first sub-tile of the set, 4-7 for the second (the matrix waves are the longer role at four waves per SIMD: the fetch
         // cost each of them 1 500-2 400 cycles per step).  Addresses stay in vector registers (the same value in every lane).
-        auto step_dma = [&](int i) {
-            const int n = i >> 3, k = i & 7, x = dw >> 2, wq4 = dw & 3, j = 2 * (k & 1) + x;
+        auto step_dma = [&](auto set_tag, int i) { // (set_tag: i & 1, a fact of the caller's position in the unrolled loop)
+            constexpr int DSET = decltype(set_tag)::value;
+            const int n = i >> 3, k = i & 7, x = dw >> 2, wq4 = dw & 3, j = 2 * DSET + x;
             const uint4 *dp = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0]);
             const uint4 d0 = dp[0], d1 = dp[1];
             const uint4 *hp = reinterpret_cast<const uint4 *>(&s_hdr[n & 3][j * 8]);
@@ -692,7 +724,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             if ((k >> 1) == 0 && wq4 < 3) {
                 const unsigned long long p = ((unsigned long long)d0.w << 32 | d0.z) + (unsigned)(wq4 * 1024 + lane * 16);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
-                                                 (__attribute__((address_space(3))) void *)(s_rec + j * kTileBoxes * kRecBytes + wq4 * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)((DSET ? s_rec1 : s_rec0) + x * kTileBoxes * kRecBytes + wq4 * 1024), 16, 0, 0);
             }
             if ((fw & kTileDirect) || (DIAG && (a.debug & 1))) return; // (diagnostic 1: no window fills; the records still come)
             const int n_slots = fw >> 8;
@@ -866,8 +898,9 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 
         // ---------------------------------------------------------------- pooling of one step (pooling waves)
         // returns false when none of the wave's 16 boxes has anything to pool (all masked, none NaN): the wave then writes zeros
-        auto unpack = [&](LaneBox &bx, bool &glob, unsigned wp, int j, bool direct) -> bool {
-            const uint4 *rp = reinterpret_cast<const uint4 *>(s_rec + j * kTileBoxes * kRecBytes) + (phalf * 16 + pb) * (kRecBytes / 16);
+        auto unpack = [&](auto set_tag, LaneBox &bx, bool &glob, unsigned wp, int x, bool direct) -> bool {
+            constexpr int USET = decltype(set_tag)::value;
+            const uint4 *rp = reinterpret_cast<const uint4 *>((USET ? s_rec1 : s_rec0) + x * kTileBoxes * kRecBytes) + (phalf * 16 + pb) * (kRecBytes / 16);
             uint4 rv[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) rv[k] = rp[k];
@@ -977,7 +1010,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     const uint4 d1 = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0])[1];
                     const int fw = uniform_i((int)d1.x);
                     live = (fw & kTileLive) != 0;
-                    if (live) live = unpack(bx, glob, d1.w, j, (fw & kTileDirect) != 0);
+                    if (live) live = unpack(set_tag, bx, glob, d1.w, x, (fw & kTileDirect) != 0);
                 }
                 if (!live) { // no live box in this layer (or no such sub-tile in the group): the matrix waves multiply zeros
                     const int row = x * 32 + phalf * 16 + pb;
@@ -1068,10 +1101,15 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         empty_tiles(k_begin == 0 ? t_begin : t_begin + 1, rec.valid() ? rec.tile : t_end);
         if (!rec.valid()) return;
         if (table_wave) hdr_dma(0);
+        if (W16 && table_wave) { // (sixteen waves: the tables run a phase further ahead, see `body`)
+            gen_phase(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            hdr_dma(1);
+        }
         lds_fence_barrier();
         if (table_wave) make_desc(0);
         lds_fence_barrier();
-        if constexpr (POOL == W16) step_dma(0);
+        if constexpr (POOL == W16) step_dma(std::integral_constant<int, 0>{}, 0);
         if constexpr (!POOL) {
             w_addr(0);
 #pragma unroll
@@ -1085,16 +1123,29 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         auto body = [&](auto pset_tag, int i) {
             constexpr int PSET = decltype(pset_tag)::value, MSET = PSET ^ 1;
             const int m = i & 7;
+            dbg_pos = m;
             tick(0);
             if constexpr (POOL) {
                 if (m == 0 && i > 0) rec = phase_rec(i >> 3);
-                // the next step's windows first, so that they land under this step's pooling -- except at the first step of a phase,
-                // where this wave still has to read its boxes out of the record buffer the fetch of step i + 1 shares (the compiler
-                // drains the DMA in front of any LDS read of the same object)
+                // the next step's windows (and records) first, so that they land under this step's pooling
                 const bool bare = DIAG && (a.debug & 64); // (diagnostic 64: the loop, the tables and the barrier only)
-                if (W16 && m != 0 && (live & 4u) && !bare) step_dma(i + 1);
+                // The tables of the next phase (see `tables and DMA`: steps 4, 5, 6 of this one), FIRST in the step: make_desc reads
+                // the header buffer, a DMA target -- behind this step's window requests the compiler drains them in front of that
+                // read, and the table wave was 3 000-4 500 cycles late at every sixth step.
+                // (make_desc reads the header buffer, a DMA target: behind this step's window requests the compiler would drain them
+                // in front of that read -- so it goes first, at a point where this wave has nothing in flight)
+                if (W16 && table_wave && m == 0) make_desc((i >> 3) + 1);
+                if (W16 && (live & 4u) && !bare) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
                 if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i);
-                if (W16 && m == 0 && (live & 4u) && !bare) step_dma(i + 1);
+                // The tables (see `tables and DMA`), a phase further ahead than on twelve waves and behind the pooling: the descriptors
+                // of phase n + 1 (~1 000 cycles; its headers were requested a phase ago) in the FIRST step of phase n, where the
+                // matrix waves end a group (relu, view sum, tile store) and the pooling waves wait longest at the barrier; the record
+                // of phase n + 2 (~550) and the request for its headers (~300) in the two steps behind.  In one step (any) the three
+                // together made every wave wait for the table wave.
+                if (W16 && table_wave) {
+                    if (m == 1) gen_phase((i >> 3) + 2);
+                    else if (m == 2) hdr_dma((i >> 3) + 2);
+                }
                 tick(1); // (pooling waves: slot 1 = requests + pooling, slot 2 = waiting for the next step's windows to land)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 tick(2);
@@ -1105,7 +1156,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 tick(1);
                 if (m == 1 && i > 1) rec = phase_rec((i - 1) >> 3);
-                if (table_wave) { // the tables of the next phase (see `tables and DMA`)
+                if (!W16 && table_wave) { // the tables of the next phase (see `tables and DMA`)
                     if (m == 4) gen_phase((i >> 3) + 1);
                     else if (m == 5) hdr_dma((i >> 3) + 1);
                     else if (m == 6) make_desc((i >> 3) + 1);
@@ -1113,7 +1164,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 // Twelve-wave layout: the matrix waves fetch.  The two matrix waves of a SIMD take their two jobs in opposite order
                 // (waves 0-3 request the next step's window and then multiply, waves 4-7 multiply first).
                 const bool dma_first = wave < 4;
-                if (!W16 && dma_first && (live & 4u)) step_dma(i + 1);
+                if (!W16 && dma_first && (live & 4u)) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
                 // (step i - 1 ends its group: the last quarter of the last layer, set 1 -- `rec` is still that step's phase)
                 const bool group_ends = MSET == 1 && ((i - 1) & 7) == 7 && (live & 1u) && rec.layer() == a.nl - 1;
                 if ((live & 1u) && !(DIAG && (a.debug & 64))) {
@@ -1126,7 +1177,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     multiply(std::integral_constant<int, MSET>{}, rec, (i - 1) & 7, MSET, next_chunk);
                     if (MSET == 1 && group_ends) group_end(rec);
                 }
-                if (!W16 && !dma_first && (live & 4u)) step_dma(i + 1);
+                if (!W16 && !dma_first && (live & 4u)) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (wave 0: the tables; the header DMA is waited for below)
                 if (!W16 || (table_wave && m == 5)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (what this wave fetched has landed)
                 tick(4);
@@ -1156,7 +1207,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             tick(6);
-            if (DIAG) stamp[7] += 1;
+            if (DIAG && !(a.debug & 32)) stamp[7] += 1;
             // the step that enters at i + 2: a new phase when (i + 2) & 7 == 0 (its record was written at step 4 of this phase)
             unsigned next_live = (live >> 2) & 1u;
             if (((i + 2) & 7) == 0 && next_live) next_live = uniform_i((int)s_phase[((i + 2) >> 3) & 3][0]) >= 0 ? 1u : 0u;
@@ -1169,7 +1220,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             // and the end of the group are facts of the code position; the phase record is read once per phase, the weight-slice
             // address comes from it by scalar arithmetic instead of an LDS read per chunk.
             auto w_set = [&](int scale, int layer, int q) {
-                const unsigned long long p = scale_ptr(scale, a.sc[0].wfrag, a.sc[1].wfrag, a.sc[2].wfrag) +
+                const uint2 wf = *reinterpret_cast<const uint2 *>(&s_sc[scale][4]);
+                const unsigned long long p = ((unsigned long long)wf.y << 32 | wf.x) +
                                              (unsigned long long)(((unsigned)layer * 8u * kSteps + (unsigned)q * 4u) * (unsigned)kWPlanes * 64u) * 16u;
                 w_lo = (unsigned)uniform_i((int)(unsigned)p); w_hi = (unsigned)uniform_i((int)(unsigned)(p >> 32));
             };
@@ -1181,14 +1233,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 PhaseRec nx = rec;
                 auto iter = [&](auto j_tag) {
                     constexpr int J = decltype(j_tag)::value, SET = J & 1;
+                    dbg_pos = (J + 1) & 7;
                     tick(0);
                     __builtin_amdgcn_s_waitcnt(0x0f70); // the weight slice requested during the last step (see `body`)
                     tick(1);
-                    if (table_wave) { // the tables of the next phase (steps 4, 5, 6 of this one: see `tables and DMA`)
-                        if constexpr (J == 3) gen_phase(n + 1);
-                        if constexpr (J == 4) hdr_dma(n + 1);
-                        if constexpr (J == 5) make_desc(n + 1);
-                    }
+                    // (the tables of the next phase are the last pooling wave's job in this layout: `body`)
                     if constexpr (J == 6) nx = phase_rec(n + 1); // (written at J == 3, behind two barriers by now)
                     const bool group_ends = J == 7 && rec.layer() == a.nl - 1;
                     if (!(DIAG && (a.debug & 64))) {
@@ -1205,7 +1254,6 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                         if (J == 7 && group_ends) group_end(rec);
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (table_wave && J == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the header DMA has landed)
                     tick(4);
                     if constexpr (J == 7) {
                         if (__builtin_expect(group_ends, 0)) {
@@ -1217,7 +1265,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                     tick(6);
-                    if (DIAG) stamp[7] += 1;
+                    if (DIAG && !(a.debug & 32)) stamp[7] += 1;
                 };
                 iter(std::integral_constant<int, 0>{});
                 iter(std::integral_constant<int, 1>{});
