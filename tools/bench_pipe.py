@@ -107,7 +107,7 @@ with torch.no_grad():
 
     if "--barrier" in sys.argv:
         # diagnostic 32: cycles a wave waits at the step barrier, by the position of the step in its phase (i & 7)
-        for wave in (0, 1, 4, 8, 12, 15):
+        for wave in range(16):
             ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=128 | 32 | (wave << 8))
             torch.cuda.synchronize()
             d = ws[lay["diag"]:lay["diag"] + 512 * 64].cpu().numpy().view(np.uint64).reshape(512, 8).astype(np.float64)

@@ -440,7 +440,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
     __shared__ unsigned s_misc[16];
     __shared__ __align__(16) unsigned s_sc[kMaxScales][12];                 // per scale: integral, recs, wfrag, hdrs (lo, hi each), Hf, Wf, nl * n_views, -
-    __shared__ __align__(16) unsigned s_phase[4][4];                        // phase records (wave 0): [phase & 3]{tile, views, w, -}
+    // phase records (table wave): [phase & 3]{tile, views, w, -, then the 12 constants of the phase's scale (s_sc)}: whoever builds
+    // tables from a phase record finds everything behind ONE LDS round trip (under the pooling waves' read traffic a dependent chain of
+    // three -- record, scale constants, headers -- took make_desc 3 500 cycles)
+    __shared__ __align__(16) unsigned s_phase[4][16];
     __shared__ __align__(16) unsigned s_groups[kGroupRing][4];              // group records (wave 0), a ring: {tile, views, scale | nj << 15 | more << 20, -}
     __shared__ __align__(16) unsigned s_desc[4][8][2][8];                   // fetch descriptors (wave 0): [phase & 3][step of the phase][sub-tile]
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63;
@@ -514,8 +517,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // The wave that runs the generator and fills the tables: matrix wave 0.  (On the last pooling wave -- they wait ~1 500 cycles
         // per step at the barrier -- the generator's scalar state no longer fits the scalar registers; what is spilled from them takes
         // vector registers of BOTH roles and the matrix loop spills: 23 scratch operations per step.)
-        const bool table_wave = W16 ? wave == kMatWaves + 7 : wave == 0; // (sixteen waves: the LAST pooling wave -- the pooling
-        // waves wait 1 300-7 000 cycles at every step barrier, the matrix waves are the longer role)
+        // (sixteen waves: a POOLING wave -- they wait 600-3 000 cycles at every step barrier --, and of those the fourth: the
+        // older pooling wave of its SIMD wins the issue conflicts with the younger one (waves 12-15) and arrives 150-250 cycles
+        // per step earlier; on the last wave, the latest of all, the tables delayed every step they ran in)
+        const bool table_wave = W16 ? wave == kMatWaves + 3 : wave == 0;
         const int pb = lane >> 2, pi = lane & 3;          // ... box 0..15 of the wave's half sub-tile, 16-byte piece 0..3
 
         // ---------------------------------------------------------------- matrix-wave state
@@ -665,7 +670,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             while (gen_layer == 0 && gen_next == gen_filled && gen_t < gen_t_lim) fill_groups(); // (tiles without a live view add none)
             const uint4 g = *reinterpret_cast<const uint4 *>(&s_groups[gen_next & (kGroupRing - 1)][0]);
             const bool end = uniform_i((int)g.x) < 0;
-            if (lane == 0) *reinterpret_cast<uint4 *>(&s_phase[n & 3][0]) = make_uint4(g.x, g.y, g.z | ((unsigned)gen_layer << 2), 0u);
+            {
+                const unsigned sc_w = s_sc[g.z & 3u][lane >= 4 && lane < 16 ? lane - 4 : 0];
+                const unsigned w0 = lane == 0 ? g.x : (lane == 1 ? g.y : (lane == 2 ? (g.z | ((unsigned)gen_layer << 2)) : 0u));
+                if (lane < 16) s_phase[n & 3][lane] = lane < 4 ? w0 : sc_w;
+            }
             if (!end && ++gen_layer == a.nl) { gen_layer = 0; ++gen_next; }
         };
         auto scale_ptr = [&](int scale, const void *p0, const void *p1, const void *p2) { // (per-lane select: no scalar branches)
@@ -678,23 +687,27 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             int j = lane >> 3;
             j = j < nj ? j : nj - 1;
             const int view = (int)((v.y >> (8 * j)) & 0xffu);
-            const uint4 c1 = *reinterpret_cast<const uint4 *>(&s_sc[scale][4]), c2 = *reinterpret_cast<const uint4 *>(&s_sc[scale][8]);
+            const uint4 c1 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][8]), c2 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][12]);
             const unsigned long long item = (unsigned long long)((unsigned)tile * c2.z + (unsigned)layer * c2.w + (unsigned)view);
             const unsigned long long p = ((unsigned long long)c1.w << 32 | c1.z) + item * kHdrBytes + (unsigned)(lane & 7) * 4u;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                              (__attribute__((address_space(3))) void *)(&s_hdr[n & 3][0]), 4, 0, 0);
         };
         // entry (k, x): {image address of (view, quarter), record address, flags | slots << 8, weight slice address (lanes x = 0)}
-        auto make_desc = [&](int n) { // (wave 0) lanes 0..15 = (step k, sub-tile x) of phase n
-            const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
-            if (uniform_i((int)v.x) < 0) return;
-            const int tile = (int)v.x, scale = (int)(v.z & 3u), layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
+        auto make_desc = [&](int n) { // (table wave) lanes 0..15 = (step k, sub-tile x) of phase n
             const int k = (lane >> 1) & 7, x = lane & 1, q = k >> 1, j = 2 * (k & 1) + x;
+            // the phase record and its scale constants in one round trip
+            const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
+            const uint4 c0 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][4]), c1 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][8]),
+                        c2 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][12]);
+            if (uniform_i((int)v.x) < 0) return;
+            const int tile = (int)v.x, layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
             const int jj = j < nj ? j : 0;
+            // (the header read stays BEHIND the validity branch and indexed by jj: reading slot j in front of it -- one round trip
+            // less -- ended in memory faults on full-size frames in the optimised build only; not understood, not used)
+            const uint2 hd = *reinterpret_cast<const uint2 *>(&s_hdr[n & 3][jj * 8]);
             const int view = (int)((v.y >> (8 * jj)) & 0xffu);
-            const unsigned flags = s_hdr[n & 3][jj * 8 + 0], n_slots = s_hdr[n & 3][jj * 8 + 1];
-            const uint4 c0 = *reinterpret_cast<const uint4 *>(&s_sc[scale][0]), c1 = *reinterpret_cast<const uint4 *>(&s_sc[scale][4]),
-                        c2 = *reinterpret_cast<const uint4 *>(&s_sc[scale][8]);
+            const unsigned flags = hd.x, n_slots = hd.y;
             const int Hf = (int)c2.x, Wf = (int)c2.y;
             const unsigned long long item = (unsigned long long)((unsigned)tile * c2.z + (unsigned)layer * c2.w + (unsigned)view);
             const unsigned long long img = ((unsigned long long)c0.y << 32 | c0.x) +
@@ -1134,7 +1147,16 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 // read, and the table wave was 3 000-4 500 cycles late at every sixth step.
                 // (make_desc reads the header buffer, a DMA target: behind this step's window requests the compiler would drain them
                 // in front of that read -- so it goes first, at a point where this wave has nothing in flight)
-                if (W16 && table_wave && m == 0) make_desc((i >> 3) + 1);
+                if (W16 && table_wave && m == 0) {
+                    unsigned long long t_tab = 0;
+                    if (DIAG && (a.debug & 32) && (a.debug & 16)) t_tab = __builtin_amdgcn_s_memtime();
+                    make_desc((i >> 3) + 1);
+                    if (DIAG && (a.debug & 32) && (a.debug & 16)) { // (diagnostic 32 + 16: the time of make_desc, in the upper bits of slot 0)
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        stamp[0] += (__builtin_amdgcn_s_memtime() - t_tab) << 24;
+                    }
+                }
+                if (W16 && table_wave && m == 2) hdr_dma((i >> 3) + 2); // (first too: its 256 bytes land under the pooling)
                 if (W16 && (live & 4u) && !bare) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
                 if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i);
                 // The tables (see `tables and DMA`), a phase further ahead than on twelve waves and behind the pooling: the descriptors
@@ -1144,7 +1166,6 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 // together made every wave wait for the table wave.
                 if (W16 && table_wave) {
                     if (m == 1) gen_phase((i >> 3) + 2);
-                    else if (m == 2) hdr_dma((i >> 3) + 2);
                 }
                 tick(1); // (pooling waves: slot 1 = requests + pooling, slot 2 = waiting for the next step's windows to land)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
