@@ -45,6 +45,13 @@ constexpr int kWinSlots3 = 92;                  // ... of the three-piece varian
 // 8 matrix waves + 8 pooling waves (four waves per SIMD, 128 registers); the six-product variant keeps 4 pooling waves (three per
 // SIMD, 168 registers: its third weight plane and third fragment do not fit into 128, and it is bound by the matrix pipe anyway)
 constexpr int kMatWaves = 8;
+#ifndef VFA_PIPE_DMA_ON_MATRIX
+#define VFA_PIPE_DMA_ON_MATRIX 0
+#endif
+// Sixteen waves: which role requests the tap windows (twelve: always the matrix waves).  Measured as an A/B in one process after
+// every other change of the round: on the pooling waves 551 / 1 485 / 3 664 us (bench frame, MultiviewC x5, Wildtrack x8), on the
+// matrix waves 565 / 1 530 / 3 727.
+constexpr bool kDmaOnMatrix = VFA_PIPE_DMA_ON_MATRIX != 0;
 constexpr int kGroupRing = 128; // group records in LDS (2 KB); a tile has at most 3 * 8 groups
 constexpr int pool_waves_of(int terms) { return terms == 6 ? 4 : 8; }
 constexpr int threads_of(int terms) { return 64 * (kMatWaves + pool_waves_of(terms)); }
@@ -513,7 +520,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // four 16-byte pieces: m = mpar, mpar + mstep, ...
         const int px = W16 ? pw >> 2 : pw >> 1, phalf = W16 ? (pw >> 1) & 1 : pw & 1, mpar = W16 ? pw & 1 : 0;
         constexpr int mstep = W16 ? 2 : 1, mcount = W16 ? 2 : 4;
-        const int dw = W16 ? pw : wave;                   // the waves that fetch (step_dma): 0..7
+        const bool dma_matrix = !W16 || kDmaOnMatrix;
+        const int dw = dma_matrix ? wave : pw;            // the waves that fetch (step_dma): 0..7
         // The wave that runs the generator and fills the tables: matrix wave 0.  (On the last pooling wave -- they wait ~1 500 cycles
         // per step at the barrier -- the generator's scalar state no longer fits the scalar registers; what is spilled from them takes
         // vector registers of BOTH roles and the matrix loop spills: 23 scratch operations per step.)
@@ -1122,7 +1130,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         lds_fence_barrier();
         if (table_wave) make_desc(0);
         lds_fence_barrier();
-        if constexpr (POOL == W16) step_dma(std::integral_constant<int, 0>{}, 0);
+        if (POOL != dma_matrix) step_dma(std::integral_constant<int, 0>{}, 0);
         if constexpr (!POOL) {
             w_addr(0);
 #pragma unroll
@@ -1157,7 +1165,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     }
                 }
                 if (W16 && table_wave && m == 2) hdr_dma((i >> 3) + 2); // (first too: its 256 bytes land under the pooling)
-                if (W16 && (live & 4u) && !bare) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
+                if (!dma_matrix && (live & 4u) && !bare) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
                 if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i);
                 // The tables (see `tables and DMA`), a phase further ahead than on twelve waves and behind the pooling: the descriptors
                 // of phase n + 1 (~1 000 cycles; its headers were requested a phase ago) in the FIRST step of phase n, where the
@@ -1247,7 +1255,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 w_lo = (unsigned)uniform_i((int)(unsigned)p); w_hi = (unsigned)uniform_i((int)(unsigned)(p >> 32));
             };
             __builtin_amdgcn_s_waitcnt(0x0f70);
-            __builtin_amdgcn_s_barrier(); // (iteration 0: the pooling waves pool step 0)
+            if (dma_matrix) { // (iteration 0: the pooling waves pool step 0; the windows of step 1)
+                step_dma(std::integral_constant<int, 1>{}, 1);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             int n = 0;
             for (;;) {
@@ -1261,6 +1273,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     // (the tables of the next phase are the last pooling wave's job in this layout: `body`)
                     if constexpr (J == 6) nx = phase_rec(n + 1); // (written at J == 3, behind two barriers by now)
                     const bool group_ends = J == 7 && rec.layer() == a.nl - 1;
+                    // the windows of step 8 n + J + 2 (the pooling waves are at 8 n + J + 1): the two matrix waves of a SIMD take
+                    // their two jobs in opposite order (waves 0-3 request and then multiply, waves 4-7 multiply first)
+                    const bool dma_now = dma_matrix && (J < 6 || nx.valid()) && !(DIAG && (a.debug & 64));
+                    if (dma_now && wave < 4) step_dma(std::integral_constant<int, J & 1>{}, 8 * n + J + 2);
                     if (!(DIAG && (a.debug & 64))) {
                         if (J == 7 && group_ends) group_begin(rec);
                         // the slice of the next chunk: behind the k-steps of set 1, or, when set 1 of the group is empty, already
@@ -1274,7 +1290,9 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                         multiply(std::integral_constant<int, SET>{}, rec, J, SET, next_chunk);
                         if (J == 7 && group_ends) group_end(rec);
                     }
+                    if (dma_now && wave >= 4) step_dma(std::integral_constant<int, J & 1>{}, 8 * n + J + 2);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (dma_matrix) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (what this wave requested has landed)
                     tick(4);
                     if constexpr (J == 7) {
                         if (__builtin_expect(group_ends, 0)) {
