@@ -287,7 +287,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
  * The inference hot path for C = 256 and ANY K = n_layers * 256 (the reference builds collapse = Linear(C * nl -> C),
  * vfa_op.py:50-59, and every shipped config has nl > 1: vfa/config.py:22-24, 49-52, 77-80):
  *
- *   vfa_pipe_boxes_f32     geometry once per frame: every (view, cell, LAYER) cube projected once, a 96-byte box record per scale
+ *   vfa_pipe_boxes_f32     geometry once per frame: every (view, cell, LAYER) cube projected once, a 48-byte box record per scale
  *                          and a 32-byte tap-window header per (tile, layer, view, scale)        replaces vfa_op.py:64-106
  *   vfa_pipe_cuts_f32      cost-balanced work cuts + collapse.weight of every scale as bf16 hi / lo MFMA fragments.
  *                          weights[k]: (256, 256 * n_layers) fp32 in the REFERENCE layout, column = c * n_layers + layer

@@ -35,13 +35,13 @@ using namespace vfa_pipe;
 
 constexpr int kTileW = 8, kTileL = 4, kTileBoxes = kTileW * kTileL;
 constexpr int kC = 256;
-constexpr int kRecBytes = 96, kHdrBytes = 32;
+constexpr int kRecBytes = 48, kHdrBytes = 32; // (box record: see pipe_records_kernel)
 constexpr int kMaxScales = 3;
 constexpr int kSlotBytes = kC * 4;              // one tap in the integral image: 256 fp32
 constexpr int kQSlot = 256;                     // ... and the 64-channel quarter of it that a step needs
-constexpr int kWinSlots = 108;                  // LDS tap window of a (tile, view, layer, scale), in quarter slots: four of them (two being
-                                                // pooled, two arriving); 27 KiB each
-constexpr int kWinSlots3 = 92;                  // ... of the three-piece variant (VFA_FLAG_TERMS 6): a third bf16 plane takes 17 KiB of LDS
+constexpr int kWinSlots = 112;                  // LDS tap window of a (tile, view, layer, scale), in quarter slots: four of them (two being
+                                                // pooled, two arriving); 28 KiB each.  A multiple of 4: a fill instruction brings four
+constexpr int kWinSlots3 = 96;                   // ... of the three-piece variant (VFA_FLAG_TERMS 6): a third bf16 plane takes 17 KiB of LDS
 // 8 matrix waves + 8 pooling waves (four waves per SIMD, 128 registers); the six-product variant keeps 4 pooling waves (three per
 // SIMD, 168 registers: its third weight plane and third fragment do not fit into 128, and it is bound by the matrix pipe anyway)
 constexpr int kMatWaves = 8;
@@ -89,7 +89,7 @@ struct RecordArgs {
 
 __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
 {
-    __shared__ uint4 stage[2][kTileBoxes * 6];
+    __shared__ uint4 stage[2][kTileBoxes * 3];
     const int lane = threadIdx.x, half = lane >> 5, b = lane & 31;
     const long long pair = (long long)blockIdx.x * 2 + half;
     const bool pair_ok = pair < (long long)a.n_views * a.n_tiles;
@@ -166,29 +166,22 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
                 if (direct) { rows[k] = (unsigned)(ys[k] + 1); cols[k] = (unsigned)(xs[k] + 1); }
                 else { rows[k] = (unsigned)(slot_row(ys[k]) * cwid); cols[k] = (unsigned)(xs[k] - x0); }
             }
-            float w[16];
-            {
-                float q[4];
-                bilinear_weights(q, xl, yt); w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];       // lt
-                bilinear_weights(q, xr, yb); w[4] = q[0]; w[5] = q[1]; w[6] = q[2]; w[7] = q[3];       // rb
-                bilinear_weights(q, xr, yt); w[8] = q[0]; w[9] = q[1]; w[10] = q[2]; w[11] = q[3];     // rt
-                bilinear_weights(q, xl, yb); w[12] = q[0]; w[13] = q[1]; w[14] = q[2]; w[15] = q[3];   // lb
-            }
+            // A box in 48 bytes: the upper bilinear fractions of its four axes (the sixteen tap weights are products of them and of
+            // 1 - them: `unpack` of the frame kernel forms them with the same two rounded operations as `bilinear_weights`), the factor
+            // (RN(1 / area), or the masked value), the visibility flag, four row and four column parts.  (96 bytes with the weights
+            // spelled out: 19 GB per frame of the 512 x 512 x 32 stress config.)
             if (pair_ok) {
-                uint4 *st = stage[half] + b * 6;
-                st[0] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
-                st[1] = make_uint4(__float_as_uint(w[4]), __float_as_uint(w[5]), __float_as_uint(w[6]), __float_as_uint(w[7]));
-                st[2] = make_uint4(__float_as_uint(w[8]), __float_as_uint(w[9]), __float_as_uint(w[10]), __float_as_uint(w[11]));
-                st[3] = make_uint4(__float_as_uint(w[12]), __float_as_uint(w[13]), __float_as_uint(w[14]), __float_as_uint(w[15]));
+                uint4 *st = stage[half] + b * 3;
                 const float rcp = 1.0f / area; // correctly rounded
-                st[4] = make_uint4(__float_as_uint(rcp), vis ? (unsigned)kVis : 0u, rows[0] | (rows[1] << 16), rows[2] | (rows[3] << 16));
-                st[5] = make_uint4(cols[0] | (cols[1] << 16), cols[2] | (cols[3] << 16), __float_as_uint(masked), __float_as_uint(area));
+                st[0] = make_uint4(__float_as_uint(xl.hi), __float_as_uint(xr.hi), __float_as_uint(yt.hi), __float_as_uint(yb.hi));
+                st[1] = make_uint4(__float_as_uint(vis ? rcp : masked), vis ? (unsigned)kVis : 0u, rows[0] | (rows[1] << 16), rows[2] | (rows[3] << 16));
+                st[2] = make_uint4(cols[0] | (cols[1] << 16), cols[2] | (cols[3] << 16), 0u, 0u);
             }
             __syncthreads(); // (one wave: orders the LDS writes above against the reads below)
             if (pair_ok) {
                 uint4 *rec = reinterpret_cast<uint4 *>(a.recs[s] + item * kTileBoxes * kRecBytes);
 #pragma unroll
-                for (int k = 0; k < 6; ++k) rec[k * 32 + b] = stage[half][k * 32 + b];
+                for (int k = 0; k < 3; ++k) rec[k * 32 + b] = stage[half][k * 32 + b];
                 if (b == 0) {
                     uint4 *hdr = reinterpret_cast<uint4 *>(a.hdrs[s] + item * kHdrBytes);
                     const int inv = cwid > 0 ? (65536 + cwid - 1) / cwid : 0; // floor(s / cwid) == (s * inv) >> 16 for s < 128
@@ -742,7 +735,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const uint4 h0 = hp[0], h1 = hp[1];
             const int fw = uniform_i((int)d1.x);
             if (!(fw & kTileLive)) return;
-            if ((k >> 1) == 0 && wq4 < 3) {
+            if ((k >> 1) == 0 && (wq4 == 0 || (wq4 == 1 && lane < 32))) { // (32 boxes x 48 bytes = a load and a half)
                 const unsigned long long p = ((unsigned long long)d0.w << 32 | d0.z) + (unsigned)(wq4 * 1024 + lane * 16);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                                  (__attribute__((address_space(3))) void *)((DSET ? s_rec1 : s_rec0) + x * kTileBoxes * kRecBytes + wq4 * 1024), 16, 0, 0);
@@ -922,19 +915,22 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         auto unpack = [&](auto set_tag, LaneBox &bx, bool &glob, unsigned wp, int x, bool direct) -> bool {
             constexpr int USET = decltype(set_tag)::value;
             const uint4 *rp = reinterpret_cast<const uint4 *>((USET ? s_rec1 : s_rec0) + x * kTileBoxes * kRecBytes) + (phalf * 16 + pb) * (kRecBytes / 16);
-            uint4 rv[6];
+            uint4 rv[3];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) rv[k] = rp[k];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                bx.wt[4 * k + 0] = __uint_as_float(rv[k].x); bx.wt[4 * k + 1] = __uint_as_float(rv[k].y);
-                bx.wt[4 * k + 2] = __uint_as_float(rv[k].z); bx.wt[4 * k + 3] = __uint_as_float(rv[k].w);
+            for (int k = 0; k < 3; ++k) rv[k] = rp[k];
+            {   // the sixteen tap weights (vfa_geom.h: make_axis, bilinear_weights -- the same operations, so the same bits)
+                const float xl1 = __uint_as_float(rv[0].x), xr1 = __uint_as_float(rv[0].y), yt1 = __uint_as_float(rv[0].z), yb1 = __uint_as_float(rv[0].w);
+                const float xl0 = 1.0f - xl1, xr0 = 1.0f - xr1, yt0 = 1.0f - yt1, yb0 = 1.0f - yb1;
+                bx.wt[0] = yt0 * xl0; bx.wt[1] = yt0 * xl1; bx.wt[2] = yt1 * xl0; bx.wt[3] = yt1 * xl1;     // lt
+                bx.wt[4] = yb0 * xr0; bx.wt[5] = yb0 * xr1; bx.wt[6] = yb1 * xr0; bx.wt[7] = yb1 * xr1;     // rb
+                bx.wt[8] = yt0 * xr0; bx.wt[9] = yt0 * xr1; bx.wt[10] = yt1 * xr0; bx.wt[11] = yt1 * xr1;   // rt
+                bx.wt[12] = yb0 * xl0; bx.wt[13] = yb0 * xl1; bx.wt[14] = yb1 * xl0; bx.wt[15] = yb1 * xl1; // lb
             }
-            const bool vis = (rv[4].y & (unsigned)kVis) != 0u;
+            const bool vis = (rv[1].y & (unsigned)kVis) != 0u;
             // a masked box reads slot / pixel 0 (finite) and multiplies by its masked value (0, or NaN for a NaN box)
-            bx.scl = vis ? __uint_as_float(rv[4].x) : __uint_as_float(rv[5].z);
-            unsigned rw[4] = {rv[4].z & 0xffffu, rv[4].z >> 16, rv[4].w & 0xffffu, rv[4].w >> 16};
-            unsigned cl[4] = {rv[5].x & 0xffffu, rv[5].x >> 16, rv[5].y & 0xffffu, rv[5].y >> 16};
+            bx.scl = __uint_as_float(rv[1].x);
+            unsigned rw[4] = {rv[1].z & 0xffffu, rv[1].z >> 16, rv[1].w & 0xffffu, rv[1].w >> 16};
+            unsigned cl[4] = {rv[2].x & 0xffffu, rv[2].x >> 16, rv[2].y & 0xffffu, rv[2].y >> 16};
             glob = direct;
             // pixel of the padded image (direct) / slot of the window = row part + column part; a masked box reads slot / pixel 0
             const unsigned unit = direct ? (unsigned)kSlotBytes : (unsigned)kQSlot;
