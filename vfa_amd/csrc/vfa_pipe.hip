@@ -678,13 +678,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             }
             if (!end && ++gen_layer == a.nl) { gen_layer = 0; ++gen_next; }
         };
-        auto scale_ptr = [&](int scale, const void *p0, const void *p1, const void *p2) { // (per-lane select: no scalar branches)
-            return (unsigned long long)(size_t)(scale == 0 ? p0 : (scale == 1 ? p1 : p2));
-        };
         auto hdr_dma = [&](int n) { // (wave 0) the headers of the sub-tiles of phase n: 8 lanes each, per-lane addresses
             const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
             if (uniform_i((int)v.x) < 0) return;
-            const int tile = (int)v.x, scale = (int)(v.z & 3u), layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
+            const int tile = (int)v.x, layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
             int j = lane >> 3;
             j = j < nj ? j : nj - 1;
             const int view = (int)((v.y >> (8 * j)) & 0xffu);
@@ -1021,7 +1018,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         };
         auto pool_step = [&](auto set_tag, int i) {
             constexpr int SET = decltype(set_tag)::value;
-            const int n = i >> 3, k = i & 7, x = px, j = 2 * SET + x;
+            const int n = i >> 3, k = i & 7, x = px;
             auto one = [&](LaneBox &bx, bool &glob, bool &live) { // (called with the registers of the step's set)
                 if ((k >> 1) == 0) { // first quarter of the layer: this wave's 16 boxes for the whole layer
                     const uint4 d1 = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0])[1];
