@@ -21,7 +21,8 @@ terms = int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--terms
 stamps = "--stamps" in sys.argv
 stamp_mask = int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--stamp-mask=")), "0"))  # ablation bits under the stamps
 dev = torch.device("cuda:0")
-wl = make_workload(name, channels=256, seed=0)
+cams = int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--cams=")), "0"))  # the first `cams` cameras of the rig only
+wl = make_workload(name, channels=256, seed=0, **({"n_cam": cams} if cams else {}))
 n = wl["n_cam"]
 torch.manual_seed(0)
 mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
