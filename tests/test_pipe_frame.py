@@ -276,6 +276,79 @@ def test_pipe_single_scale_accumulate_degenerate_grids_and_bands(monkeypatch):
     _check("banded vs whole", banded, whole.double())
 
 
+@pytest.mark.parametrize("name,n_cam,crop,origin", [
+    ("multiviewc_156x156x5", 3, (41, 67), (20, 10)),   # ragged grid, five layers
+    ("wildtrack_120x360x8", 2, (24, 96), (50, 130)),   # eight layers, many masked boxes, boxes in front of a camera
+])
+def test_pipe_box_records_match_the_box_parameter_kernel(name, n_cam, crop, origin):
+    """The 48-byte box records and the window headers of the pipelined kernel's geometry pass, decoded on the host, against the
+    bit-exact box-parameter entry point (`vfa_box_params_f32`, pinned to the reference's fixtures): visibility, RN(1 / area), the
+    upper bilinear fraction of each of the four axes (the frame kernel forms the sixteen tap weights from them with the operations
+    of `bilinear_weights`), and the sixteen taps' pixel coordinates rebuilt from the window header -- every layer, view and scale."""
+    from vfa_amd import _lib, ops
+    dev = _dev()
+    wl, grid, lats, calibs = _frame(name, n_cam, crop, dev, origin=origin)
+    mods = _mods(wl, dev)
+    zl, co = mods[0]._kernel_geometry(dev)
+    kind, img_wh = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
+    sizes = [tuple(l.shape[-2:]) for l in lats]
+    n, nl, ns = calibs.shape[0], mods[0].num_grid_layer, 3
+    L, W = grid.shape[1:3]
+    ws = ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=[m.collapse.weight for m in mods])
+    torch.cuda.synchronize()
+    host = ws.cpu().numpy()
+    lay = ops.pipe_workspace_layout(n, L, W, nl, ns)
+    tl_n, tw_n = lay["tiles_l"], lay["tiles_w"]
+    tiles = tl_n * tw_n
+    seen_direct = 0
+    for s, (Hf, Wf) in enumerate(sizes):
+        box, area, vis = ops.box_params(calibs, grid.reshape(-1, 3), zl, co, kind, img_wh, (Hf, Wf))
+        box = box.cpu().numpy().reshape(n, nl, L, W, 4)
+        area = area.cpu().numpy().reshape(n, nl, L, W)
+        vis = vis.cpu().numpy().reshape(n, nl, L, W).astype(bool)
+        rec = host[lay["recs"][s]:lay["recs"][s] + tiles * nl * n * 32 * 48].view(np.uint32).reshape(tl_n, tw_n, nl, n, 4, 8, 12)
+        hdr = host[lay["hdrs"][s]:lay["hdrs"][s] + tiles * nl * n * 32].view(np.uint32).reshape(tl_n, tw_n, nl, n, 8)
+        # (tile row, tile col, layer, view, cell row, cell col) -> (view, layer, grid row, grid col)
+        g = rec.transpose(3, 2, 0, 4, 1, 5, 6).reshape(n, nl, tl_n * 4, tw_n * 8, 12)[:, :, :L, :W]
+        h = np.broadcast_to(hdr.transpose(3, 2, 0, 1, 4)[:, :, :, None, :, None, :], (n, nl, tl_n, 4, tw_n, 8, 8))
+        h = h.reshape(n, nl, tl_n * 4, tw_n * 8, 8)[:, :, :L, :W].astype(np.int64)
+        assert np.array_equal((g[..., 5] & 1).astype(bool), vis), f"scale {s}: visibility"
+        rcp = (np.float32(1) / area).view(np.uint32)
+        assert np.array_equal(g[..., 4][vis], rcp[vis]), f"scale {s}: 1 / area"
+        assert (g[..., 4][~vis & (area == area)] == 0).all(), f"scale {s}: the factor of a masked box is 0"
+
+        def axis(coord, size):  # vfa_geom.h make_axis: X = fma(g + 1, size / 2, -0.5) (one rounding), i0 = floor(X), hi = X - i0
+            x = (np.float32(coord) + np.float32(1)).astype(np.float64) * (size / 2.0) - 0.5
+            x = x.astype(np.float32)
+            f = np.floor(x)
+            return f.astype(np.int64), (x - f).astype(np.float32)
+
+        (xl_i, xl_h), (xr_i, xr_h) = axis(box[..., 0], Wf), axis(box[..., 2], Wf)
+        (yt_i, yt_h), (yb_i, yb_h) = axis(box[..., 1], Hf), axis(box[..., 3], Hf)
+        for k, (nm, want) in enumerate((("left", xl_h), ("right", xr_h), ("top", yt_h), ("bottom", yb_h))):
+            assert np.array_equal(g[..., k][vis], want.view(np.uint32)[vis]), f"scale {s}: upper fraction of the {nm} axis"
+        # tap coordinates: the record holds (row part, column part) of the four tap rows / columns, relative to the tile's window
+        # (slots) or, for a tile whose window does not fit LDS, as pixels of the padded image
+        direct = ((h[..., 0] >> 1) & 1).astype(bool)
+        cwid, x0, t0, top, b0 = h[..., 2], h[..., 4].astype(np.int32).astype(np.int64), h[..., 5].astype(np.int32).astype(np.int64), h[..., 6], h[..., 7].astype(np.int32).astype(np.int64)
+        rows = np.stack([g[..., 6] & 0xffff, g[..., 6] >> 16, g[..., 7] & 0xffff, g[..., 7] >> 16], -1).astype(np.int64)
+        cols = np.stack([g[..., 8] & 0xffff, g[..., 8] >> 16, g[..., 9] & 0xffff, g[..., 9] >> 16], -1).astype(np.int64)
+        want_y = np.stack([np.clip(yt_i, -1, Hf), np.clip(yt_i + 1, -1, Hf), np.clip(yb_i, -1, Hf), np.clip(yb_i + 1, -1, Hf)], -1)
+        want_x = np.stack([np.clip(xl_i, -1, Wf), np.clip(xl_i + 1, -1, Wf), np.clip(xr_i, -1, Wf), np.clip(xr_i + 1, -1, Wf)], -1)
+        sel = vis & direct
+        seen_direct += int(sel.sum())
+        assert np.array_equal(rows[sel], want_y[sel] + 1) and np.array_equal(cols[sel], want_x[sel] + 1), f"scale {s}: direct taps"
+        sel = vis & ~direct
+        assert (h[..., 1][sel] <= lay["max_slots"]).all()
+        cw = np.maximum(cwid, 1)[..., None]
+        srow = rows // cw
+        assert np.array_equal((srow * cw)[sel], rows[sel])
+        y = np.where(srow < top[..., None], t0[..., None] + srow, b0[..., None] + (srow - top[..., None]))
+        assert np.array_equal(y[sel], want_y[sel]) and np.array_equal((cols + x0[..., None])[sel], want_x[sel]), f"scale {s}: window taps"
+        assert ((rows + cols)[sel] < h[..., 1][..., None][sel]).all(), f"scale {s}: a tap outside its window"
+    print(f"[records] {name}: {seen_direct} visible boxes in tiles pooled straight from L2")
+
+
 def test_pipe_work_cuts_match_the_serial_restatement():
     """The chunk tables the device kernel leaves in the workspace against a serial Python restatement of the same rule
     (tests/native/pipe_seq_harness.cpp holds the C++ one and checks the step order on the CPU)."""
