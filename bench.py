@@ -295,11 +295,13 @@ ROOFLINE_ENTRY_POINTS = tuple(KERNEL_NAMES)
 def committed_traffic(workload, kernel_substr):
     """HBM bytes per dispatch from the committed PMC passes of this command (profiles/rNN_pmc_traffic.json), or None."""
     for tag in ("r03", "r02", "r01"):
-        tpath = os.path.join(REPO, "profiles", f"{tag}_pmc_traffic.json")
-        if workload == PRIMARY and os.path.exists(tpath):
+        # (the PMC passes of the bench default, and -- per workload -- of `--workload <name>`)
+        fname = f"{tag}_pmc_traffic.json" if workload == PRIMARY else f"{tag}_{workload}_pmc_traffic.json"
+        tpath = os.path.join(REPO, "profiles", fname)
+        if os.path.exists(tpath):
             for name, rec in json.load(open(tpath))["kernels"].items():
                 if kernel_substr in name:
-                    return rec["hbm_bytes_per_dispatch"], f"profiles/{tag}_pmc_traffic.json"
+                    return rec["hbm_bytes_per_dispatch"], f"profiles/{fname}"
     return None, None
 
 
