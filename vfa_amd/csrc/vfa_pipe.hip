@@ -804,8 +804,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             // operands when they issued) and land under them and under the partner wave's MFMAs; a second set for reading ahead
             // does not fit beside four accumulators, the tile sums and the weight slice (168 registers at three waves per SIMD)
             bf16x8 h0, h1, l0, l1; // row blocks 0 / 1 of the hi and of the lo plane: one k-step ahead of the MFMAs
-            // Both row blocks, always: a sub-tile without a live box in this layer was ZEROED by its pooling wave, and the rows
-            // of a sub-tile the group does not have feed an accumulator nobody reads.
+            // A sub-tile without a live box in this layer was ZEROED by its pooling wave and is multiplied like any other; the second
+            // row block of a set that has only ONE sub-tile (the last set of a group with an odd number of views: one step in four
+            // on a seven-camera rig) is left out -- BOTH = false: half the MFMAs of the step, its accumulator is never read.
+            const bool BOTH = 2 * SET + 1 < ph.nj() || TERMS == 6; // (uniform; the six-product variant, bound by the matrix pipe of its own schedule, keeps both)
             auto kstep = [&](auto ks_tag) {
                 constexpr int KS = decltype(ks_tag)::value;
                 {
@@ -822,32 +824,34 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                         acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wq[KS].hi, acc[2 * SET], 0, 0, 0);
                         acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
-                        read_frags3<KS, 1, kPlaneBytes>(pa, a0, a1, a2);
-                        __builtin_amdgcn_sched_barrier(0);
-                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].lo2, acc[2 * SET + 1], 0, 0, 0);
-                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
-                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
-                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
-                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
-                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                        {
+                            read_frags3<KS, 1, kPlaneBytes>(pa, a0, a1, a2);
+                            __builtin_amdgcn_sched_barrier(0);
+                            acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].lo2, acc[2 * SET + 1], 0, 0, 0);
+                            acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                            acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                            acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                            acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                            acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     } else {
                     // the hi pair of this k-step was requested behind the hi MFMAs of the last one, the lo pair behind its lo MFMAs
                     wait_pair<2>(h0, h1);
                     __builtin_amdgcn_sched_barrier(0);
                     acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
-                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                    if (BOTH) acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
                     acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
-                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                    if (BOTH) acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (KS < 3) { read_pair<KS + 1, 0>(pa, h0, h1); wait_pair<2>(l0, l1); } // (the MFMAs latched h0, h1 at issue)
                     else wait_pair<0>(l0, l1);
                     __builtin_amdgcn_sched_barrier(0);
                     acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
-                    acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                    if (BOTH) acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
                     if (TERMS >= 4) {
                         acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
-                        acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                        if (BOTH) acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (KS < 3) read_pair<KS + 1, 1>(pa, l0, l1);
