@@ -118,6 +118,10 @@ with torch.no_grad():
                 y[lb] = full[:, :7].sum(1)
                 coef, *_ = np.linalg.lstsq(feats, y, rcond=None)
                 res = y - feats @ coef
+                xcd_of = np.arange(nblk) // per  # (range index -> XCD: xcd_contiguous)
+                print("    residual by XCD (mean, max, of the mean load): " + "  ".join(
+                    f"{x}: {res[xcd_of == x].mean() / y.mean():+.3f} {res[xcd_of == x].max() / y.mean():+.3f}" for x in range(8))
+                    + f" | max/mean {y.max() / y.mean():.3f}")
                 print(f"    cycles ~ {coef[0]:.0f} x items + {coef[1]:.1f} x slots + {coef[2]:.0f} x row items + {coef[3]:.0f} x scale changes"
                       f" + {coef[4]:.0f} x tiles + {coef[5]:.0f};  residual std {res.std():.3g} of mean {y.mean():.3g} (raw std {y.std():.3g})")
             order = np.argsort(tot)[-5:]

@@ -135,7 +135,7 @@ with torch.no_grad():
             lb = (blk & 7) * (nblk // 8) + (blk >> 3)
             c0, c1 = K * lb // nblk, K * (lb + 1) // nblk
             tb, kb, te, ke = int(start[c0]), int(rank[c0]), int(start[c1]), int(rank[c1])
-            real = half = dummy = glob = ntile = shared = groups = 0
+            real = half = dummy = glob = ntile = shared = groups = fills = 0
             for t in range(tb, min(te + (1 if ke > 0 else 0), tiles)):
                 k = 0
                 mine = False
@@ -153,6 +153,7 @@ with torch.no_grad():
                             for st in range(2):
                                 sub = grp[2 * st:2 * st + 2]
                                 lv = [v for v in sub if hdrs[s][t, layer, v, 0] & 1]
+                                fills += 4 * sum(int(hdrs[s][t, layer, v, 1] + 3) // 4 for v in lv if not (hdrs[s][t, layer, v, 0] & 2))
                                 if lv and len(sub) == 1:
                                     half += 4  # (a set with one sub-tile: the matrix waves multiply one row block)
                                 elif lv:
@@ -164,12 +165,17 @@ with torch.no_grad():
                     ntile += 1
                     if (t == tb and kb > 0) or (t == te and ke > 0):
                         shared += 1
-            rows.append((blk, real, dummy, glob, ntile, shared, groups, d[blk, :7].sum(), half))
-        A = np.array([[r[1], r[2], r[3], r[4], r[5], r[6], r[8]] for r in rows if r[7] > 0], np.float64)
+            rows.append((blk, real, dummy, glob, ntile, shared, groups, d[blk, :7].sum(), half, fills))
+        A = np.array([[r[1], r[2], r[3], r[4], r[5], r[6], r[8], r[9]] for r in rows if r[7] > 0], np.float64)
         y = np.array([r[7] for r in rows if r[7] > 0])
         coef, *_ = np.linalg.lstsq(A, y, rcond=None)
         pred = A @ coef
-        print("  fit (cycles): full step %.0f, empty step %.0f, + per sub-tile step pooled from L2 %.0f, per tile %.0f, per shared tile %.0f, per group %.0f, half step %.0f"
+        print("  fit (cycles): full step %.0f, empty step %.0f, + per sub-tile step pooled from L2 %.0f, per tile %.0f, per shared tile %.0f, per group %.0f, half step %.0f, per window request (4 slots) %.0f"
               % tuple(coef))
+        blks = np.array([r[0] for r in rows if r[7] > 0])
+        res = (y - pred) / y.mean()
+        print("  residual by XCD (mean, max): " + "  ".join(f"{x}: {res[(blks & 7) == x].mean():+.3f} {res[(blks & 7) == x].max():+.3f}" for x in range(8)))
+        worst = np.argsort(-res)[:6]
+        print("  slowest against the model: " + ", ".join(f"block {blks[i]} (xcd {blks[i] & 7}, rank {blks[i] >> 3}) {res[i]:+.3f}" for i in worst))
         print(f"  measured max/mean {y.max() / y.mean():.3f}; residual rms {np.sqrt(np.mean((pred - y) ** 2)) / y.mean():.3f} of the mean; "
               f"if cut by this model: max/mean of the residual-corrected load {1 + (y - pred).max() / y.mean():.3f}")
