@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VFA_ABI_VERSION 4
+#define VFA_ABI_VERSION 5
 
 /* world-unit conversion of the grid, reference vfa_op.py:23-44 (chosen by args.data) */
 #define VFA_CONV_MULTIVIEWC 0 /* x / 1.0                                   */
@@ -308,7 +308,19 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
  * largest: the arithmetic width of the reference's fp32 sgemm (<= 5e-7 normwise against float64), at twice the matrix work.
  * The geometry calls take the same terms in `flags` (the three-piece variant has smaller LDS tap windows, so the geometry must
  * know which kernel will read its records; pass the value that goes to vfa_pipe_collapse_relu_sum_f32).  On a single-layer
- * grid the three-product result equals vfa_pool_collapse_relu_sum_f32 bit for bit (on tiles no workgroup boundary cuts). */
+ * grid the three-product result equals vfa_pool_collapse_relu_sum_f32 bit for bit (on tiles no workgroup boundary cuts).
+ *
+ *   vfa_pipe_balance_f32   (ABI v5) cameras and grid of a frame stream do not move: every launch of the frame kernel leaves the cycles
+ *                          each of its workgroups took in the workspace, and mode 1 turns them into new BOUNDS of the workgroups'
+ *                          shares of the work cuts (damped, normalised); the frame kernel uses them for every later frame whose cuts
+ *                          have the same total cost and whose launch has the same number of workgroups, and falls back to the uniform
+ *                          split otherwise.  mode 0 clears the state: call it once on a fresh workspace (the geometry calls never
+ *                          touch the state).  Results stay inside the path's tolerance but are NOT bitwise the unbalanced ones: a
+ *                          tile cut between two workgroups is summed in another association when the cut moves -- balance for a few
+ *                          frames, then stop, and every later frame repeats bit for bit.  offsets[18] of
+ *                          vfa_pipe_workspace_layout: the state (8 KiB: int bounds[513], launch size, cost signature; at byte
+ *                          4096 a u64 cycle count per workgroup), for callers that keep one state per band of a banded frame.
+ *                          offsets must hold 19 entries since ABI v5. */
 size_t vfa_pipe_workspace_bytes(int n_views, int L, int W, int n_layers, int n_scales);
 int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_scales, size_t *offsets, int *tiles);
 int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off, int n_views,
@@ -322,6 +334,8 @@ int vfa_pipe_records_f32(const float *calibs, const float *grid, const float *z_
 int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, void *workspace, size_t workspace_bytes,
                                    float *out, int n_views, int L, int W, int n_layers, int n_scales, const int *feat_hw, int accumulate,
                                    int flags, void *stream);
+int vfa_pipe_balance_f32(int n_views, int L, int W, int n_layers, int n_scales, int reserved_cus, int mode, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* ---- consumers of the path ---------------------------------------------------------------------------
  *

@@ -349,6 +349,56 @@ def test_pipe_box_records_match_the_box_parameter_kernel(name, n_cam, crop, orig
     print(f"[records] {name}: {seen_direct} visible boxes in tiles pooled straight from L2")
 
 
+def test_pipe_balance_minimises_the_heaviest_share(monkeypatch):
+    """`vfa_pipe_balance_f32` through `vfa_op.pipe_frame`: the first frame of a geometry leaves bounds of the workgroups' shares in the
+    persistent workspace that minimise the heaviest share (estimated cost); every frame of the stream uses them and repeats bit for bit;
+    the heaviest share is no heavier than under the uniform split and within one group of the mean; the result stays within the path's
+    tolerance of the float64 product; a frame with OTHER cameras does not match the state's signature and still comes out right."""
+    from vfa_amd import ops, vfa_op
+    dev = _dev()
+    monkeypatch.setattr(vfa_op, "PIPE_BALANCE", True)
+    vfa_op._pipe_states.clear()
+    wl, grid, lats, calibs = _frame("multiviewc_156x156x5", None, None, dev)
+    mods = _mods(wl, dev)
+    n, nl = calibs.shape[0], mods[0].num_grid_layer
+    L, W = grid.shape[1:3]
+    lay = ops.pipe_workspace_layout(n, L, W, nl, 3)
+    outs = [vfa_op.pipe_frame(mods, lats, calibs, grid).clone() for _ in range(3)]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    _check("balanced frame", outs[0], _float64_reference(mods, lats, calibs, grid, wl))
+    (st,) = vfa_op._pipe_states.values()
+    assert st["frames"] == 3
+    K = lay["n_chunks"]
+    ws = st["ws"]
+    state = ws[lay["balance"]:lay["balance"] + 4096].cpu().numpy().view(np.int32)
+    chunks = ws[lay["chunks"]:lay["chunks"] + 4 * (K + 3)].cpu().numpy().view(np.int32)
+    nblk = int(state[513])
+    assert nblk > 0 and nblk % 8 == 0 and tuple(state[514:516]) == tuple(chunks[K + 1:K + 3])
+    bounds = state[:nblk + 1].astype(np.int64)
+    assert bounds[0] == 0 and bounds[-1] == K and (np.diff(bounds) >= 0).all()
+    # estimated cost of a share from the cumulative costs the cuts kernel left per piece (pieces behind the last group: ~0 = the total)
+    total = int(np.uint32(chunks[K + 1])) | (int(np.uint32(chunks[K + 2])) << 32)
+    costs_off = lay["ranks"] + (4 * (K + 1) + 255) // 256 * 256
+    G = ws[costs_off:costs_off + 8 * (K + 1)].cpu().numpy().view(np.uint64).astype(np.float64)
+    G[G > 1e19] = total
+    assert (np.diff(G) >= 0).all() and G[0] == 0 and G[K] == total
+    heaviest = np.diff(G[bounds]).max()
+    uniform = np.array([K * k // nblk for k in range(nblk + 1)])
+    heaviest_uniform = np.diff(G[uniform]).max()
+    mean = total / nblk
+    print(f"[balance] {nblk} workgroups: heaviest share / mean {heaviest / mean:.3f} (uniform split: {heaviest_uniform / mean:.3f})")
+    assert heaviest <= heaviest_uniform and heaviest / mean < 1.06
+    cycles = ws[lay["balance"] + 4096:lay["balance"] + 4096 + 8 * nblk].cpu().numpy().view(np.uint64).astype(np.float64)
+    print(f"[balance] last launch: slowest / mean workgroup (cycles) {cycles.max() / cycles[cycles > 0].mean():.3f}")
+    # other cameras, same shapes: the state does not fit these cuts
+    calibs2 = calibs.flip(0).contiguous()
+    lats2 = [l.flip(0).contiguous() for l in lats]
+    got = vfa_op.pipe_frame(mods, lats2, calibs2, grid)
+    _check("other cameras on a balanced workspace", got, _float64_reference(mods, lats2, calibs2, grid, wl))
+    vfa_op._pipe_states.clear()
+
+
 def test_pipe_work_cuts_match_the_serial_restatement():
     """The chunk tables the device kernel leaves in the workspace against a serial Python restatement of the same rule
     (tests/native/pipe_seq_harness.cpp holds the C++ one and checks the step order on the CPU)."""

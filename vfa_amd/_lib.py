@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFA_AMD_LIB") or os.path.join(_HERE, "csrc", "libvfa_hip.so")  # (override: A/B runs of two builds)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 CONV_KIND = {"MultiviewC": 0, "MultiviewX": 1, "Wildtrack": 2}
 VOX_REFERENCE, VOX_LAYER_MAJOR = 0, 1
@@ -77,6 +77,7 @@ SIGNATURES = {
                              _c_int, _vp, _vp, _c_int, _vp, _c_size_t, _vp],
     "vfa_pipe_collapse_relu_sum_f32": [_vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
                                        _vp],
+    "vfa_pipe_balance_f32": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_size_t, _vp],
 }
 
 _lib = None

@@ -63,6 +63,13 @@ constexpr int kPlaneBytes = 8 * kChunkStride;   // 8448
 constexpr int kWPlanes = 3;                     // bf16 planes of the split collapse weight in the workspace: hi, mid (= lo of the two-piece split), lo
 constexpr int kSteps = 16;                      // k-steps of v_mfma_f32_32x32x16_bf16 per layer
 constexpr int kChunks = 8192, kMaxBlocks = 512;
+// Balance state of a workspace (written by vfa_pipe_balance_f32, read by the frame kernel; nothing else touches it):
+//   int bounds[kMaxBlocks + 1]   workgroup wg of a launch of `tag` workgroups takes the pieces [bounds[wg], bounds[wg + 1]) of the kChunks
+//   int tag                      number of workgroups the bounds are for (0: none -- the uniform split)
+//   int sig[2]                   total estimated cost of the frame the bounds were made for (the cuts of another geometry do not match)
+//   u64 cycles[kMaxBlocks]       at byte 4096: cycles every workgroup of the LAST launch took
+constexpr int kBalTag = kMaxBlocks + 1, kBalSig = kMaxBlocks + 2, kBalCyclesAt = 4096, kBalanceBytes = kBalCyclesAt + kMaxBlocks * 8;
+constexpr int kSigAt = kChunks + 1; // the cuts kernel leaves the frame's total cost behind the last entry of chunk_start (2 ints)
 constexpr int kVis = 1;
 constexpr int kTileLive = 1, kTileDirect = 2;
 
@@ -235,6 +242,7 @@ struct CutArgs {
     const unsigned *globs;
     int n_scales, n_tiles, n_views, nl;
     int *chunk_start, *chunk_rank;
+    unsigned long long *chunk_cost; // (kChunks + 1): estimated cost of everything in front of the group boundary a piece starts at
 };
 __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
 {
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
         local += walk_tile(m, a.n_scales, a.nl, a.globs[t], [](int, unsigned, unsigned) {});
     }
     part[tid] = local;
-    for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_tiles; a.chunk_rank[c] = 0; }
+    for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_tiles; a.chunk_rank[c] = 0; a.chunk_cost[c] = ~0ull; }
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
         const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
@@ -262,6 +270,8 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
         __syncthreads();
     }
     const unsigned long long total = part[1023];
+    if (tid == 0) { a.chunk_start[kSigAt] = (int)(unsigned)total; a.chunk_start[kSigAt + 1] = (int)(unsigned)(total >> 32); }
+    // (pieces behind the last group keep chunk_cost = ~0: the balance kernel reads them as `total`)
     unsigned long long before = part[tid] - local;
     auto pos_of = [&](long long cc) { return (total * (unsigned long long)cc + kChunks - 1) / kChunks; };
     for (int t = t0; t < t1; ++t) {
@@ -280,11 +290,12 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
                 const int k = ((unsigned)(pc - tb) - w0) * 2 < (w1 - w0) ? kk : kk + 1;
                 if (k >= n_groups) { a.chunk_start[c] = t + 1 < n_tiles ? t + 1 : n_tiles; a.chunk_rank[c] = 0; }
                 else { a.chunk_start[c] = t; a.chunk_rank[c] = k; }
+                a.chunk_cost[c] = tb + (k == kk ? w0 : w1);
                 ++c;
             }
         });
         if (n_groups == 0)
-            for (; c < kChunks && pos_of(c) < tb + w; ++c) { a.chunk_start[c] = t; a.chunk_rank[c] = 0; }
+            for (; c < kChunks && pos_of(c) < tb + w; ++c) { a.chunk_start[c] = t; a.chunk_rank[c] = 0; a.chunk_cost[c] = tb; }
         before += w;
     }
 }
@@ -310,6 +321,7 @@ struct PipeArgs {
     int accumulate;
     unsigned long long *diag;       // per workgroup 8 counters (VFA_FLAG_DEBUG)
     int debug;
+    int *balance;                   // balance state of the workspace (kBalanceBytes: see kBalTag)
 };
 
 struct DevMasks {
@@ -451,14 +463,23 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     const int nblk = gridDim.x;
     const int lb = (int)xcd_contiguous(blockIdx.x, (nblk + 7) / 8);
     if (lb >= nblk) return;
+    // the pieces of workgroup wg: the uniform split, or the bounds a balance call left for exactly this frame and launch size
+    const long long t_start = __builtin_amdgcn_s_memtime();
+    const bool balanced = uniform_i(a.balance[kBalTag]) == nblk && uniform_i(a.balance[kBalSig]) == uniform_i(a.chunk_start[kSigAt]) &&
+                          uniform_i(a.balance[kBalSig + 1]) == uniform_i(a.chunk_start[kSigAt + 1]);
     auto range_of = [&](int wg, int &tb, int &kb, int &te, int &ke) {
-        const int c0 = (int)((long long)kChunks * wg / nblk), c1 = (int)((long long)kChunks * (wg + 1) / nblk);
+        int c0 = (int)((long long)kChunks * wg / nblk), c1 = (int)((long long)kChunks * (wg + 1) / nblk);
+        if (balanced) { c0 = uniform_i(a.balance[wg]); c1 = uniform_i(a.balance[wg + 1]); }
         tb = uniform_i(a.chunk_start[c0]); kb = uniform_i(a.chunk_rank[c0]);
         te = uniform_i(a.chunk_start[c1]); ke = uniform_i(a.chunk_rank[c1]);
     };
     int t_begin, k_begin, t_end, k_end;
     range_of(lb, t_begin, k_begin, t_end, k_end);
-    if (t_begin > t_end || (t_begin == t_end && k_begin >= k_end)) return;
+    unsigned long long *wg_cycles = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(a.balance) + kBalCyclesAt) + lb;
+    if (t_begin > t_end || (t_begin == t_end && k_begin >= k_end)) {
+        if (tid == 0) *wg_cycles = 0ull;
+        return;
+    }
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
     DevMasks masks;
     masks.l0 = a.sc[0].live; masks.l1 = a.sc[1].live; masks.l2 = a.sc[2].live;
@@ -1338,13 +1359,81 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 #ifndef VFA_PIPE_NO_MAT
         run(std::false_type{});
 #endif
+        // what this workgroup took (matrix wave 0 leaves the loop with the last step): vfa_pipe_balance_f32 moves the bounds by it
+        if (tid == 0) *wg_cycles = (unsigned long long)(__builtin_amdgcn_s_memtime() - t_start);
+    }
+}
+
+// Bounds of the workgroups' shares that minimise the HEAVIEST share (estimated cost), for a launch of nblk workgroups.  The uniform
+// split puts a bound at every (kChunks / nblk)-th piece and each bound then snaps to the nearest group -- a group is indivisible: up
+// to four views x all layers, 5 % of a workgroup's load on the shipped five-layer MultiviewC grid --, so a share can be a whole group
+// above the mean (slowest / mean workgroup 1.09 measured there).  Here: the smallest B for which the pieces split into at most nblk
+// contiguous shares of cost <= B (512 candidates per round, each thread sweeps its own; cost of a share = difference of the cumulative
+// costs the cuts kernel left per piece), then the greedy split for that B.  One workgroup; mode 0 clears the state.
+__global__ __launch_bounds__(kMaxBlocks) void pipe_balance_kernel(int *bal, const int *chunk_start, const unsigned long long *cost, int nblk, int mode)
+{
+    __shared__ unsigned long long s_lo, s_hi;
+    __shared__ int s_ok[kMaxBlocks];
+    const int tid = threadIdx.x;
+    if (mode == 0) {
+        if (tid == 0) { bal[kBalTag] = 0; bal[kBalSig] = 0; bal[kBalSig + 1] = 0; }
+        return;
+    }
+    const unsigned long long total = (unsigned long long)(unsigned)chunk_start[kSigAt] | ((unsigned long long)(unsigned)chunk_start[kSigAt + 1] << 32);
+    auto G = [&](int c) { const unsigned long long v = cost[c]; return v == ~0ull ? total : v; };
+    // last piece boundary e in [s, kChunks] with G(e) <= G(s) + B
+    auto reach = [&](int s0, unsigned long long B) {
+        const unsigned long long lim = G(s0) + B;
+        int lo = s0, hi = kChunks;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (G(mid) <= lim) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    };
+    auto feasible = [&](unsigned long long B) {
+        int s0 = 0;
+        for (int parts = 0; parts < nblk; ++parts) {
+            const int e = reach(s0, B);
+            if (e >= kChunks) return true;
+            if (e == s0) return false; // (one group heavier than B)
+            s0 = e;
+        }
+        return false;
+    };
+    if (tid == 0) { s_lo = total / (unsigned long long)nblk; s_hi = total; if (s_lo > 0) s_lo -= 1; }
+    __syncthreads();
+    for (int round = 0; round < 5; ++round) {
+        const unsigned long long lo = s_lo, hi = s_hi, span = hi - lo;
+        const unsigned long long B = lo + (span * (unsigned long long)(tid + 1)) / kMaxBlocks; // (tid = 511: hi, known feasible)
+        s_ok[tid] = feasible(B) ? 1 : 0;
+        __syncthreads();
+        if (tid == 0) {
+            int j = 0;
+            while (j < kMaxBlocks - 1 && !s_ok[j]) ++j;
+            s_hi = lo + (span * (unsigned long long)(j + 1)) / kMaxBlocks;
+            s_lo = j == 0 ? lo : lo + (span * (unsigned long long)j) / kMaxBlocks;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const unsigned long long B = s_hi;
+        int s0 = 0;
+        bal[0] = 0;
+        for (int wg = 0; wg < nblk; ++wg) {
+            int e = s0 < kChunks ? reach(s0, B) : kChunks;
+            if (wg == nblk - 1) e = kChunks;
+            bal[wg + 1] = e;
+            s0 = e;
+        }
+        bal[kBalTag] = nblk; bal[kBalSig] = chunk_start[kSigAt]; bal[kBalSig + 1] = chunk_start[kSigAt + 1];
     }
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PipeLayout {
-    size_t live[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, partial, diag, total;
+    size_t live[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, costs, partial, diag, balance, total;
     int tiles_l, tiles_w, n_tiles;
 };
 inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
@@ -1372,10 +1461,28 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
     }
     w.chunks = off;  off = align_up(off + (kChunks + 1) * sizeof(int), 256);
     w.ranks = off;   off = align_up(off + (kChunks + 1) * sizeof(int), 256);
+    w.costs = off;   off = align_up(off + (kChunks + 1) * sizeof(unsigned long long), 256);
     w.partial = off; off = align_up(off + (size_t)kMaxBlocks * 3 * 8 * 16 * 64 * sizeof(float), 256);
     w.diag = off;    off = align_up(off + (size_t)kMaxBlocks * 8 * sizeof(unsigned long long), 256);
+    w.balance = off; off = align_up(off + kBalanceBytes, 256); // work-cut bounds per workgroup + the last launch's times (vfa_pipe_balance_f32)
     w.total = off;
     return w;
+}
+
+// workgroups of a launch of the frame kernel: one per CU (less the reserved ones), a multiple of eight
+inline int pipe_blocks(int n_tiles, int reserved_cus)
+{
+    int n_cu = 256;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            cus > 0)
+            n_cu = cus;
+    }
+    if (reserved_cus > 0 && n_cu - reserved_cus >= 8) n_cu -= reserved_cus;
+    int nblk = n_tiles < n_cu ? n_tiles : n_cu;
+    nblk = (nblk + 7) / 8 * 8; // xcd_contiguous deals whole eighths; surplus workgroups find an empty range and leave
+    return nblk > kMaxBlocks ? kMaxBlocks : nblk;
 }
 
 inline bool dims_ok(int n_views, int L, int W, int nl, int n_scales)
@@ -1409,6 +1516,7 @@ int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_sca
     offsets[14] = lay.ranks;
     offsets[15] = lay.diag;
     offsets[16] = lay.total;
+    offsets[18] = lay.balance;
     tiles[0] = lay.tiles_l;
     tiles[1] = lay.tiles_w;
     tiles[2] = kWinSlots;
@@ -1469,6 +1577,7 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
     ca.n_scales = n_scales; ca.n_tiles = lay.n_tiles; ca.n_views = n_views; ca.nl = n_layers;
     ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
     ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);
+    ca.chunk_cost = reinterpret_cast<unsigned long long *>(ws + lay.costs);
     hipLaunchKernelGGL(pipe_cuts_kernel, dim3(1), dim3(1024), 0, s, ca);
     int st = (int)hipGetLastError();
     if (st) return st;
@@ -1484,6 +1593,20 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
         st = (int)hipGetLastError();
     }
     return st;
+}
+
+int vfa_pipe_balance_f32(int n_views, int L, int W, int n_layers, int n_scales, int reserved_cus, int mode, void *workspace,
+                         size_t workspace_bytes, void *stream)
+{
+    if (!dims_ok(n_views, L, W, n_layers, n_scales) || (mode != 0 && mode != 1)) return VFA_ERR_BAD_ARGUMENT;
+    const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
+    if (lay.n_tiles == 0 || n_views == 0) return 0;
+    if (!workspace || workspace_bytes < lay.total) return VFA_ERR_BAD_ARGUMENT;
+    unsigned char *ws = reinterpret_cast<unsigned char *>(workspace);
+    hipLaunchKernelGGL(pipe_balance_kernel, dim3(1), dim3(kMaxBlocks), 0, (hipStream_t)stream, reinterpret_cast<int *>(ws + lay.balance),
+                       reinterpret_cast<const int *>(ws + lay.chunks), reinterpret_cast<const unsigned long long *>(ws + lay.costs),
+                       pipe_blocks(lay.n_tiles, reserved_cus), mode);
+    return (int)hipGetLastError();
 }
 
 int vfa_pipe_records_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off,
@@ -1535,17 +1658,8 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *c
     a.tickets = reinterpret_cast<unsigned *>(ws + lay.tickets);
     a.diag = reinterpret_cast<unsigned long long *>(ws + lay.diag);
     a.debug = debug;
-    int n_cu = 256;
-    {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            cus > 0)
-            n_cu = cus;
-    }
-    if (reserved_cus > 0 && n_cu - reserved_cus >= 8) n_cu -= reserved_cus;
-    int nblk = lay.n_tiles < n_cu ? lay.n_tiles : n_cu;
-    nblk = (nblk + 7) / 8 * 8; // xcd_contiguous deals whole eighths; surplus workgroups find an empty range and leave
-    if (nblk > kMaxBlocks) nblk = kMaxBlocks;
+    a.balance = reinterpret_cast<int *>(ws + lay.balance);
+    const int nblk = pipe_blocks(lay.n_tiles, reserved_cus);
     // every call takes its own tickets: a second pass over the same workspace (accumulate) must not see the first one's
     const hipError_t e = hipMemsetAsync(a.tickets, 0, (size_t)lay.n_tiles * 4, s);
     if (e != hipSuccess) return (int)e;

@@ -603,15 +603,29 @@ def pipe_collapse(integrals, biases, workspace, grid_lw, n_layers, out=None, acc
     return out
 
 
+def pipe_balance(workspace, n_views, grid_lw, n_layers, n_scales, reserved_cus=0, reset=False):
+    """Balance state of a ``pipe_records`` workspace (``vfa_pipe_balance_f32``).  ``reset``: clear it (once, on a fresh workspace);
+    otherwise, from the work cuts ``pipe_records`` has just left there: the bounds of the workgroups' shares that minimise the
+    heaviest share -- used by every ``pipe_collapse`` launch of the same size on a frame with the same cuts (static cameras and
+    grid); deterministic."""
+    _lib.require_device(workspace)
+    L, W = grid_lw
+    _launch("vfa_pipe_balance_f32", int(n_views), int(L), int(W), int(n_layers), int(n_scales), int(reserved_cus), 0 if reset else 1,
+            _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle())
+
+
+BALANCE_STATE_BYTES = 8192  # (bounds + launch size + cost signature, and at byte 4096 the workgroups' cycle counts)
+
+
 def pipe_workspace_layout(n_views, L, W, n_layers, n_scales):
     """Offsets inside the ``pipe_records`` workspace, for tests and tools."""
     import ctypes
-    off = (ctypes.c_size_t * 18)()
+    off = (ctypes.c_size_t * 19)()
     tiles = (ctypes.c_int * 5)()
     _lib.call("vfa_pipe_workspace_layout", int(n_views), int(L), int(W), int(n_layers), int(n_scales), off, tiles)
     names = ("live", "hdrs", "recs", "wfrag")
     out = {nm: [int(off[4 * k + i]) for k in range(n_scales)] for i, nm in enumerate(names)}
     out.update(tickets=int(off[12]), globs=int(off[17]), chunks=int(off[13]), ranks=int(off[14]), diag=int(off[15]), total=int(off[16]),
                tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]),
-               max_slots_3piece=int(tiles[4]))
+               max_slots_3piece=int(tiles[4]), balance=int(off[18]))
     return out

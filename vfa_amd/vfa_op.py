@@ -258,12 +258,17 @@ def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumu
         side = _side_stream(dev) if SIDE_STREAM and integrals is None else cur
         weights = [m.collapse.weight for m in mods]  # reference layout: the weight-split kernel reads column c * nl + layer
         biases = [m.collapse.bias for m in mods]
-        ws = torch.empty(max(ops.pipe_workspace_bytes(n, min(rows, length), width, nl, ns), 1), dtype=torch.uint8, device=dev)
-        for r0 in range(0, length, rows):
+        band_rows = min(rows, length)
+        n_bands = (length + rows - 1) // rows
+        st = _pipe_state(dev, (n, length, width, band_rows, nl, ns, terms, int(reserved_cus), conv_kind, tuple(feat_hws)),
+                         ops.pipe_workspace_bytes(n, band_rows, width, nl, ns), n_bands)
+        ws = st["ws"]
+        balancing = PIPE_BALANCE and st["frames"] == 0
+        for b, r0 in enumerate(range(0, length, rows)):
             r1 = min(length, r0 + rows)
             band = grid[r0:r1]
             if side is not cur:
-                side.wait_stream(cur)  # (the previous band's kernel has read the workspace)
+                side.wait_stream(cur)  # (the previous band's -- or frame's -- kernel has read the workspace)
             with torch.cuda.stream(side):
                 ops.pipe_records(calibs, band, z_layers, corner_off, conv_kind, (img_w, img_h), feat_hws, weights=weights,
                                  crange=crange, workspace=ws, terms=terms)
@@ -271,11 +276,43 @@ def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumu
                 integrals = ops.integral_images(features)  # all strides in one launch pair, beside the geometry
             if side is not cur:
                 cur.wait_stream(side)
+            if n_bands > 1:  # one workspace for all bands: every band has its own balance state (and a shorter last band its own layout)
+                bal_off = st["balance_off"] if r1 - r0 == band_rows else ops.pipe_workspace_layout(n, r1 - r0, width, nl, ns)["balance"]
+                ws[bal_off:bal_off + ops.BALANCE_STATE_BYTES].copy_(st["bands"][b], non_blocking=True)
+            if balancing:
+                # First frame of a geometry: the shares of the kernel's workgroups that minimise the heaviest one (from this frame's
+                # work cuts; deterministic).  Cameras and grid of a frame stream stand still, so every later frame finds bounds
+                # that carry the signature of its own cuts; a frame with other cuts does not match and runs the uniform split.
+                ops.pipe_balance(ws, n, (r1 - r0, width), nl, ns, reserved_cus=reserved_cus)
+                if n_bands > 1:
+                    st["bands"][b].copy_(ws[bal_off:bal_off + ops.BALANCE_STATE_BYTES], non_blocking=True)
             ops.pipe_collapse(integrals, biases, ws, (r1 - r0, width), nl, out=out[r0 * width:r1 * width], accumulate=accumulate,
                               terms=terms, reserved_cus=reserved_cus)
+        st["frames"] += 1
         if side is not cur:
             ws.record_stream(side)
     return out
+
+
+# "1" (default): the first frame of a geometry computes balanced work shares for the pipelined kernel's workgroups
+# (`vfa_pipe_balance_f32`), kept with the persistent workspace; "0": the uniform split of the work cuts.
+PIPE_BALANCE = os.environ.get("VFA_AMD_PIPE_BALANCE", "1") == "1"
+_pipe_states = {}  # (device, shapes) -> persistent workspace (+ balance state per band); the two most recent geometries are kept
+
+
+def _pipe_state(dev, key, ws_bytes, n_bands):
+    key = (dev.index,) + key
+    st = _pipe_states.pop(key, None)
+    if st is None:
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        lay = ops.pipe_workspace_layout(key[1], key[4], key[3], key[5], key[6])
+        st = {"ws": ws, "frames": 0, "balance_off": lay["balance"],
+              "bands": [torch.zeros(ops.BALANCE_STATE_BYTES, dtype=torch.uint8, device=dev) for _ in range(n_bands)] if n_bands > 1 else None}
+        ws[lay["balance"]:lay["balance"] + ops.BALANCE_STATE_BYTES].zero_()  # (= vfa_pipe_balance_f32 mode 0)
+    _pipe_states[key] = st  # (most recent last)
+    while len(_pipe_states) > 2:
+        _pipe_states.pop(next(iter(_pipe_states)))
+    return st
 
 
 # Training: "1" (default) = the forward of a frame is the fused per-frame kernel (no voxel features, no pre-activations kept);
