@@ -298,6 +298,7 @@ def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumu
 # (`vfa_pipe_balance_f32`), kept with the persistent workspace; "0": the uniform split of the work cuts.
 PIPE_BALANCE = os.environ.get("VFA_AMD_PIPE_BALANCE", "1") == "1"
 _pipe_states = {}  # (device, shapes) -> persistent workspace (+ balance state per band); the two most recent geometries are kept
+_pipe_pinned = []  # ... and those a captured hipGraph replays into
 
 
 def _pipe_state(dev, key, ws_bytes, n_bands):
@@ -309,6 +310,10 @@ def _pipe_state(dev, key, ws_bytes, n_bands):
         st = {"ws": ws, "frames": 0, "balance_off": lay["balance"],
               "bands": [torch.zeros(ops.BALANCE_STATE_BYTES, dtype=torch.uint8, device=dev) for _ in range(n_bands)] if n_bands > 1 else None}
         ws[lay["balance"]:lay["balance"] + ops.BALANCE_STATE_BYTES].zero_()  # (= vfa_pipe_balance_f32 mode 0)
+    if torch.cuda.is_current_stream_capturing() and not st.get("pinned"):
+        # a hipGraph that is being captured will replay into this workspace for as long as it lives: never dropped from here on
+        st["pinned"] = True
+        _pipe_pinned.append(st)
     _pipe_states[key] = st  # (most recent last)
     while len(_pipe_states) > 2:
         _pipe_states.pop(next(iter(_pipe_states)))
