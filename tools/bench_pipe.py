@@ -136,6 +136,8 @@ with torch.no_grad():
             c0, c1 = K * lb // nblk, K * (lb + 1) // nblk
             tb, kb, te, ke = int(start[c0]), int(rank[c0]), int(start[c1]), int(rank[c1])
             real = half = dummy = glob = ntile = shared = groups = fills = 0
+            by_scale = [0, 0, 0]
+            masked = 0
             for t in range(tb, min(te + (1 if ke > 0 else 0), tiles)):
                 k = 0
                 mine = False
@@ -154,6 +156,9 @@ with torch.no_grad():
                                 sub = grp[2 * st:2 * st + 2]
                                 lv = [v for v in sub if hdrs[s][t, layer, v, 0] & 1]
                                 fills += 4 * sum(int(hdrs[s][t, layer, v, 1] + 3) // 4 for v in lv if not (hdrs[s][t, layer, v, 0] & 2))
+                                if lv:
+                                    by_scale[s] += 4 * len(sub)
+                                    masked += 4 * (len(sub) - len(lv))
                                 if lv and len(sub) == 1:
                                     half += 4  # (a set with one sub-tile: the matrix waves multiply one row block)
                                 elif lv:
@@ -165,12 +170,12 @@ with torch.no_grad():
                     ntile += 1
                     if (t == tb and kb > 0) or (t == te and ke > 0):
                         shared += 1
-            rows.append((blk, real, dummy, glob, ntile, shared, groups, d[blk, :7].sum(), half, fills))
-        A = np.array([[r[1], r[2], r[3], r[4], r[5], r[6], r[8], r[9]] for r in rows if r[7] > 0], np.float64)
+            rows.append((blk, real, dummy, glob, ntile, shared, groups, d[blk, :7].sum(), half, fills, by_scale[1], by_scale[2], masked))
+        A = np.array([[r[1], r[2], r[3], r[4], r[5], r[6], r[8], r[9], r[10], r[11], r[12]] for r in rows if r[7] > 0], np.float64)
         y = np.array([r[7] for r in rows if r[7] > 0])
         coef, *_ = np.linalg.lstsq(A, y, rcond=None)
         pred = A @ coef
-        print("  fit (cycles): full step %.0f, empty step %.0f, + per sub-tile step pooled from L2 %.0f, per tile %.0f, per shared tile %.0f, per group %.0f, half step %.0f, per window request (4 slots) %.0f"
+        print("  fit (cycles): full step %.0f, empty step %.0f, + per sub-tile step pooled from L2 %.0f, per tile %.0f, per shared tile %.0f, per group %.0f, half step %.0f, per window request (4 slots) %.0f; per sub-tile step at stride 16 %+.0f, at stride 32 %+.0f, per sub-tile step without a live box in the layer %+.0f"
               % tuple(coef))
         blks = np.array([r[0] for r in rows if r[7] > 0])
         res = (y - pred) / y.mean()
