@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define VFA_ABI_VERSION 5
+#define VFA_ABI_VERSION 6
 
 /* world-unit conversion of the grid, reference vfa_op.py:23-44 (chosen by args.data) */
 #define VFA_CONV_MULTIVIEWC 0 /* x / 1.0                                   */
@@ -61,7 +61,15 @@ extern "C" {
 int vfa_abi_version(void);
 
 /* Per-call `flags` of the MFMA collapse entry points (there is no process-wide state):
- *   bits 0-3   number of bf16 product terms per fp32 product: 0 = default (3), 3, 4 (adds lo*lo)
+ *   bits 0-3   arithmetic of the `collapse` product (reference: an fp32 nn.Linear, vfa_op.py:59, :123):
+ *                0 / 2  (default) TWO FP16 PIECES per operand, three products hi.hi + hi.lo + lo.hi, fp32 accumulation -- with a
+ *                       power-of-two scale per operand and feature scale the split is exact to 22 bits and the result has the error
+ *                       of an sgemm (2e-7 normwise against float64 at K = 256): the reference's arithmetic width.  The fused frame
+ *                       kernels only (vfa_pool_collapse_relu_sum_f32, vfa_pipe_collapse_relu_sum_f32 and their geometry calls);
+ *                       the unfused product kernels (vfa_collapse_relu_sum_f32, vfa_collapse_gemm_*) read 0 as 3.
+ *                3      two bf16 pieces, three products (16 bits: ~4e-6 normwise; inside the path's 1e-4 / 1e-5 tolerance)
+ *                4      ... plus lo.lo
+ *                6      three bf16 pieces, six products (sgemm class at twice the matrix work; vfa_pipe_* only)
  *   bits 8-15  VFA_FLAG_RESERVED_CUS(n): the persistent kernels (one workgroup per CU with all of its LDS) launch on at
  *              most n_cu - n CUs whenever that does not add a round of tiles.  Multi-GPU: leaves room for the RCCL
  *              kernels of the all-reduce that overlaps the next frame, which could otherwise only start at a kernel
@@ -98,13 +106,23 @@ int vfa_affine_relu_integral_image_f32(const float *x, const float *scale, const
  * both NULL (plain maps, vfa_integral_image_f32 of each) or both arrays of n_maps device pointers (n_views, C) (producer fusion,
  * vfa_affine_relu_integral_image_f32 of each).  Results are bit-identical to the per-map entry points; the small maps share the
  * launch of the large one instead of paying a launch pair each.   replaces the three vfa_op.py:110 calls of vfanet.py:76-78 */
+/* absmax (ABI v6): NULL, or a HOST array of n_maps device pointers (entries may be NULL), absmax[s] -> vfa_feature_stats_count(n_views,
+ * C, H_s) uint32: the call leaves there partial maxima of |feature| (fp32 bit patterns, sign cleared; the maximum of all entries is
+ * the map's largest |value| AFTER the affine + ReLU) -- the fused frame kernels scale their fp16 operand split by it.  No
+ * initialisation needed, every entry is written. */
+size_t vfa_feature_stats_count(int n_views, int C, int Hf);
 int vfa_integral_images_f32(const float *const *features, const float *const *scales, const float *const *shifts,
-                            float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream);
+                            float *const *integrals, unsigned *const *absmax, int n_views, int C, int n_maps, const int *feat_hw,
+                            void *stream);
+/* The same statistic from a finished integral image (n_views, Hf+2, Wf+2, C), for callers that kept no feature map: second
+ * differences of the integral image, exact up to its rounding -- enough for a power-of-two scale.  absmax: as above. */
+int vfa_integral_absmax_f32(const float *integral, unsigned *absmax, int n_views, int C, int Hf, int Wf, void *stream);
 
 /* The same for CHANNELS-LAST inputs features_hwc[s] (n_views, H_s, W_s, C) -- what vfa_lateral_conv_f32 writes --: no NCHW copy of the
  * lateral convolution exists.  C a multiple of 64.  Bit-identical to vfa_integral_images_f32 of the permuted input. */
 int vfa_integral_images_hwc_f32(const float *const *features_hwc, const float *const *scales, const float *const *shifts,
-                                float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream);
+                                float *const *integrals, unsigned *const *absmax, int n_views, int C, int n_maps, const int *feat_hw,
+                                void *stream);
 
 /* The lateral branch of one feature scale, as far as the integral image needs it:
  *   y = conv1x1(feat) + bias            feat (n_views, K, Hf, Wf) NCHW (the trunk's output), weight (256, K) = lat.weight.view(256, K)
@@ -262,15 +280,20 @@ size_t vfa_frame_workspace_bytes(int n_views, int L, int W, int n_scales);
 int vfa_frame_workspace_layout(int n_views, int L, int W, int n_scales, size_t *offsets, int *tiles);
 int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
                           int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
-                          const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream);
+                          const int *feat_hw, const float *const *weights, int flags, void *workspace, size_t workspace_bytes,
+                          void *stream);
 /* The same in two calls (vfa_frame_records_f32 = boxes, then cuts): vfa_frame_boxes_f32 projects the boxes and writes records,
  * headers, masks and the list of direct items; vfa_frame_cuts_f32 forms the work cuts of the persistent kernel from them and
  * splits the collapse weights (`weights` NULL: left as they are in the workspace).                 replaces vfa_op.py:64-106 */
 int vfa_frame_boxes_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
                         int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
                         const int *feat_hw, void *workspace, size_t workspace_bytes, void *stream);
-int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *const *weights, void *workspace, size_t workspace_bytes,
-                       void *stream);
+int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *const *weights, int flags, void *workspace,
+                       size_t workspace_bytes, void *stream);
+/* (flags, ABI v6: VFA_FLAG_TERMS_MASK -- the arithmetic the weights are split for; pass what goes to vfa_pool_collapse_relu_sum_f32.
+ * vfa_pool_collapse_relu_sum_f32 / vfa_pipe_collapse_relu_sum_f32 take `feat_absmax`: NULL, or a HOST array of n_scales device
+ * pointers to the statistics vfa_integral_images_f32 left for the SAME integral images (entries may be NULL).  With the default
+ * fp16 arithmetic a scale without statistics costs one extra pass over its integral image inside the call.) */
 /* Box pooling alone from the same workspace: vox (n_views, L * W, 256) fp32, BIT-IDENTICAL to vfa_project_gather_f32 (layer-major,
  * nl = 1): four bilinear samples of the integral image of scale `scale`, (((lt + rb) - rt) - lb) / area * visible.
  *                                                                                            replaces vfa_op.py:112-120
@@ -278,9 +301,9 @@ int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *con
  * read from L2 / HBM once; bound by the HBM write of `vox`.  Hf, Wf must be the sizes the records of `scale` were built for. */
 int vfa_pool_windows_f32(const float *integral, const void *workspace, size_t workspace_bytes, float *vox, int n_views, int L, int W,
                          int n_scales, int scale, int Hf, int Wf, void *stream);
-int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, const void *workspace,
-                                   size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales, const int *feat_hw,
-                                   int accumulate, int flags, void *stream);
+int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned *const *feat_absmax, const float *const *biases,
+                                   const void *workspace, size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales,
+                                   const int *feat_hw, int accumulate, int flags, void *stream);
 
 /* ---- the frame as a producer / consumer pipeline, any number of z-layers (vfa_pipe.hip) ----------------------------------------
  *
@@ -326,14 +349,14 @@ int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_sca
 int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off, int n_views,
                        int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales, const int *feat_hw,
                        int flags, void *workspace, size_t workspace_bytes, void *stream);
-int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, const float *const *weights, void *workspace,
+int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, const float *const *weights, int flags, void *workspace,
                       size_t workspace_bytes, void *stream);
 int vfa_pipe_records_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off,
                          int n_views, int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
                          const int *feat_hw, const float *const *weights, int flags, void *workspace, size_t workspace_bytes, void *stream);
-int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, void *workspace, size_t workspace_bytes,
-                                   float *out, int n_views, int L, int W, int n_layers, int n_scales, const int *feat_hw, int accumulate,
-                                   int flags, void *stream);
+int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned *const *feat_absmax, const float *const *biases,
+                                   void *workspace, size_t workspace_bytes, float *out, int n_views, int L, int W, int n_layers,
+                                   int n_scales, const int *feat_hw, int accumulate, int flags, void *stream);
 int vfa_pipe_balance_f32(int n_views, int L, int W, int n_layers, int n_scales, int reserved_cus, int mode, void *workspace,
                          size_t workspace_bytes, void *stream);
 

@@ -467,7 +467,7 @@ def test_two_call_forms_of_the_entry_points_are_bitwise_the_one_call_forms():
         got = ops.pool_collapse(integrals, biases, two, (L, W), stage="main")
     assert torch.equal(got, ref)
     with pytest.raises(_lib.VFAHipError):  # both stage flags at once
-        _lib.call("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array([None] * 3), _lib.ptr(two), two.numel(),
+        _lib.call("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), None, _lib.ptr_array([None] * 3), _lib.ptr(two), two.numel(),
                   _lib.ptr(got), 2, L, W, 3, _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)]), 0,
                   _lib.FLAG_ROWS_ONLY | _lib.FLAG_SKIP_ROWS, _lib.current_stream_handle())
 
@@ -529,3 +529,54 @@ def test_work_cuts_cover_every_item_once(name, n_cam, crop):
         assert per.sum() == items.sum()
         cost = np.diff(cost_upto[idx])
         assert cost.max() - cost.min() <= biggest + 0.03 * cost.mean(), (cost.min(), cost.max(), biggest)
+
+
+def test_serial_kernel_default_product_has_the_width_of_the_reference_sgemm(monkeypatch):
+    """`pool_collapse_kernel<2>` (the default of single-layer grids): two fp16 pieces per operand with a power-of-two scale, three
+    MFMA products (vfa_split.h).  The reference's ``collapse`` is an fp32 ``nn.Linear`` (vfa_op.py:59, :123): against float64
+    the fused frame must sit where an fp32 library GEMM on the same (bit-pinned) voxel features sits -- <= 1.3 x its normwise
+    error or 3e-7 --, on ordinary, signed, 1e4 x and 1e-6 x feature maps, with or without the statistics of the integral-image call
+    (without them the entry point derives the scale from the integral images), and an order of magnitude inside the two-piece bf16
+    form (VFA_FLAG_TERMS 3)."""
+    from vfa_amd import _lib, ops, vfa_op
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload("multiviewc_200x200x1", channels=256, seed=3, n_cam=5)
+    grid = wl["grid"][:, 70:70 + 48, 50:50 + 96].contiguous().to(dev)
+    mods = _mods(wl, dev)
+    lats0 = [torch.cat([wl["features"][c][s] for c in range(5)]).to(dev) for s in range(3)]
+    calibs = wl["calibs"].to(dev)
+    L, W = grid.shape[1:3]
+    z_layers, corner_off = mods[0]._kernel_geometry(dev)
+    kind, img_wh = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
+    weights = [m.layer_major_weight() for m in mods]
+
+    def run(lats, terms, with_stats=True):
+        ws = ops.frame_records(calibs, grid, z_layers, corner_off, kind, img_wh, [tuple(l.shape[-2:]) for l in lats], weights=weights, terms=terms)
+        integrals = ops.integral_images(lats)
+        return ops.pool_collapse(integrals if with_stats else list(integrals), [m.collapse.bias for m in mods], ws, (L, W), terms=terms)
+
+    for label, factor, shift in (("relu(randn)", 1.0, 0.0), ("signed", 1.0, -0.4), ("x 1e4", 1e4, 0.0), ("x 1e-6", 1e-6, 0.0)):
+        lats = [l * factor + shift for l in lats0]
+        saved = [m.collapse.bias.detach().clone() for m in mods]
+        with torch.no_grad():
+            if factor < 1e-3:  # (the bias would drown the product: leave it out of this variant)
+                for m in mods:
+                    m.collapse.bias.zero_()
+            want = _float64_reference(mods, lats, calibs, grid, wl)
+            lib32 = torch.zeros(L * W, 256, device=dev)
+            grid_flat = grid.reshape(-1, 3).contiguous()
+            for m, lat in zip(mods, lats):
+                vox = ops.project_gather(ops.integral_image(lat), calibs.reshape(5, 12).contiguous(), grid_flat, z_layers, corner_off, kind, img_wh,
+                                         kernel="direct")
+                lib32 += torch.relu(torch.matmul(vox, m.collapse.weight.T) + m.collapse.bias).sum(0)
+            got2, got2n, got3 = run(lats, 2), run(lats, 2, with_stats=False), run(lats, 3)
+            for m, b in zip(mods, saved):
+                m.collapse.bias.copy_(b)
+        err = lambda t: ((t.double() - want).norm() / want.norm()).item()
+        e2, e2n, e3, e32 = err(got2), err(got2n), err(got3), err(lib32)
+        print(f"[width] serial kernel, {label}: fp16 x 2 {e2:.2e} (scale from the integral images: {e2n:.2e}), fp32 library GEMM {e32:.2e}, bf16 x 2 {e3:.2e}")
+        assert torch.isfinite(got2).all() and torch.isfinite(got2n).all()
+        assert e2 <= max(1.3 * e32, 3e-7) and e2n <= max(1.3 * e32, 3e-7), (label, e2, e2n, e32)
+        assert e3 >= 3 * e2, (label, e2, e3)
+        _check(f"serial kernel {label} fp16 x 2", got2, want)

@@ -497,3 +497,99 @@ def test_three_piece_product_has_the_width_of_the_reference_sgemm(name, n_cam, c
         assert e6 <= 5e-7, (label, e6)
         assert m6 <= 2e-6, (label, m6)
         _check(f"{name} {label} two pieces", got3, want)
+
+
+def _sgemm_reference(mods, lats, calibs, grid, wl):
+    """The same sum with the product as a plain fp32 library GEMM on the bit-pinned voxel features: what the reference's fp32
+    nn.Linear (vfa_op.py:123) is, numerically."""
+    from vfa_amd import _lib, ops
+    dev = grid.device
+    n = calibs.shape[0]
+    grid_flat = grid.reshape(-1, 3).contiguous()
+    out = torch.zeros(grid_flat.shape[0], 256, dtype=torch.float32, device=dev)
+    for m, lat in zip(mods, lats):
+        zl, co = m._kernel_geometry(dev)
+        vox = ops.project_gather(ops.integral_image(lat), calibs.reshape(n, 12).contiguous(), grid_flat, zl, co,
+                                 _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1], kernel="direct")
+        out += torch.relu(torch.matmul(vox, m.layer_major_weight().T) + m.collapse.bias).sum(0)
+    return out
+
+
+@pytest.mark.parametrize("name,n_cam,crop,origin", [
+    ("multiviewc_200x200x1", 7, (48, 96), (70, 50)),      # K = 256
+    ("multiviewc_156x156x5", 5, (32, 56), (60, 40)),      # K = 1280
+])
+def test_fp16_split_product_has_the_width_of_the_reference_sgemm(name, n_cam, crop, origin):
+    """VFA_FLAG_TERMS 2, the default: two fp16 pieces per operand with a power-of-two scale, three products (vfa_split.h).  The
+    reference's ``collapse`` is an fp32 ``nn.Linear`` (vfa_op.py:123).  Against float64 the default product must sit where an fp32
+    library GEMM on the same voxel features sits (<= 1.3 x its normwise error, or 3e-7), on ordinary and signed maps and on maps
+    scaled by 1e4 and 1e-6 (the scale follows the feature maximum); on heavy-tailed maps (dynamic range 2^17 inside one map) it stays
+    inside 1e-6 normwise and far inside the path's tolerance.  The two-piece bf16 form (terms 3) is an order of magnitude wider."""
+    from vfa_amd import vfa_op
+    dev = _dev()
+    wl, grid, lats, calibs = _frame(name, n_cam, crop, dev, origin=origin)
+    mods = _mods(wl, dev)
+    gen = torch.Generator().manual_seed(11)
+    variants = {
+        "relu(randn)": lats,
+        "signed": [l - 0.4 for l in lats],
+        "x 1e4": [l * 1e4 for l in lats],
+        "x 1e-6": [l * 1e-6 for l in lats],
+        "heavy-tailed": [l * (torch.exp(2.5 * torch.randn(l.shape, generator=gen)) * torch.sign(torch.randn(l.shape, generator=gen))).to(dev)
+                         for l in lats],
+    }
+    for label, feats in variants.items():
+        if label == "x 1e-6":  # (the bias would drown the product: leave it out of this variant)
+            saved = [m.collapse.bias.detach().clone() for m in mods]
+            with torch.no_grad():
+                for m in mods:
+                    m.collapse.bias.zero_()
+        with torch.no_grad():
+            want = _float64_reference(mods, feats, calibs, grid, wl)
+            lib32 = _sgemm_reference(mods, feats, calibs, grid, wl)
+            got2 = vfa_op.pipe_frame(mods, feats, calibs, grid, terms=2)
+            got3 = vfa_op.pipe_frame(mods, feats, calibs, grid, terms=3)
+        if label == "x 1e-6":
+            with torch.no_grad():
+                for m, b in zip(mods, saved):
+                    m.collapse.bias.copy_(b)
+        scale = want.abs().max().item()
+        e2 = ((got2.double() - want).norm() / want.norm()).item()
+        e3 = ((got3.double() - want).norm() / want.norm()).item()
+        e32 = ((lib32.double() - want).norm() / want.norm()).item()
+        m2 = (got2.double() - want).abs().max().item() / scale
+        print(f"[width] {name} {label}: fp16 x 2 normwise {e2:.2e} (max {m2:.2e} of max|out|), fp32 library GEMM {e32:.2e}, bf16 x 2 {e3:.2e}")
+        assert torch.isfinite(got2).all()
+        if label == "heavy-tailed":
+            assert e2 <= 1e-6, (label, e2)
+        else:
+            assert e2 <= max(1.3 * e32, 3e-7), (label, e2, e32)
+            assert e3 >= 3 * e2, (label, e2, e3)
+        _check(f"{name} {label} fp16 x 2", got2, want)
+
+
+def test_fp16_split_saturates_instead_of_overflowing_and_keeps_nan():
+    """vfa_split.h: a voxel feature beyond fp16's range after scaling (here: feature maps whose statistics are deliberately those of
+    a map 1e6 times smaller) must come out finite (MODE.FP16_OVFL: +-65504 instead of Inf - Inf = NaN), a NaN feature stays a NaN in
+    the cells that see it and nowhere else."""
+    from vfa_amd import ops, vfa_op
+    dev = _dev()
+    wl, grid, lats, calibs = _frame("multiviewc_156x156x5", 3, (16, 24), dev, origin=(60, 40))
+    mods = _mods(wl, dev)
+    with torch.no_grad():
+        good = vfa_op.pipe_frame(mods, lats, calibs, grid)
+        integrals = ops.integral_images(lats)
+        tiny = ops.integral_images([l * 1e-6 for l in lats])
+        integrals.absmax = tiny.absmax  # the scale of a map a million times smaller: every voxel feature overflows fp16
+        sat = vfa_op.pipe_frame(mods, None, calibs, grid, integrals=integrals)
+        assert torch.isfinite(sat).all()
+        assert not torch.allclose(sat, good, rtol=1e-2, atol=0.0)  # (and it IS wrong: the statistics must belong to the maps)
+        poisoned = [l.clone() for l in lats]
+        poisoned[0][0, 3, 0, 0] = float("nan")  # (the double cumsum spreads it over the whole of channel 3 of camera 0: as in the reference)
+        out = vfa_op.pipe_frame(mods, poisoned, calibs, grid)
+        want = _float64_reference(mods, poisoned, calibs, grid, wl)
+        bad = torch.isnan(want).any(dim=1)
+        assert bad.any(), "camera 0 should see cells of the crop"
+        assert torch.equal(torch.isnan(out), torch.isnan(want))
+        if not bad.all():
+            _check("cells that do not see the NaN", out[~bad], want[~bad])

@@ -93,3 +93,101 @@ def test_six_term_product_is_sgemm_class(K):
     e3 = np.linalg.norm(three - ref) / np.linalg.norm(ref)
     assert e6 <= 3e-8, e6
     assert 3e-7 <= e3 <= 1e-5, e3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the default arithmetic of the fused frame kernels: two fp16 pieces per operand with a power-of-two scale (vfa_split.h)
+# ---------------------------------------------------------------------------------------------------------------------------
+EXP_A, EXP_W, EXP_LIM = 14, 14, 40  # vfa_split.h: kExpA, kExpW, kExpLim
+
+
+def split_exponent(absmax, target):
+    """vfa_split.h: split_exponent -- the power of two that brings `absmax` into [2^target, 2^(target+1))."""
+    bits = int(np.float32(absmax).view(np.uint32)) & 0x7FFFFFFF
+    if bits == 0 or bits >= 0x7F800000:
+        return 0
+    return int(np.clip(target - ((bits >> 23) - 127), -EXP_LIM, EXP_LIM))
+
+
+def f16_sat(x):
+    """fp32 -> fp16, round to nearest even, overflow clamped to +-65504 (MODE.FP16_OVFL), NaN / Inf kept; returned as fp32."""
+    x = np.asarray(x, dtype=np.float32)
+    with np.errstate(over="ignore"):
+        h = x.astype(np.float16)
+    h = np.where(np.isinf(h) & np.isfinite(x), np.copysign(np.float16(65504), h), h)
+    return h.astype(np.float32)
+
+
+def split16(x, e):
+    s = (x * np.float32(2.0 ** e)).astype(np.float32)
+    hi = f16_sat(s)
+    lo = f16_sat((s - hi).astype(np.float32))
+    return hi, lo
+
+
+def test_fp16_split_is_exact_to_two_fp16_mantissas_over_the_range_of_the_scale():
+    """x 2^e = hi + lo + r with |r| <= 2^-23 |x 2^e| wherever lo is a normal fp16 number, and |r| <= 2^-25 (half a subnormal step)
+    below that: with the maximum at 2^14 every element down to 2^-14 of it keeps 22 bits, whatever the magnitude of the map."""
+    rng = np.random.default_rng(0)
+    for mag in (1.0, 1e4, 1e-6, 1e-7, 1e8):  # (|e| <= 40: maxima from 2^-26 to 2^54)
+        x = (rng.standard_normal(100000) * 10.0 ** rng.uniform(-4, 0, 100000) * mag).astype(np.float32)
+        e = split_exponent(np.abs(x).max(), EXP_A)
+        hi, lo = split16(x, e)
+        s = x.astype(np.float64) * 2.0 ** e
+        assert 2.0 ** 14 <= np.abs(s).max() < 2.0 ** 15
+        r = s - hi.astype(np.float64) - lo.astype(np.float64)
+        assert np.all(np.abs(r) <= np.maximum(2.0 ** -23 * np.abs(s), 2.0 ** -25)), mag
+        big = np.abs(s) >= 1.0  # 2^-14 of the maximum and up
+        assert np.all(np.abs(r[big]) <= 2.0 ** -23 * np.abs(s[big]))
+
+
+@pytest.mark.parametrize("K", [256, 1280, 8192])
+def test_fp16_three_product_scheme_is_sgemm_class(K):
+    """hi.hi + hi.lo + lo.hi of the scaled fp16 pieces against float64, beside a plain fp32 product of the same operands
+    (np.float32 matmul: what the reference's nn.Linear is, vfa_op.py:123): the split contributes <= 1e-7 normwise (the dropped
+    lo.lo is 2^-22 of a product), below the rounding of an fp32 accumulation over K terms -- and an order of magnitude below the
+    two-piece bf16 form.  Voxel-like A (non-negative, a third of the rows masked), nn.Linear-scale W."""
+    rng = np.random.default_rng(K)
+    M, N = 256, 256
+    a = (rng.random((M, K)) * 3.0).astype(np.float32)
+    a[rng.random(M) < 0.3] = 0.0
+    w = ((rng.random((N, K)) - 0.5) * (2.0 / np.sqrt(K))).astype(np.float32)
+    f64 = np.float64
+    ea, ew = split_exponent(np.abs(a).max() * 4, EXP_A), split_exponent(np.abs(w).max(), EXP_W)  # (features are ~4 x the voxel features)
+    a_hi, a_lo = (p.astype(f64) for p in split16(a, ea))
+    w_hi, w_lo = (p.astype(f64) for p in split16(w, ew))
+    out = (a_hi @ w_hi.T + a_hi @ w_lo.T + a_lo @ w_hi.T) * 2.0 ** -(ea + ew)
+    ref = a.astype(f64) @ w.astype(f64).T
+    e16 = np.linalg.norm(out - ref) / np.linalg.norm(ref)
+    e32 = np.linalg.norm((a @ w.T).astype(f64) - ref) / np.linalg.norm(ref)
+    hb, lb = split(a)
+    whb, wlb = split(w)
+    eb = np.linalg.norm(hb.astype(f64) @ whb.astype(f64).T + hb.astype(f64) @ wlb.astype(f64).T + lb.astype(f64) @ whb.astype(f64).T - ref) / np.linalg.norm(ref)
+    assert e16 <= 1e-7, e16
+    assert e16 <= e32, (e16, e32)       # the split alone stays below what fp32 accumulation costs an sgemm
+    assert eb >= 10 * e16, (eb, e16)    # ... and an order of magnitude below the 16-bit two-piece bf16 split
+
+
+def test_fp16_split_range_nan_and_saturation():
+    """Range: the same relative error for maps of magnitude 1e4 and 1e-6 (the scale follows the maximum).  NaN and Inf survive
+    both pieces; a value beyond fp16's range after scaling saturates to finite pieces (never Inf - Inf)."""
+    rng = np.random.default_rng(5)
+    base = (rng.random((64, 256)) * 3.0).astype(np.float32)
+    w = ((rng.random((256, 256)) - 0.5) * 0.125).astype(np.float32)
+    errs = []
+    for mag in (1.0, 1e4, 1e-6):
+        a = (base * np.float32(mag)).astype(np.float32)
+        ea, ew = split_exponent(np.abs(a).max() * 4, EXP_A), split_exponent(np.abs(w).max(), EXP_W)
+        a_hi, a_lo = (p.astype(np.float64) for p in split16(a, ea))
+        w_hi, w_lo = (p.astype(np.float64) for p in split16(w, ew))
+        out = (a_hi @ w_hi.T + a_hi @ w_lo.T + a_lo @ w_hi.T) * 2.0 ** -(ea + ew)
+        ref = a.astype(np.float64) @ w.astype(np.float64).T
+        errs.append(np.linalg.norm(out - ref) / np.linalg.norm(ref))
+    assert max(errs) <= 1e-7 and max(errs) <= 1.5 * min(errs), errs
+    hi, lo = split16(np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 3.0], np.float32), 10)
+    assert np.isnan(hi[0]) and np.isnan(lo[0])
+    assert np.isinf(hi[1]) and np.isinf(hi[2])                     # (an infinite feature: Inf - Inf in lo, NaN in the product -- as in the bf16 forms)
+    assert hi[3] == 65504 and lo[3] == 65504 and hi[4] == -65504 and lo[4] == -65504  # saturated, finite
+    assert hi[5] + lo[5] == 3.0 * 2 ** 10
+    assert split_exponent(0.0, EXP_A) == 0 and split_exponent(np.nan, EXP_A) == 0 and split_exponent(np.inf, EXP_A) == 0
+    assert split_exponent(1e-30, EXP_A) == EXP_LIM and split_exponent(1e30, EXP_A) == -EXP_LIM

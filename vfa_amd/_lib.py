@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFA_AMD_LIB") or os.path.join(_HERE, "csrc", "libvfa_hip.so")  # (override: A/B runs of two builds)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 CONV_KIND = {"MultiviewC": 0, "MultiviewX": 1, "Wildtrack": 2}
 VOX_REFERENCE, VOX_LAYER_MAJOR = 0, 1
@@ -20,7 +20,8 @@ FLAG_ROWS_ONLY, FLAG_SKIP_ROWS = 1 << 28, 1 << 29  # VFA_FLAG_ROWS_ONLY / VFA_FL
 
 
 def collapse_flags(terms=0, reserved_cus=0):
-    """`flags` of the MFMA collapse entry points: product terms (0 = default 3) | VFA_FLAG_RESERVED_CUS(n)."""
+    """`flags` of the MFMA collapse entry points: product arithmetic (0 / 2 = two fp16 pieces, the default of the fused frame
+    kernels; 3 / 4 / 6 = the bf16 forms) | VFA_FLAG_RESERVED_CUS(n)."""
     return (int(terms) & 0xf) | ((int(reserved_cus) & 0xff) << 8)
 
 
@@ -52,8 +53,10 @@ SIGNATURES = {
     "vfa_collapse_gemm_f32": [_vp, _vp, _vp, _vp, _c_size_t, _c_size_t, _c_int, _c_int, _c_int, _vp],
     "vfa_collapse_gemm_relu_backward_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_size_t, _c_int, _c_int, _c_int, _vp],
     "vfa_collapse_relu_sum_f32": [_vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
-    "vfa_integral_images_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp],
-    "vfa_integral_images_hwc_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp],
+    "vfa_feature_stats_count": [_c_int, _c_int, _c_int],
+    "vfa_integral_images_f32": [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp],
+    "vfa_integral_images_hwc_f32": [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp],
+    "vfa_integral_absmax_f32": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_lateral_conv_workspace_bytes": [_c_int, _c_int, _c_int],
     "vfa_lateral_conv_f32": [_vp, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_sort_vertices_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp],
@@ -61,21 +64,21 @@ SIGNATURES = {
     "vfa_frame_workspace_bytes": [_c_int, _c_int, _c_int, _c_int],
     "vfa_frame_workspace_layout": [_c_int, _c_int, _c_int, _c_int, _vp, _vp],
     "vfa_frame_records_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
-                              _c_int, _vp, _vp, _vp, _c_size_t, _vp],
+                              _c_int, _vp, _vp, _c_int, _vp, _c_size_t, _vp],
     "vfa_frame_boxes_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
                             _c_int, _vp, _vp, _c_size_t, _vp],
-    "vfa_frame_cuts_f32": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_size_t, _vp],
+    "vfa_frame_cuts_f32": [_c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _c_size_t, _vp],
     "vfa_pool_windows_f32": [_vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp],
-    "vfa_pool_collapse_relu_sum_f32": [_vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
+    "vfa_pool_collapse_relu_sum_f32": [_vp, _vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
                                        _vp],
     "vfa_pipe_workspace_bytes": [_c_int, _c_int, _c_int, _c_int, _c_int],
     "vfa_pipe_workspace_layout": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp],
     "vfa_pipe_boxes_f32": [_vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
                            _c_int, _vp, _c_int, _vp, _c_size_t, _vp],
-    "vfa_pipe_cuts_f32": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_size_t, _vp],
+    "vfa_pipe_cuts_f32": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp, _c_size_t, _vp],
     "vfa_pipe_records_f32": [_vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float,
                              _c_int, _vp, _vp, _c_int, _vp, _c_size_t, _vp],
-    "vfa_pipe_collapse_relu_sum_f32": [_vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
+    "vfa_pipe_collapse_relu_sum_f32": [_vp, _vp, _vp, _vp, _c_size_t, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
                                        _vp],
     "vfa_pipe_balance_f32": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_size_t, _vp],
 }
@@ -99,7 +102,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_size_t if name.endswith("_bytes") else ctypes.c_int
+            fn.restype = ctypes.c_size_t if name.endswith(("_bytes", "_count")) else ctypes.c_int
         got = handle.vfa_abi_version()
         if got != ABI_VERSION:
             raise VFAHipError(f"libvfa_hip.so has ABI version {got}, the Python side expects {ABI_VERSION}; rebuild")

@@ -229,7 +229,7 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
             "integral-image inputs need a per-frame inference path"
         ortho = torch.empty((length * width, vfa8.collapse.out_features), dtype=torch.float32, device=grid.device)
         frame = vfa_op.pipe_frame if vfa_op.pipe_frame_ok(mods3, n) else vfa_op.fused_frame
-        frame(mods3, None, calibs, grid, crange, out=ortho, reserved_cus=reserved, integrals=list(integrals))
+        frame(mods3, None, calibs, grid, crange, out=ortho, reserved_cus=reserved, integrals=integrals)  # (an ops.IntegralImages keeps its feature statistics)
     elif n > 0 and vfa_op.fused_train_ok(mods3, n, (lat8, lat16, lat32)):
         # training: the fused kernel in the forward, voxel features and pre-activations recomputed scale by scale in the backward
         ortho = vfa_op.fused_frame_train(mods3, [lat8, lat16, lat32], calibs, grid, crange, reserved_cus=reserved)

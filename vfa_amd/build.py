@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 
 def build(force=False, verbose=False):
-    cmd = ["make", "-C", CSRC] + (["-B"] if force else []) + ["libvfa_hip.so"]
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else []) + ["libvfa_hip.so"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         sys.stdout.write(res.stdout)

@@ -249,7 +249,7 @@ extern "C" int vfa_collapse_relu_sum_f32(const float *vox, const float *weight, 
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
     if (flags & ~(VFA_FLAG_TERMS_MASK | 0xff00)) return VFA_ERR_BAD_ARGUMENT;
-    if (n_views < 0 || K <= 0 || N <= 0 || (terms != 0 && terms != 3 && terms != 4)) return VFA_ERR_BAD_ARGUMENT;
+    if (n_views < 0 || K <= 0 || N <= 0 || (terms != 0 && terms != 2 && terms != 3 && terms != 4 && terms != 6)) return VFA_ERR_BAD_ARGUMENT;
     if (K != kK || N != kN) return VFA_ERR_UNSUPPORTED;
     if (M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;

@@ -248,7 +248,7 @@ static int collapse_gemm_launch(const float *vox, const float *weight, float *ou
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
     if (flags & ~(VFA_FLAG_TERMS_MASK | 0xff00)) return VFA_ERR_BAD_ARGUMENT;
-    if (K <= 0 || N <= 0 || (terms != 0 && terms != 3 && terms != 4)) return VFA_ERR_BAD_ARGUMENT;
+    if (K <= 0 || N <= 0 || (terms != 0 && terms != 2 && terms != 3 && terms != 4 && terms != 6)) return VFA_ERR_BAD_ARGUMENT;
     if (N != kN || K % kChunk != 0) return VFA_ERR_UNSUPPORTED;
     if (M == 0) return 0;
     if (!workspace || workspace_bytes < vfa_collapse_gemm_workspace_bytes(K, N)) return VFA_ERR_BAD_ARGUMENT;

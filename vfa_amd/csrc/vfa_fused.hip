@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "vfa_geom.h"
+#include "vfa_split.h"
 
 namespace {
 using namespace vfa_dev;
@@ -209,7 +210,28 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
 
 // collapse.weight (N = 256, K = 256) fp32 -> bf16 hi / lo planes in MFMA B-fragment order:
 //   out[((wave * 16 + s) * 2 + plane) * 64 + lane] (16 B) = W[n = 32 wave + (lane & 31)][k = 16 s + 8 (lane >> 5) + j], j = 0..7
-struct SplitArgs { const float *w[kMaxScales]; uint4 *out[kMaxScales]; };
+// F16 (VFA_FLAG_TERMS 2, the default): the two-piece fp16 split of vfa_split.h, scaled by 2^ew with max|W| 2^ew in [2^14, 2^15)
+// -- the maximum comes from weight_absmax_kernel (kWmaxParts partial maxima per scale), the exponent is left in wexp[scale] for
+// the frame kernel.
+constexpr int kWmaxParts = 32;
+struct SplitArgs { const float *w[kMaxScales]; uint4 *out[kMaxScales]; unsigned *wmax; int *wexp; int f16; };
+__global__ __launch_bounds__(256) void weight_absmax_kernel(SplitArgs sa, int count)
+{
+    __shared__ unsigned part[4];
+    const float *__restrict__ w = sa.w[blockIdx.y];
+    unsigned m = 0u;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += kWmaxParts * 256) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) sa.wmax[blockIdx.y * kWmaxParts + blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+__device__ __forceinline__ int weight_exponent(const unsigned *wmax, int scale)
+{
+    unsigned m = 0u;
+    for (int i = 0; i < kWmaxParts; ++i) m = max(m, wmax[scale * kWmaxParts + i]);
+    return split_exponent(m, kExpW);
+}
 __global__ __launch_bounds__(256) void split_weight_frag_kernel(SplitArgs sa)
 {
     const float *__restrict__ w = sa.w[blockIdx.y];
@@ -218,15 +240,29 @@ __global__ __launch_bounds__(256) void split_weight_frag_kernel(SplitArgs sa)
     if (idx >= 8 * kSteps * 64) return;
     const int lane = idx & 63, s = (idx >> 6) & 15, wave = idx >> 10;
     const float *src = w + (size_t)(wave * 32 + (lane & 31)) * kC + 16 * s + 8 * (lane >> 5);
-    union { __bf16 b[8]; uint4 u; } hi, lo;
+    uint4 uh, ul;
+    if (sa.f16) {
+        fp16_saturate_mode(true);
+        const int ew = weight_exponent(sa.wmax, blockIdx.y);
+        if (idx == 0) sa.wexp[blockIdx.y] = ew;
+        const float sc = pow2f(ew);
+        uint2 h0, l0, h1, l1;
+        split_f16x4(src[0] * sc, src[1] * sc, src[2] * sc, src[3] * sc, h0, l0);
+        split_f16x4(src[4] * sc, src[5] * sc, src[6] * sc, src[7] * sc, h1, l1);
+        uh = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        ul = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    } else {
+        union { __bf16 b[8]; uint4 u; } hi, lo;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = src[j];
-        hi.b[j] = (__bf16)x;
-        lo.b[j] = (__bf16)(x - (float)hi.b[j]);
+        for (int j = 0; j < 8; ++j) {
+            const float x = src[j];
+            hi.b[j] = (__bf16)x;
+            lo.b[j] = (__bf16)(x - (float)hi.b[j]);
+        }
+        uh = hi.u; ul = lo.u;
     }
-    out[((size_t)(wave * kSteps + s) * 2 + 0) * 64 + lane] = hi.u;
-    out[((size_t)(wave * kSteps + s) * 2 + 1) * 64 + lane] = lo.u;
+    out[((size_t)(wave * kSteps + s) * 2 + 0) * 64 + lane] = uh;
+    out[((size_t)(wave * kSteps + s) * 2 + 1) * 64 + lane] = ul;
 }
 
 // Work balance of the persistent kernel: the item sequence (tile, scale, view) is cut into kChunks pieces of equal estimated COST;
@@ -360,6 +396,8 @@ struct FusedScale {
     const unsigned *live, *direct, *overflow; // (n_tiles) each
     const unsigned char *hdrs, *recs;
     int Hf, Wf;
+    const unsigned *amax;           // amax_n partial maxima of |feature| (fp32 bits): the scale of the fp16 split (vfa_split.h)
+    int amax_n;
 };
 struct FusedArgs {
     FusedScale sc[kMaxScales];
@@ -372,6 +410,7 @@ struct FusedArgs {
     const unsigned *row_counter;    // direct items of the frame
     int rows_cap;                   // row slots in the workspace
     int accumulate;
+    const int *wexp;                // (kMaxScales) scale exponent of the split collapse weight (split_weight_frag_kernel; fp16 form)
     int debug;                      // diagnostic build only: ablation mask (kDbg*), results are then meaningless
     unsigned long long *diag;       // diagnostic build only: per workgroup 8 cycle counters
 };
@@ -405,32 +444,30 @@ struct LRec { uint4 v[6]; }; // one box record per lane: v[0..3] the 16 tap weig
 
 // x = hi + lo + r exactly in fp32 arithmetic: hi = RNE bf16(x), lo = RNE bf16(x - hi); row `row` of the A tile, channels
 // 4 c4 .. 4 c4 + 3, written into the XOR-swizzled hi / lo planes
-__device__ __forceinline__ void store_quad(unsigned char *planes, int row, int c4, float4 v)
-{
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    union { __bf16 b[4]; uint2 u; } hi, lo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        hi.b[j] = (__bf16)x[j];
-        lo.b[j] = (__bf16)(x[j] - (float)hi.b[j]);
-    }
-    const int off = row * kRowBytes + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
-    *reinterpret_cast<uint2 *>(planes + off) = hi.u;
-    *reinterpret_cast<uint2 *>(planes + kPlane + off) = lo.u;
-}
-
-// the same with the byte offset inside a plane given
+// F16: the two-piece fp16 split of vfa_split.h (v already carries the scale 2^ea)
+template <bool F16>
 __device__ __forceinline__ void store_quad_at(unsigned char *planes, int off, float4 v)
 {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    union { __bf16 b[4]; uint2 u; } hi, lo;
+    uint2 hu, lu;
+    if constexpr (F16) {
+        split_f16x4(v.x, v.y, v.z, v.w, hu, lu);
+    } else {
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        union { __bf16 b[4]; uint2 u; } hi, lo;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        hi.b[j] = (__bf16)x[j];
-        lo.b[j] = (__bf16)(x[j] - (float)hi.b[j]);
+        for (int j = 0; j < 4; ++j) {
+            hi.b[j] = (__bf16)x[j];
+            lo.b[j] = (__bf16)(x[j] - (float)hi.b[j]);
+        }
+        hu = hi.u; lu = lo.u;
     }
-    *reinterpret_cast<uint2 *>(planes + off) = hi.u;
-    *reinterpret_cast<uint2 *>(planes + kPlane + off) = lo.u;
+    *reinterpret_cast<uint2 *>(planes + off) = hu;
+    *reinterpret_cast<uint2 *>(planes + kPlane + off) = lu;
+}
+template <bool F16>
+__device__ __forceinline__ void store_quad(unsigned char *planes, int row, int c4, float4 v)
+{
+    store_quad_at<F16>(planes, row * kRowBytes + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3)), v);
 }
 
 struct Item { int tile, scale, view; unsigned rest; bool valid; int rank; }; // rest: live views of (tile, scale) above `view`; rank: index among the tile's live items
@@ -444,6 +481,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     __shared__ __align__(16) unsigned char s_planes[2 * kPlane];    // 32 KiB: bf16 hi / lo planes of the 32 x 256 A tile
     __shared__ uint4 s_hdr[2][16];                                  // tile headers of the next two items (32 B used of each 256)
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
+    constexpr bool F16 = TERMS == 2; // two fp16 pieces per operand (vfa_split.h) instead of two bf16 pieces
 
     // Main launch: a contiguous range of tiles of equal COST for this workgroup (tile_chunks_kernel); neighbouring ranges
     // share an XCD (their tap windows overlap).  Direct-item launch: tiles dealt round-robin -- those items sit in clusters
@@ -488,6 +526,33 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     if (!DIRECT && k_begin > 0) share_of(t_begin, sh_b_first, sh_b_last, sh_b_parts);
     if (!DIRECT && k_end > 0) share_of(t_end, sh_e_first, sh_e_last, sh_e_parts);
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
+
+    // fp16 form: per scale, the factor 2^ea of the voxel features (from the largest |feature| the integral-image kernels saw) and
+    // 2^(ea + ew) / 2^-(ea + ew) for the bias in the accumulator / the epilogue (powers of two: exact)
+    float f_a[kMaxScales] = {1.0f, 1.0f, 1.0f}, f_fwd[kMaxScales] = {1.0f, 1.0f, 1.0f}, f_inv[kMaxScales] = {1.0f, 1.0f, 1.0f};
+    if constexpr (F16) {
+        __shared__ unsigned s_amax[kMaxScales];
+        if (tid < kMaxScales) s_amax[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < kMaxScales; ++s2) {
+            if (s2 < a.n_scales) {
+                unsigned m = 0u;
+                for (int i = tid; i < a.sc[s2].amax_n; i += kThreads) m = max(m, a.sc[s2].amax[i]);
+                m = wave_max_u32(m);
+                if (lane == 0) atomicMax(&s_amax[s2], m);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < kMaxScales; ++s2) {
+            if (s2 < a.n_scales) {
+                const int ea = split_exponent((unsigned)uniform_i((int)s_amax[s2]), kExpA), ew = uniform_i(a.wexp[s2]);
+                f_a[s2] = pow2f(ea); f_fwd[s2] = pow2f(ea + ew); f_inv[s2] = pow2f(-(ea + ew));
+            }
+        }
+    }
+    auto pick = [&](const float (&t)[kMaxScales], int scale) { return scale == 0 ? t[0] : (scale == 1 ? t[1] : t[2]); };
 
     // view masks come by SCALAR loads (constant address space: the records kernel finished before this launch): a vector load
     // here would queue behind the window DMA of the next item, which is in flight whenever the item sequence is advanced
@@ -636,13 +701,16 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                                              (__attribute__((address_space(3))) void *)(s_taps + (kMaxSlots + k) * 64), 16, 0, 0);
         }
     };
-    auto pool = [&](const Item &it, int it_flags, int it_word1) {
+    auto pool = [&](const Item &it, int it_flags, int it_word1, float s_a) {
         if (!DIRECT && (it_flags & kTileRows)) {
-            // a direct item of the main launch: its pooled rows arrived as its window (slot b = row of box b); only the bf16
+            // a direct item of the main launch: its pooled rows arrived as its window (slot b = row of box b); only the
             // split remains
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                store_quad(s_planes, 4 * wave + grp, q * 16 + cq, s_taps[(4 * wave + grp) * 64 + q * 16 + cq]);
+            for (int q = 0; q < 4; ++q) {
+                float4 v = s_taps[(4 * wave + grp) * 64 + q * 16 + cq];
+                if constexpr (F16) v = mul4(v, s_a);
+                store_quad<F16>(s_planes, 4 * wave + grp, q * 16 + cq, v);
+            }
             return;
         }
         const FusedScale &sc = a.sc[it.scale];
@@ -691,14 +759,15 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         // a masked box reads slot / pixel 0 (finite) and multiplies by its masked value (0, or NaN for a NaN box) instead of
         // selecting afterwards; the A-plane address of quarter q is that of quarter 0 with one bit pair flipped
         // (((8 q + a) ^ r) << 4 = ((a ^ r) << 4) ^ (q << 7) for a < 8): both keep VALU work out of the quarter passes
-        const float scale = vis ? rcp : masked;
+        // (fp16 form: times 2^ea -- a power of two, so v * (rcp 2^ea) = (v * rcp) 2^ea exactly)
+        const float scale = F16 ? (vis ? rcp : masked) * s_a : (vis ? rcp : masked);
         const int plane0 = row * kRowBytes + (((((cq >> 1) ^ (row & 15)) << 4)) | ((cq & 1) << 3));
         auto finish = [&](int q, float4 lt, float4 rb, float4 rt, float4 lb) {
             // (((lt + rb) - rt) - lb) * RN(1 / area)                                              (A.6)
             float4 v = make_float4(lt.x + rb.x, lt.y + rb.y, lt.z + rb.z, lt.w + rb.w);
             v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
             v = make_float4(v.x - lb.x, v.y - lb.y, v.z - lb.z, v.w - lb.w);
-            store_quad_at(s_planes, plane0 ^ (q << 7), make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale));
+            store_quad_at<F16>(s_planes, plane0 ^ (q << 7), make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale));
         };
         if constexpr (DIRECT) {
 #pragma unroll 1
@@ -797,7 +866,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     Item nxt = seek(cur.tile, cur.scale, cur.rest, cur.rank + 1);
     if (nxt.valid) header_of(nxt, hbuf);
     int w_scale = -1;
-    float bc = 0.0f;
+    float bc = 0.0f, sa_cur = 1.0f, inv_cur = 1.0f;
     f32x16 sum;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
@@ -870,9 +939,13 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         if (cur.scale != w_scale && !((dbg & kDbgOneW) && w_scale >= 0)) { // W and bias of this scale: land while the boxes are pooled
             load_weights(cur.scale);
             bc = bias_of(cur.scale);
+            if constexpr (F16) { bc *= pick(f_fwd, cur.scale); sa_cur = pick(f_a, cur.scale); inv_cur = pick(f_inv, cur.scale); }
             w_scale = cur.scale;
         }
-        if (!(dbg & kDbgNoPool)) pool(cur, cur_flags, cur_word1);
+        // (the conversions of the fp16 split saturate instead of overflowing; the MFMAs below need the default mode: vfa_split.h)
+        if constexpr (F16) fp16_saturate_mode(true);
+        if (!(dbg & kDbgNoPool)) pool(cur, cur_flags, cur_word1, sa_cur);
+        if constexpr (F16) fp16_saturate_mode(false);
         tick(3);
         // W, the bias and the tile stores of `flush` were issued a pooling pass ago.  Waiting for them HERE, explicitly, is
         // what keeps the compiler from doing it in front of the first MFMA, behind the DMA instructions issued below: its
@@ -923,16 +996,27 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[k % 3]), "+v"(fl[k % 3]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[k % 3], w[k].lo, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[k % 3], w[k].hi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[k % 3], w[k].hi, acc, 0, 0, 0);
-                if (TERMS >= 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[k % 3], w[k].lo, acc, 0, 0, 0);
+                if constexpr (F16) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, fh[k % 3]), al = __builtin_bit_cast(f16x8, fl[k % 3]);
+                    const f16x8 wh = __builtin_bit_cast(f16x8, w[k].hi), wl = __builtin_bit_cast(f16x8, w[k].lo);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[k % 3], w[k].lo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[k % 3], w[k].hi, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[k % 3], w[k].hi, acc, 0, 0, 0);
+                    if (TERMS >= 4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[k % 3], w[k].lo, acc, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         rest_fills(); // windows of more than 64 slots
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sum[i] = sum[i] + relu_t(acc[i]); // vfa_op.py:124; vfanet.py:79, 82
+        for (int i = 0; i < 16; ++i) { // vfa_op.py:124; vfanet.py:79, 82
+            if constexpr (F16) sum[i] = fmaf(relu_t(acc[i]), inv_cur, sum[i]); // (relu(acc) 2^-(ea+ew) is exact: the same bits as multiply, then add)
+            else sum[i] = sum[i] + relu_t(acc[i]);
+        }
         tick(6);
 
         if (!nxt.valid || nxt.tile != cur.tile) {
@@ -1274,7 +1358,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WorkspaceLayout {
     size_t live[kMaxScales], direct[kMaxScales], overflow[kMaxScales], counter, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales],
-        masks_bytes, chunks, ranks, diag, rows, row_list, partial, tickets, item_w, total;
+        masks_bytes, chunks, ranks, diag, rows, row_list, partial, tickets, item_w, wmax, wexp, amax, total;
     int tiles_l, tiles_w, n_tiles, rows_cap, views_pad;
 };
 inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
@@ -1317,6 +1401,9 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     w.rows_cap = (int)cap;
     w.row_list = off;
     off = align_up(off + cap * sizeof(unsigned), 256);
+    w.wmax = off; off = align_up(off + (size_t)kMaxScales * kWmaxParts * sizeof(unsigned), 256); // fp16 split: partial maxima of |W| per scale,
+    w.wexp = off; off = align_up(off + kMaxScales * sizeof(int), 256);                            // ... the weight exponents,
+    w.amax = off; off = align_up(off + (size_t)kMaxScales * kFallbackStats * sizeof(unsigned), 256); // ... and feature statistics made here for callers that pass none
     w.views_pad = (n_views + 7) / 8 * 8; // cost estimates of the items, per tile (tile_chunks_kernel)
     w.item_w = off;
     off = align_up(off + (size_t)w.n_tiles * kMaxScales * w.views_pad * sizeof(unsigned short) + 16, 256);
@@ -1410,9 +1497,11 @@ int vfa_frame_boxes_f32(const float *calibs, const float *grid, const float *z_l
     return (int)hipGetLastError();
 }
 
-int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *const *weights, void *workspace, size_t workspace_bytes,
-                       void *stream)
+int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *const *weights, int flags, void *workspace,
+                       size_t workspace_bytes, void *stream)
 {
+    const int terms = flags & VFA_FLAG_TERMS_MASK;
+    if ((flags & ~VFA_FLAG_TERMS_MASK) || (terms != 0 && terms != 2 && terms != 3 && terms != 4)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales) return VFA_ERR_BAD_ARGUMENT;
     if (n_views > 32) return VFA_ERR_UNSUPPORTED;
     const WorkspaceLayout lay = layout_of(n_views, L, W, n_scales);
@@ -1441,6 +1530,14 @@ int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *con
             sa.out[k] = reinterpret_cast<uint4 *>(ws + lay.wfrag[k < n_scales ? k : 0]);
             if (!sa.w[k]) return VFA_ERR_BAD_ARGUMENT;
         }
+        sa.wmax = reinterpret_cast<unsigned *>(ws + lay.wmax);
+        sa.wexp = reinterpret_cast<int *>(ws + lay.wexp);
+        sa.f16 = (terms == 0 || terms == 2) ? 1 : 0;
+        if (sa.f16) {
+            hipLaunchKernelGGL(weight_absmax_kernel, dim3(kWmaxParts, n_scales), dim3(256), 0, s, sa, kC * kC);
+            st = (int)hipGetLastError();
+            if (st) return st;
+        }
         hipLaunchKernelGGL(split_weight_frag_kernel, dim3(8 * kSteps * 64 / 256, n_scales), dim3(256), 0, s, sa);
         st = (int)hipGetLastError();
     }
@@ -1450,12 +1547,12 @@ int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *con
 // a single entry point = few launches: boxes (memset + records kernel), then the work cuts and one weight-split launch
 int vfa_frame_records_f32(const float *calibs, const float *grid, const float *z_layers, const float *corner_off, int n_views, int L,
                           int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int n_scales,
-                          const int *feat_hw, const float *const *weights, void *workspace, size_t workspace_bytes, void *stream)
+                          const int *feat_hw, const float *const *weights, int flags, void *workspace, size_t workspace_bytes, void *stream)
 {
     const int st = vfa_frame_boxes_f32(calibs, grid, z_layers, corner_off, n_views, L, W, conv_kind, img_w, img_h, cmin, cmax, n_scales, feat_hw,
                                        workspace, workspace_bytes, stream);
     if (st) return st;
-    return vfa_frame_cuts_f32(n_views, L, W, n_scales, weights, workspace, workspace_bytes, stream);
+    return vfa_frame_cuts_f32(n_views, L, W, n_scales, weights, flags, workspace, workspace_bytes, stream);
 }
 
 int vfa_pool_windows_f32(const float *integral, const void *workspace, size_t workspace_bytes, float *vox, int n_views, int L, int W,
@@ -1493,16 +1590,17 @@ int vfa_pool_windows_f32(const float *integral, const void *workspace, size_t wo
     return (int)hipGetLastError();
 }
 
-int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, const void *workspace,
-                                   size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales, const int *feat_hw,
-                                   int accumulate, int flags, void *stream)
+int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned *const *feat_absmax, const float *const *biases,
+                                   const void *workspace, size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales,
+                                   const int *feat_hw, int accumulate, int flags, void *stream)
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xfff;
     if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00 | VFA_FLAG_ROWS_ONLY | VFA_FLAG_SKIP_ROWS)) return VFA_ERR_BAD_ARGUMENT;
     if ((flags & VFA_FLAG_ROWS_ONLY) && (flags & VFA_FLAG_SKIP_ROWS)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales || !feat_hw || !integrals ||
-        (terms != 0 && terms != 3 && terms != 4))
+        (terms != 0 && terms != 2 && terms != 3 && terms != 4))
         return VFA_ERR_BAD_ARGUMENT;
+    const bool f16 = terms == 0 || terms == 2;
     if (n_views > 32) return VFA_ERR_UNSUPPORTED;
     const WorkspaceLayout lay = layout_of(n_views, L, W, n_scales);
     if (lay.n_tiles == 0) return 0;
@@ -1528,7 +1626,23 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
         a.sc[k].Hf = feat_hw[2 * q];
         a.sc[k].Wf = feat_hw[2 * q + 1];
         if (!a.sc[k].integral) return VFA_ERR_BAD_ARGUMENT;
+        a.sc[k].amax = nullptr; a.sc[k].amax_n = 0;
     }
+    if (f16 && !(flags & VFA_FLAG_ROWS_ONLY)) {
+        // the scale of the fp16 split: what the integral-image call left (feat_absmax), or one pass over the integral images here
+        for (int k = 0; k < n_scales; ++k) {
+            if (feat_absmax && feat_absmax[k]) {
+                a.sc[k].amax = feat_absmax[k];
+                a.sc[k].amax_n = (int)feature_stats_count(n_views, kC, a.sc[k].Hf);
+            } else {
+                unsigned *dst = reinterpret_cast<unsigned *>(const_cast<unsigned char *>(ws) + lay.amax) + (size_t)k * kFallbackStats;
+                const int st = integral_absmax_folded(a.sc[k].integral, dst, n_views, kC, a.sc[k].Hf, a.sc[k].Wf, kFallbackStats, &a.sc[k].amax_n, stream);
+                if (st) return st;
+                a.sc[k].amax = dst;
+            }
+        }
+    }
+    a.wexp = reinterpret_cast<const int *>(ws + lay.wexp);
     a.n_scales = n_scales; a.n_views = n_views; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles;
     a.out = out; a.accumulate = accumulate;
     a.chunk_start = reinterpret_cast<const int *>(ws + lay.chunks);
@@ -1570,23 +1684,27 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const float *c
         if (e != hipSuccess) return (int)e;
     }
     if (debug & 64) { // diagnostic: only the second launch (direct items without a row slot)
-        hipLaunchKernelGGL((pool_collapse_kernel<3, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+        hipLaunchKernelGGL((pool_collapse_kernel<2, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
         return (int)hipGetLastError();
     }
-    if (debug) // diagnostic build (ablations / cycle stamps): never used by the product path
-        hipLaunchKernelGGL((pool_collapse_kernel<3, true, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+    if (debug) // diagnostic build (ablations / cycle stamps) of the default arithmetic: never used by the product path
+        hipLaunchKernelGGL((pool_collapse_kernel<2, true, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     else if (terms == 4)
         hipLaunchKernelGGL((pool_collapse_kernel<4, false, false>), dim3(nblk), dim3(kThreads), 0, s, a);
-    else
+    else if (terms == 3)
         hipLaunchKernelGGL((pool_collapse_kernel<3, false, false>), dim3(nblk), dim3(kThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL((pool_collapse_kernel<2, false, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     int st = (int)hipGetLastError();
     if (st || debug) return st;
     // the few items whose tap window does not fit LDS: same kernel, taps straight from the image, ADDED to the map (the
     // launch leaves at once where there are none)
     if (terms == 4)
         hipLaunchKernelGGL((pool_collapse_kernel<4, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
-    else
+    else if (terms == 3)
         hipLaunchKernelGGL((pool_collapse_kernel<3, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL((pool_collapse_kernel<2, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 

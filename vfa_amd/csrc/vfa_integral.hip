@@ -16,6 +16,7 @@
 
 #include "../../include/vfa_hip.h"
 #include "vfa_geom.h"
+#include "vfa_split.h"
 
 namespace {
 using namespace vfa_dev;
@@ -31,6 +32,7 @@ struct MapDesc {
     int H, W;
     unsigned row_blocks; // H * (C / 64) * n_views
     unsigned long long col_vecs; // n_views * (W + 2) * C / 4
+    unsigned *absmax;    // (row_blocks) or NULL: max |feature| (fp32 bits, sign cleared) over the wave-row of every block of pass 1
 };
 struct MapArgs {
     MapDesc m[kMaxMaps];
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(kWave) void rows_batched_kernel(MapArgs a)
     };
     const int q = lane & 7, cq = lane & 15;
     double acc = 0.0;
+    unsigned amax = 0u; // largest |feature| of this lane's channel row (what the fp16 split of the fused kernels is scaled by: vfa_split.h)
     for (int x0 = 0; x0 < W; x0 += kChunk) {
         const int nx = min(kChunk, W - x0); // a multiple of 4
         if (4 * q < nx) {
@@ -82,7 +85,9 @@ __global__ __launch_bounds__(kWave) void rows_batched_kernel(MapArgs a)
         }
         __syncthreads();
         for (int k = 0; k < nx; ++k) {
-            acc += (double)act(tile[lane][k]);
+            const float f = act(tile[lane][k]);
+            amax = max(amax, __float_as_uint(f) & 0x7fffffffu);
+            acc += (double)f;
             tile[lane][k] = (float)acc;
         }
         __syncthreads();
@@ -91,6 +96,10 @@ __global__ __launch_bounds__(kWave) void rows_batched_kernel(MapArgs a)
             *reinterpret_cast<float4 *>(dst + (size_t)(x0 + k + 1) * C + 4 * cq) = t;
         }
         __syncthreads();
+    }
+    if (m.absmax) {
+        amax = wave_max_u32(amax);
+        if (lane == 0) m.absmax[b] = amax;
     }
 }
 
@@ -126,6 +135,7 @@ __global__ __launch_bounds__(kWave) void rows_hwc_kernel(MapArgs a)
     };
     constexpr int U = 8;
     double acc = 0.0;
+    unsigned amax = 0u;
     int x = 0;
     for (; x + U <= W; x += U) {
         float t[U];
@@ -133,13 +143,21 @@ __global__ __launch_bounds__(kWave) void rows_hwc_kernel(MapArgs a)
         for (int k = 0; k < U; ++k) t[k] = src[(size_t)(x + k) * C];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            acc += (double)act(t[k]);
+            const float f = act(t[k]);
+            amax = max(amax, __float_as_uint(f) & 0x7fffffffu);
+            acc += (double)f;
             dst[(size_t)(x + k + 1) * C] = (float)acc;
         }
     }
     for (; x < W; ++x) {
-        acc += (double)act(src[(size_t)x * C]);
+        const float f = act(src[(size_t)x * C]);
+        amax = max(amax, __float_as_uint(f) & 0x7fffffffu);
+        acc += (double)f;
         dst[(size_t)(x + 1) * C] = (float)acc;
+    }
+    if (m.absmax) {
+        amax = wave_max_u32(amax);
+        if (lane == 0) m.absmax[b] = amax;
     }
 }
 
@@ -188,14 +206,64 @@ __global__ __launch_bounds__(256) void cols_batched_kernel(MapArgs a, unsigned l
     }
 }
 
+// The same statistic from a finished integral image (callers that have no feature map at hand, odd shapes): the feature value
+// of a pixel is the second difference of its four integral-image neighbours -- exact up to the rounding of the integral image
+// (~6e-8 of its largest value), which is all a power-of-two scale with a factor 32 of headroom needs.  One wave per entry =
+// (view, row, 64-channel block), the layout of pass 1 above.
+__global__ __launch_bounds__(kWave) void integral_absmax_kernel(const float *integral, unsigned *absmax, int n_views, int C, int H, int W,
+                                                                unsigned units)
+{
+    const int lane = threadIdx.x, cblocks = (C + kWave - 1) / kWave;
+    unsigned amax = 0u;
+    for (unsigned b = blockIdx.x; b < units; b += gridDim.x) { // (one entry per BLOCK: a grid smaller than `units` folds them)
+        const int y = (int)(b % (unsigned)H);
+        const unsigned rest = b / (unsigned)H;
+        const int c = (int)(rest % (unsigned)cblocks) * kWave + lane, v = (int)(rest / (unsigned)cblocks);
+        if (c < C) {
+            const float *up = integral + (((size_t)v * (H + 2) + y) * (W + 2)) * C + c, *dn = up + (size_t)(W + 2) * C;
+            float u0 = up[0], d0 = dn[0];
+            for (int x = 1; x <= W; ++x) {
+                const float u1 = up[(size_t)x * C], d1 = dn[(size_t)x * C];
+                const float f = ((d1 - u1) - d0) + u0;
+                amax = max(amax, __float_as_uint(f) & 0x7fffffffu);
+                u0 = u1; d0 = d1;
+            }
+        }
+    }
+    amax = wave_max_u32(amax);
+    if (lane == 0) absmax[blockIdx.x] = amax;
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 } // namespace
 
+namespace vfa_dev {
+size_t feature_stats_count(int n_views, int C, int Hf)
+{
+    if (n_views < 0 || C <= 0 || Hf <= 0) return 0;
+    return (size_t)n_views * Hf * ((C + kWave - 1) / kWave);
+}
+// the same folded into at most `max_entries` entries (the frame entry points, for callers without statistics: their workspaces
+// hold VFA_FALLBACK_STATS entries per scale); returns the number of entries written through *n_entries
+int integral_absmax_folded(const float *integral, unsigned *absmax, int n_views, int C, int Hf, int Wf, int max_entries, int *n_entries,
+                               void *stream)
+{
+    const size_t n = feature_stats_count(n_views, C, Hf);
+    if (!integral || !absmax || max_entries <= 0 || n == 0 || n >= (1ull << 31)) return VFA_ERR_BAD_ARGUMENT;
+    const unsigned grid = n < (size_t)max_entries ? (unsigned)n : (unsigned)max_entries;
+    hipLaunchKernelGGL(integral_absmax_kernel, dim3(grid), dim3(kWave), 0, (hipStream_t)stream, integral, absmax, n_views, C, Hf, Wf, (unsigned)n);
+    *n_entries = (int)grid;
+    return (int)hipGetLastError();
+}
+
+} // namespace vfa_dev
+
 extern "C" {
 
 static int integral_images_launch(const float *const *features, const float *const *scales, const float *const *shifts,
-                                  float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, bool hwc, void *stream)
+                                  float *const *integrals, unsigned *const *absmax, int n_views, int C, int n_maps, const int *feat_hw,
+                                  bool hwc, void *stream)
 {
     MapArgs a = {};
     a.n_maps = n_maps; a.n_views = n_views; a.C = C;
@@ -204,6 +272,7 @@ static int integral_images_launch(const float *const *features, const float *con
         MapDesc &m = a.m[s];
         m.feat = features[s]; m.out = integrals[s];
         m.scale = scales ? scales[s] : nullptr; m.shift = shifts ? shifts[s] : nullptr;
+        m.absmax = absmax ? absmax[s] : nullptr;
         m.H = feat_hw[2 * s]; m.W = feat_hw[2 * s + 1];
         const unsigned long long rb = (unsigned long long)m.H * (C / kWave) * n_views;
         if (rb >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
@@ -226,8 +295,22 @@ static int integral_images_launch(const float *const *features, const float *con
     return (int)hipGetLastError();
 }
 
+size_t vfa_feature_stats_count(int n_views, int C, int Hf) { return vfa_dev::feature_stats_count(n_views, C, Hf); }
+
+int vfa_integral_absmax_f32(const float *integral, unsigned *absmax, int n_views, int C, int Hf, int Wf, void *stream)
+{
+    if (!integral || !absmax || n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0) return VFA_ERR_BAD_ARGUMENT;
+    const size_t n = vfa_feature_stats_count(n_views, C, Hf);
+    if (n == 0) return 0;
+    if (n >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(integral_absmax_kernel, dim3((unsigned)n), dim3(kWave), 0, (hipStream_t)stream, integral, absmax, n_views, C, Hf, Wf,
+                       (unsigned)n);
+    return (int)hipGetLastError();
+}
+
 int vfa_integral_images_f32(const float *const *features, const float *const *scales, const float *const *shifts,
-                            float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream)
+                            float *const *integrals, unsigned *const *absmax, int n_views, int C, int n_maps, const int *feat_hw,
+                            void *stream)
 {
     if (!features || !integrals || !feat_hw || n_views < 0 || C <= 0 || n_maps < 0) return VFA_ERR_BAD_ARGUMENT;
     if ((scales == nullptr) != (shifts == nullptr)) return VFA_ERR_BAD_ARGUMENT;
@@ -245,14 +328,19 @@ int vfa_integral_images_f32(const float *const *features, const float *const *sc
                                                                         feat_hw[2 * s], feat_hw[2 * s + 1], stream)
                                   : vfa_integral_image_f32(features[s], integrals[s], n_views, C, feat_hw[2 * s], feat_hw[2 * s + 1], stream);
             if (st) return st;
+            if (absmax && absmax[s]) { // (the per-map kernels keep no statistics: one more pass, over the result)
+                const int st2 = vfa_integral_absmax_f32(integrals[s], absmax[s], n_views, C, feat_hw[2 * s], feat_hw[2 * s + 1], stream);
+                if (st2) return st2;
+            }
         }
         return 0;
     }
-    return integral_images_launch(features, scales, shifts, integrals, n_views, C, n_maps, feat_hw, false, stream);
+    return integral_images_launch(features, scales, shifts, integrals, absmax, n_views, C, n_maps, feat_hw, false, stream);
 }
 
 int vfa_integral_images_hwc_f32(const float *const *features_hwc, const float *const *scales, const float *const *shifts,
-                                float *const *integrals, int n_views, int C, int n_maps, const int *feat_hw, void *stream)
+                                float *const *integrals, unsigned *const *absmax, int n_views, int C, int n_maps, const int *feat_hw,
+                                void *stream)
 {
     if (!features_hwc || !integrals || !feat_hw || n_views < 0 || C <= 0 || n_maps < 0) return VFA_ERR_BAD_ARGUMENT;
     if ((scales == nullptr) != (shifts == nullptr)) return VFA_ERR_BAD_ARGUMENT;
@@ -264,7 +352,7 @@ int vfa_integral_images_hwc_f32(const float *const *features_hwc, const float *c
     if (C % kWave != 0 || n_maps > kMaxMaps) return VFA_ERR_UNSUPPORTED;
     for (int s = 0; s < n_maps; ++s)
         if (!aligned16(integrals[s])) return VFA_ERR_UNSUPPORTED; // (the column pass works on float4)
-    return integral_images_launch(features_hwc, scales, shifts, integrals, n_views, C, n_maps, feat_hw, true, stream);
+    return integral_images_launch(features_hwc, scales, shifts, integrals, absmax, n_views, C, n_maps, feat_hw, true, stream);
 }
 
 } // extern "C"

@@ -28,6 +28,7 @@
 
 #include "vfa_geom.h"
 #include "vfa_pipe_seq.h"
+#include "vfa_split.h"
 
 namespace {
 using namespace vfa_dev;
@@ -211,7 +212,21 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
 // collapse.weight of a scale, in the REFERENCE layout (256, 256 * nl), column = c * nl + layer (vfa_op.py:59, :120), as THREE bf16
 // planes x = p0 + p1 + p2 (+ r, |r| <= 2^-25 |x|; p0 + p1 is the two-piece split) in MFMA B-fragment order, 384 KiB per layer:
 //   out[(((layer * 8 + wave) * 16 + s) * 3 + plane) * 64 + lane] (16 B) = W[n = 32 wave + (lane & 31)][c = 16 s + 8 (lane >> 5) + j], j = 0..7
-struct SplitArgs { const float *w[kMaxScales]; uint4 *out[kMaxScales]; int nl; };
+// F16 (VFA_FLAG_TERMS 2, the default): the two-piece fp16 split of vfa_split.h in planes 0 and 1, scaled by 2^ew with
+// max|W| 2^ew in [2^14, 2^15) (pipe_weight_absmax_kernel: kWmaxParts partial maxima per scale); ew is left in wexp[scale].
+constexpr int kWmaxParts = 32;
+struct SplitArgs { const float *w[kMaxScales]; uint4 *out[kMaxScales]; int nl; unsigned *wmax; int *wexp; int f16; };
+__global__ __launch_bounds__(256) void pipe_weight_absmax_kernel(SplitArgs sa, long long count)
+{
+    __shared__ unsigned part[4];
+    const float *__restrict__ w = sa.w[blockIdx.y];
+    unsigned m = 0u;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += kWmaxParts * 256) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) sa.wmax[blockIdx.y * kWmaxParts + blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
 __global__ __launch_bounds__(256) void pipe_split_weight_kernel(SplitArgs sa)
 {
     const int scale = blockIdx.y / sa.nl, layer = blockIdx.y - scale * sa.nl;
@@ -221,6 +236,24 @@ __global__ __launch_bounds__(256) void pipe_split_weight_kernel(SplitArgs sa)
     if (idx >= 8 * kSteps * 64) return;
     const int lane = idx & 63, s = (idx >> 6) & 15, wave = idx >> 10;
     const float *src = w + (size_t)(wave * 32 + (lane & 31)) * kC * sa.nl + (size_t)(16 * s + 8 * (lane >> 5)) * sa.nl + layer;
+    if (sa.f16) {
+        fp16_saturate_mode(true);
+        unsigned m = 0u;
+        for (int i = 0; i < kWmaxParts; ++i) m = max(m, sa.wmax[scale * kWmaxParts + i]);
+        const int ew = split_exponent(m, kExpW);
+        if (idx == 0 && layer == 0) sa.wexp[scale] = ew;
+        const float sc = pow2f(ew);
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = src[(size_t)j * sa.nl] * sc;
+        uint2 h0, l0, h1, l1;
+        split_f16x4(x[0], x[1], x[2], x[3], h0, l0);
+        split_f16x4(x[4], x[5], x[6], x[7], h1, l1);
+        out[((size_t)(wave * kSteps + s) * kWPlanes + 0) * 64 + lane] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        out[((size_t)(wave * kSteps + s) * kWPlanes + 1) * 64 + lane] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        out[((size_t)(wave * kSteps + s) * kWPlanes + 2) * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     union { __bf16 b[8]; uint4 u; } p0, p1, p2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -310,6 +343,8 @@ struct PipeScale {
     const unsigned *live;           // (n_tiles)
     const unsigned char *hdrs, *recs;
     int Hf, Wf;
+    const unsigned *amax;           // amax_n partial maxima of |feature| (fp32 bits): the scale of the fp16 split (vfa_split.h)
+    int amax_n;
 };
 struct PipeArgs {
     PipeScale sc[kMaxScales];
@@ -322,6 +357,7 @@ struct PipeArgs {
     unsigned long long *diag;       // per workgroup 8 counters (VFA_FLAG_DEBUG)
     int debug;
     int *balance;                   // balance state of the workspace (kBalanceBytes: see kBalTag)
+    const int *wexp;                // (kMaxScales) scale exponent of the split collapse weight (fp16 form)
 };
 
 struct DevMasks {
@@ -369,9 +405,13 @@ __device__ __forceinline__ void lds_wait4(f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : "n"(N));
 }
 // the same for a box pooled straight from the integral image in L2: 32-bit byte offsets from the image address in scalar registers
+// (`s_nop 4`: the image address reaches its scalar registers by v_readfirstlane, and on gfx9 a VMEM instruction that reads an SGPR a
+// VALU instruction has just written needs five wait states in between.  The compiler inserts them for its own instructions but
+// cannot see into an asm statement: scheduled four instructions behind the v_readfirstlane, these loads went out with the OLD low
+// half of the address -- a memory fault that came and went with unrelated edits, in the optimised build only.)
 __device__ __forceinline__ void glob_read4(f32x4 &t0, f32x4 &t1, f32x4 &t2, f32x4 &t3, const char *img, unsigned p0, unsigned p1, unsigned p2, unsigned p3)
 {
-    asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\tglobal_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %8"
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\tglobal_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %8"
                  : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(img) : "memory");
 }
 template <int N>
@@ -440,7 +480,8 @@ template <int TERMS, bool DIAG>
 __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 {
     // separate objects: one per role of the data (hipcc orders LDS-DMA against every LDS access it cannot prove disjoint)
-    constexpr int kPieces = TERMS == 6 ? 3 : 2;                             // bf16 pieces of an operand
+    constexpr int kPieces = TERMS == 6 ? 3 : 2;                             // 16-bit pieces of an operand
+    constexpr bool F16 = TERMS == 2;                                        // ... fp16 pieces with a scale (vfa_split.h) instead of bf16 ones
     constexpr int kWinBytes = (TERMS == 6 ? kWinSlots3 : kWinSlots) * kQSlot;
     __shared__ __align__(16) unsigned char s_win[4 * kWinBytes];            // tap windows: [step parity][sub-tile of the set]
     __shared__ __align__(16) unsigned char s_planes[2 * kPieces * kPlaneBytes]; // A tiles: [step parity][piece]
@@ -451,7 +492,9 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     __shared__ __align__(16) unsigned char s_rec1[2 * kTileBoxes * kRecBytes];
     __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
     __shared__ unsigned s_misc[16];
-    __shared__ __align__(16) unsigned s_sc[kMaxScales][12];                 // per scale: integral, recs, wfrag, hdrs (lo, hi each), Hf, Wf, nl * n_views, -
+    // per scale: integral, recs, wfrag, hdrs (lo, hi each), Hf, Wf | (ea + 64) << 16, nl * n_views, n_views; fp16 form: 2^(ea+ew), 2^-(ea+ew)
+    __shared__ __align__(16) unsigned s_sc[kMaxScales][16];
+    __shared__ unsigned s_amax[kMaxScales];
     // phase records (table wave): [phase & 3]{tile, views, w, -, then the 12 constants of the phase's scale (s_sc)}: whoever builds
     // tables from a phase record finds everything behind ONE LDS round trip (under the pooling waves' read traffic a dependent chain of
     // three -- record, scale constants, headers -- took make_desc 3 500 cycles)
@@ -515,6 +558,17 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     // Per-scale constants in LDS: the kernel arguments live in memory (the scalar registers are full), and a table job that picks
     // one of three pointers by scale became a chain of dependent scalar loads -- make_desc alone took ~4 000 cycles on the wave
     // every other wave waits for.  One vector read of this table instead.
+    if constexpr (F16) { // the largest |feature| of every scale (what the integral-image kernels saw): the scale 2^ea of its voxel features
+        if (tid < kMaxScales) s_amax[tid] = 0u;
+        __syncthreads();
+        for (int s2 = 0; s2 < a.n_scales; ++s2) {
+            unsigned m = 0u;
+            for (int i = tid; i < a.sc[s2].amax_n; i += threads_of(TERMS)) m = max(m, a.sc[s2].amax[i]);
+            m = wave_max_u32(m);
+            if (lane == 0) atomicMax(&s_amax[s2], m);
+        }
+        __syncthreads();
+    }
     if (tid < kMaxScales) {
         const int s3 = tid < a.n_scales ? tid : 0;
         unsigned *d = &s_sc[tid][0];
@@ -523,6 +577,12 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         d[0] = (unsigned)p0; d[1] = (unsigned)(p0 >> 32); d[2] = (unsigned)p1; d[3] = (unsigned)(p1 >> 32);
         d[4] = (unsigned)p2; d[5] = (unsigned)(p2 >> 32); d[6] = (unsigned)p3; d[7] = (unsigned)(p3 >> 32);
         d[8] = (unsigned)a.sc[s3].Hf; d[9] = (unsigned)a.sc[s3].Wf; d[10] = (unsigned)(a.nl * a.n_views); d[11] = (unsigned)a.n_views;
+        d[12] = d[13] = pow2_bits(0);
+        if constexpr (F16) {
+            const int ea = split_exponent(s_amax[s3], kExpA), ew = a.wexp[s3];
+            d[9] |= (unsigned)(ea + 64) << 16; // (Wf <= 65533: vfa_pipe_boxes_f32)
+            d[12] = pow2_bits(ea + ew); d[13] = pow2_bits(-(ea + ew));
+        }
     }
     __syncthreads();
     auto run = [&](auto role_tag) {
@@ -558,8 +618,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 #pragma unroll
             for (int s = 0; s < kMaxScales; ++s) {
                 bc[s] = (s < a.n_scales && a.sc[s].bias) ? a.sc[s].bias[wave * 32 + r] : 0.0f;
+                if constexpr (F16) bc[s] *= __uint_as_float(s_sc[s][12]); // the bias rides in the accumulator: in its units, 2^(ea+ew)
             }
         }
+        // 2^-(ea+ew) of a scale (1 in the bf16 forms): what turns accumulator units back into the map's
+        auto inv_of = [&](int s) { return F16 ? __uint_as_float((unsigned)uniform_i((int)s_sc[s][13])) : 1.0f; };
         // ---------------------------------------------------------------- pooling-wave state: the wave's 16 boxes of each set
         LaneBox boxA, boxB;
         bool globA = false, globB = false, liveA = false, liveB = false;
@@ -586,7 +649,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             float extra = 0.0f; // fully masked (view, scale) of this tile: vox = 0 -> relu(bias)
 #pragma unroll
             for (int s = 0; s < kMaxScales; ++s)
-                if (s < a.n_scales) extra += (float)(a.n_views - __popc(masks(s, tile))) * relu_t(bc[s]);
+                if (s < a.n_scales) extra += (float)(a.n_views - __popc(masks(s, tile))) * (F16 ? relu_t(bc[s]) * inv_of(s) : relu_t(bc[s]));
             int h2 = h, r2 = r;
             asm volatile("" : "+v"(h2), "+v"(r2)); // (keeps the 16 row offsets out of long-lived registers)
             float *ocol = a.out + wave * 32 + r2;
@@ -727,7 +790,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const uint2 hd = *reinterpret_cast<const uint2 *>(&s_hdr[n & 3][jj * 8]);
             const int view = (int)((v.y >> (8 * jj)) & 0xffu);
             const unsigned flags = hd.x, n_slots = hd.y;
-            const int Hf = (int)c2.x, Wf = (int)c2.y;
+            const int Hf = (int)c2.x, Wf = (int)(c2.y & 0xffffu);
+            const unsigned ea64 = c2.y & 0xffff0000u; // (fp16 form: the exponent of the scale's voxel-feature factor, + 64, in the upper half)
             const unsigned long long item = (unsigned long long)((unsigned)tile * c2.z + (unsigned)layer * c2.w + (unsigned)view);
             const unsigned long long img = ((unsigned long long)c0.y << 32 | c0.x) +
                                            (unsigned long long)view * (unsigned)((Hf + 2) * (Wf + 2)) * kSlotBytes + (unsigned)(q * kQSlot);
@@ -738,7 +802,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             if (lane < 16) {
                 uint4 *d = reinterpret_cast<uint4 *>(&s_desc[n & 3][k][x][0]);
                 d[0] = make_uint4((unsigned)img, (unsigned)(img >> 32), (unsigned)rec, (unsigned)(rec >> 32));
-                d[1] = make_uint4(fw, (unsigned)wsl, (unsigned)(wsl >> 32), (unsigned)(Wf + 2));
+                d[1] = make_uint4(fw, (unsigned)wsl, (unsigned)(wsl >> 32), (unsigned)(Wf + 2) | ea64);
             }
         };
         // Tap window (and, at the first quarter of a layer, the box records) of ONE sub-tile of step i: pooling waves 0-3 fetch for
@@ -763,7 +827,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const int cw = (int)h0.z, inv = (int)h0.w, x0 = (int)h1.x, t0 = (int)h1.y, top = (int)h1.z, b0 = (int)h1.w;
             const int n_fill = (n_slots + 3) >> 2;
             const unsigned long long img = ((unsigned long long)d0.y << 32 | d0.x) + (unsigned)((lane & 15) * 16);
-            const int wpad = (int)d1.w; // (Wf + 2 of the scale: see make_desc)
+            const int wpad = (int)(d1.w & 0xffffu); // (Wf + 2 of the scale: see make_desc)
             unsigned char *dst = s_win + ((k & 1) * 2 + x) * kWinBytes;
             for (int f = wq4; f < n_fill; f += 4) { // four quarter slots per instruction, 16 lanes each
                 const int slot = min(4 * f + (lane >> 4), n_slots - 1);
@@ -799,6 +863,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // SET is the parity of the step's index, hence a compile-time fact of the loop body it is called from; the weight is
         // reloaded behind the k-steps of set 1 (the next step starts another slice), never behind those of set 0 -- a reload
         // decided at run time inside the k-loop cost register copies at every merge point.
+        // one 32 x 32 x 16 product on the matrix pipe: fp16 pieces (default) or bf16 pieces -- the registers hold 8 x 16 bits either way
+        auto mfma16 = [](const bf16x8 &av, const bf16x8 &bv, const f32x16 &cv) {
+            if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), cv, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, cv, 0, 0, 0);
+        };
         auto multiply = [&](auto set_tag, const PhaseRec &ph, int k, int par, bool next_chunk) {
             constexpr int SET = decltype(set_tag)::value;
             constexpr bool reload = SET == 1;
@@ -860,19 +929,19 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     // the hi pair of this k-step was requested behind the hi MFMAs of the last one, the lo pair behind its lo MFMAs
                     wait_pair<2>(h0, h1);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
-                    if (BOTH) acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
-                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
-                    if (BOTH) acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                    acc[2 * SET] = mfma16(h0, wq[KS].lo, acc[2 * SET]);
+                    if (BOTH) acc[2 * SET + 1] = mfma16(h1, wq[KS].lo, acc[2 * SET + 1]);
+                    acc[2 * SET] = mfma16(h0, wq[KS].hi, acc[2 * SET]);
+                    if (BOTH) acc[2 * SET + 1] = mfma16(h1, wq[KS].hi, acc[2 * SET + 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (KS < 3) { read_pair<KS + 1, 0>(pa, h0, h1); wait_pair<2>(l0, l1); } // (the MFMAs latched h0, h1 at issue)
                     else wait_pair<0>(l0, l1);
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, wq[KS].hi, acc[2 * SET], 0, 0, 0);
-                    if (BOTH) acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, wq[KS].hi, acc[2 * SET + 1], 0, 0, 0);
+                    acc[2 * SET] = mfma16(l0, wq[KS].hi, acc[2 * SET]);
+                    if (BOTH) acc[2 * SET + 1] = mfma16(l1, wq[KS].hi, acc[2 * SET + 1]);
                     if (TERMS >= 4) {
-                        acc[2 * SET] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l0, wq[KS].lo, acc[2 * SET], 0, 0, 0);
-                        if (BOTH) acc[2 * SET + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l1, wq[KS].lo, acc[2 * SET + 1], 0, 0, 0);
+                        acc[2 * SET] = mfma16(l0, wq[KS].lo, acc[2 * SET]);
+                        if (BOTH) acc[2 * SET + 1] = mfma16(l1, wq[KS].lo, acc[2 * SET + 1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (KS < 3) read_pair<KS + 1, 1>(pa, l0, l1);
@@ -917,6 +986,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         auto group_end = [&](const PhaseRec &ph) {
             float *slot = a.partial + (((size_t)lb * 3 + 2) * 8 + wave) * 16 * 64 + lane;
             const bool three = ph.nj() > 2, four = ph.nj() > 3, more = ph.more(), open = tile_open;
+            const float inv = inv_of(ph.scale());
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float g = acc[0][i];
@@ -924,7 +994,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 g = three ? g + r2 : g;
                 g = four ? g + r3 : g;
                 const float s0 = open ? acc[1][i] : 0.0f;
-                acc[0][i] = s0 + g;
+                if constexpr (F16) acc[0][i] = fmaf(g, inv, s0); // (g 2^-(ea+ew) is exact: the same bits as multiply, then add)
+                else acc[0][i] = s0 + g;
             }
             if (more) {
 #pragma unroll
@@ -951,6 +1022,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const bool vis = (rv[1].y & (unsigned)kVis) != 0u;
             // a masked box reads slot / pixel 0 (finite) and multiplies by its masked value (0, or NaN for a NaN box)
             bx.scl = __uint_as_float(rv[1].x);
+            if constexpr (F16) bx.scl *= pow2f((int)(wp >> 16) - 64); // times 2^ea: a power of two, v * (rcp 2^ea) = (v * rcp) 2^ea exactly
+            wp &= 0xffffu;
             unsigned rw[4] = {rv[1].z & 0xffffu, rv[1].z >> 16, rv[1].w & 0xffffu, rv[1].w >> 16};
             unsigned cl[4] = {rv[2].x & 0xffffu, rv[2].x >> 16, rv[2].y & 0xffffu, rv[2].y >> 16};
             glob = direct;
@@ -1027,12 +1100,16 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 // x = hi + lo + r, |r| <= 2^-17 |x|: hi = RNE bf16(x), lo = RNE bf16(x - hi)
                 // (three-piece variant: lo2 = RNE bf16(x - hi - lo), |x - hi - lo - lo2| <= 2^-25 |x|)
                 union { __bf16 b[4]; uint2 u; } hi, lo, lo2;
+                if constexpr (F16) { // (fp16 form: two fp16 pieces of the scaled value, vfa_split.h)
+                    split_f16x4(xs[0], xs[1], xs[2], xs[3], hi.u, lo.u);
+                } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     hi.b[k] = (__bf16)xs[k];
                     const float r1 = xs[k] - (float)hi.b[k];
                     lo.b[k] = (__bf16)r1;
                     if constexpr (TERMS == 6) lo2.b[k] = (__bf16)(r1 - (float)lo.b[k]);
+                }
                 }
                 // channels 16 piece + 4 pi .. + 3 of the quarter: chunk 2 piece + (pi >> 1), half pi & 1
                 const int off = (int)(2 * piece + (pi >> 1)) * kChunkStride + row * 16 + (pi & 1) * 8;
@@ -1351,6 +1428,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // the pooling wave is the busiest third of its SIMD and its step the longest: it goes first (its step head 150 against 500
         // cycles, pooling 3 800 against 4 000 without the priority)
         if (!(DIAG && (a.debug & 8))) __builtin_amdgcn_s_setprio(1);
+        if constexpr (F16) fp16_saturate_mode(true); // (the pooling waves convert and never multiply; the matrix waves keep the default mode: vfa_split.h)
 #ifndef VFA_PIPE_NO_POOL
         run(std::true_type{});
 #endif
@@ -1433,7 +1511,7 @@ __global__ __launch_bounds__(kMaxBlocks) void pipe_balance_kernel(int *bal, cons
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PipeLayout {
-    size_t live[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, costs, partial, diag, balance, total;
+    size_t live[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, costs, partial, diag, balance, wmax, wexp, amax, total;
     int tiles_l, tiles_w, n_tiles;
 };
 inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
@@ -1465,6 +1543,9 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
     w.partial = off; off = align_up(off + (size_t)kMaxBlocks * 3 * 8 * 16 * 64 * sizeof(float), 256);
     w.diag = off;    off = align_up(off + (size_t)kMaxBlocks * 8 * sizeof(unsigned long long), 256);
     w.balance = off; off = align_up(off + kBalanceBytes, 256); // work-cut bounds per workgroup + the last launch's times (vfa_pipe_balance_f32)
+    w.wmax = off;    off = align_up(off + (size_t)kMaxScales * kWmaxParts * sizeof(unsigned), 256); // fp16 split: partial maxima of |W| per scale,
+    w.wexp = off;    off = align_up(off + kMaxScales * sizeof(int), 256);                            // ... the weight exponents,
+    w.amax = off;    off = align_up(off + (size_t)kMaxScales * kFallbackStats * sizeof(unsigned), 256); // ... feature statistics made here for callers that pass none
     w.total = off;
     return w;
 }
@@ -1530,7 +1611,7 @@ int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_la
                        int flags, void *workspace, size_t workspace_bytes, void *stream)
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK;
-    if ((flags & ~VFA_FLAG_TERMS_MASK) || (terms != 0 && terms != 3 && terms != 4 && terms != 6)) return VFA_ERR_BAD_ARGUMENT;
+    if ((flags & ~VFA_FLAG_TERMS_MASK) || (terms != 0 && terms != 2 && terms != 3 && terms != 4 && terms != 6)) return VFA_ERR_BAD_ARGUMENT;
     if (!dims_ok(n_views, L, W, n_layers, n_scales) || conv_kind < 0 || conv_kind > 2 || !feat_hw) return VFA_ERR_BAD_ARGUMENT;
     if (n_views > 32) return VFA_ERR_UNSUPPORTED; // live-view masks are 32 bits wide
     const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
@@ -1561,9 +1642,11 @@ int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_la
     return (int)hipGetLastError();
 }
 
-int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, const float *const *weights, void *workspace,
+int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, const float *const *weights, int flags, void *workspace,
                       size_t workspace_bytes, void *stream)
 {
+    const int terms = flags & VFA_FLAG_TERMS_MASK;
+    if ((flags & ~VFA_FLAG_TERMS_MASK) || (terms != 0 && terms != 2 && terms != 3 && terms != 4 && terms != 6)) return VFA_ERR_BAD_ARGUMENT;
     if (!dims_ok(n_views, L, W, n_layers, n_scales)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views > 32) return VFA_ERR_UNSUPPORTED;
     const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
@@ -1588,6 +1671,14 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
             sa.w[k] = weights[k < n_scales ? k : 0];
             sa.out[k] = reinterpret_cast<uint4 *>(ws + lay.wfrag[k < n_scales ? k : 0]);
             if (!sa.w[k]) return VFA_ERR_BAD_ARGUMENT;
+        }
+        sa.wmax = reinterpret_cast<unsigned *>(ws + lay.wmax);
+        sa.wexp = reinterpret_cast<int *>(ws + lay.wexp);
+        sa.f16 = (terms == 0 || terms == 2) ? 1 : 0;
+        if (sa.f16) {
+            hipLaunchKernelGGL(pipe_weight_absmax_kernel, dim3(kWmaxParts, n_scales), dim3(256), 0, s, sa, (long long)kC * kC * n_layers);
+            st = (int)hipGetLastError();
+            if (st) return st;
         }
         hipLaunchKernelGGL(pipe_split_weight_kernel, dim3(8 * kSteps * 64 / 256, n_scales * n_layers), dim3(256), 0, s, sa);
         st = (int)hipGetLastError();
@@ -1616,17 +1707,19 @@ int vfa_pipe_records_f32(const float *calibs, const float *grid, const float *z_
     const int st = vfa_pipe_boxes_f32(calibs, grid, z_layers, n_layers, corner_off, n_views, L, W, conv_kind, img_w, img_h, cmin, cmax,
                                       n_scales, feat_hw, flags, workspace, workspace_bytes, stream);
     if (st) return st;
-    return vfa_pipe_cuts_f32(n_views, L, W, n_layers, n_scales, weights, workspace, workspace_bytes, stream);
+    return vfa_pipe_cuts_f32(n_views, L, W, n_layers, n_scales, weights, flags, workspace, workspace_bytes, stream);
 }
 
-int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *const *biases, void *workspace, size_t workspace_bytes,
-                                   float *out, int n_views, int L, int W, int n_layers, int n_scales, const int *feat_hw, int accumulate,
-                                   int flags, void *stream)
+int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned *const *feat_absmax, const float *const *biases,
+                                   void *workspace, size_t workspace_bytes, float *out, int n_views, int L, int W, int n_layers,
+                                   int n_scales, const int *feat_hw, int accumulate, int flags, void *stream)
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xfff;
     if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00)) return VFA_ERR_BAD_ARGUMENT;
-    if (!dims_ok(n_views, L, W, n_layers, n_scales) || !feat_hw || !integrals || (terms != 0 && terms != 3 && terms != 4 && terms != 6))
+    if (!dims_ok(n_views, L, W, n_layers, n_scales) || !feat_hw || !integrals ||
+        (terms != 0 && terms != 2 && terms != 3 && terms != 4 && terms != 6))
         return VFA_ERR_BAD_ARGUMENT;
+    const bool f16 = terms == 0 || terms == 2;
     if (n_views > 32) return VFA_ERR_UNSUPPORTED;
     const PipeLayout lay = layout_of(n_views, L, W, n_layers, n_scales);
     if (lay.n_tiles == 0) return 0;
@@ -1649,7 +1742,24 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *c
         a.sc[k].Hf = feat_hw[2 * q];
         a.sc[k].Wf = feat_hw[2 * q + 1];
         if (!a.sc[k].integral) return VFA_ERR_BAD_ARGUMENT;
+        a.sc[k].amax = nullptr; a.sc[k].amax_n = 0;
     }
+    if (f16) {
+        // the scale of the fp16 split: what the integral-image call left (feat_absmax), or one pass over the integral images here
+        for (int k = 0; k < n_scales; ++k) {
+            if (feat_absmax && feat_absmax[k]) {
+                a.sc[k].amax = feat_absmax[k];
+                a.sc[k].amax_n = (int)feature_stats_count(n_views, kC, a.sc[k].Hf);
+            } else {
+                unsigned *dst = reinterpret_cast<unsigned *>(ws + lay.amax) + (size_t)k * kFallbackStats;
+                const int st = integral_absmax_folded(a.sc[k].integral, dst, n_views, kC, a.sc[k].Hf, a.sc[k].Wf, kFallbackStats, &a.sc[k].amax_n, stream);
+                if (st) return st;
+                a.sc[k].amax = dst;
+            }
+        }
+        for (int k = n_scales; k < kMaxScales; ++k) { a.sc[k].amax = a.sc[0].amax; a.sc[k].amax_n = a.sc[0].amax_n; }
+    }
+    a.wexp = reinterpret_cast<const int *>(ws + lay.wexp);
     a.n_scales = n_scales; a.n_views = n_views; a.nl = n_layers; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles;
     a.out = out; a.accumulate = accumulate;
     a.chunk_start = reinterpret_cast<const int *>(ws + lay.chunks);
@@ -1663,14 +1773,16 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const float *c
     // every call takes its own tickets: a second pass over the same workspace (accumulate) must not see the first one's
     const hipError_t e = hipMemsetAsync(a.tickets, 0, (size_t)lay.n_tiles * 4, s);
     if (e != hipSuccess) return (int)e;
-    if (debug)
-        hipLaunchKernelGGL((pipe_kernel<3, true>), dim3(nblk), dim3(threads_of(3)), 0, s, a);
+    if (debug) // (diagnostic build of the default arithmetic)
+        hipLaunchKernelGGL((pipe_kernel<2, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     else if (terms == 4)
         hipLaunchKernelGGL((pipe_kernel<4, false>), dim3(nblk), dim3(threads_of(4)), 0, s, a);
     else if (terms == 6)
         hipLaunchKernelGGL((pipe_kernel<6, false>), dim3(nblk), dim3(threads_of(6)), 0, s, a);
-    else
+    else if (terms == 3)
         hipLaunchKernelGGL((pipe_kernel<3, false>), dim3(nblk), dim3(threads_of(3)), 0, s, a);
+    else
+        hipLaunchKernelGGL((pipe_kernel<2, false>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,94 @@
+// vfa_split.h -- the reference-width `collapse` product of the fused kernels (reference vfa/model/vfa_op.py:59, :123: an fp32
+// nn.Linear) on the 16-bit matrix pipe: both operands are scaled by a power of two and split EXACTLY into two fp16 pieces,
+//
+//     x * 2^e = hi + lo + r,   hi = RN_f16(x 2^e),  lo = RN_f16(x 2^e - hi),   |r| <= 2^-23 |x 2^e|  (or 2^-25: the fp16 subnormal step)
+//
+// and a product is the three MFMA products  hi.hi + hi.lo + lo.hi  (v_mfma_f32_32x32x16_f16, fp32 accumulation; the dropped lo.lo
+// is <= 2^-22 of the product).  Two 11-bit mantissas cover 22 of fp32's 24 bits: against float64 the result has the error of an
+// sgemm (2e-7 normwise at K = 256; tests/test_split_arithmetic.py), at HALF the matrix work of the three-piece bf16 form (six
+// products) and the SAME work as the two-piece bf16 form (16 bits, 4e-6) it replaces as the default.
+//
+// fp16 has five exponent bits, so the pieces need a scale.  One power of two per operand and feature scale:
+//   A (voxel features):  2^ea with  absmax(feature map) 2^ea in [2^14, 2^15).  A box mean is (up to the rounding noise of the
+//                        integral image) at most absmax / 4 -- the box area of vfa_op.py:104 is four times the pixel area --, so
+//                        voxel features sit below 2^13 with a factor 8 of headroom up to fp16's 65504; the absolute error of a
+//                        piece is at most 2^-25 (half a subnormal step), i.e. 2^-38 of the largest voxel feature: rows down to
+//                        2^-14 of the largest keep the full 22 bits.  absmax comes from the integral-image kernels, which see
+//                        every feature value (vfa_integral.hip), or from a pass over the integral images when the caller has none
+//                        (integral_absmax_kernel).
+//   W (collapse.weight): 2^ew with  absmax(W) 2^ew in [2^14, 2^15).
+// The accumulator starts at bias 2^(ea+ew) and the epilogue multiplies relu(acc) by 2^-(ea+ew): powers of two, exact.
+// A value beyond fp16's range (a noise-dominated box of ~1e-6 pixels) must not turn a finite reference value into Inf - Inf:
+// the CONVERSIONS run under MODE.FP16_OVFL, where a result that overflows is +-65504 instead of infinity (true infinities and
+// NaNs stay what they are: measured, tools/micro/fp16_modes.hip).  The MFMAs must NOT: under that mode v_mfma_f32_32x32x16_f16
+// reads a NaN operand as a number and an infinite one as FLT_MAX (same tool) -- a NaN box (vfa_op.py:118-119: NaN * 0 stays NaN)
+// or a NaN feature would vanish from the map.  The mode is per wave: the pooling waves of vfa_pipe.hip set it for good, the
+// serial kernel of vfa_fused.hip switches it on around its pooling phase.
+#ifndef VFA_SPLIT_H
+#define VFA_SPLIT_H
+#include <hip/hip_runtime.h>
+
+namespace vfa_dev {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int kExpA = 14, kExpW = 14, kExpLim = 40;
+
+// power-of-two scale exponent that brings a maximum with the fp32 bit pattern `absmax_bits` (sign cleared) into
+// [2^target, 2^(target+1)); 0 for an all-zero or non-finite operand
+__host__ __device__ __forceinline__ int split_exponent(unsigned absmax_bits, int target)
+{
+    if (absmax_bits == 0u || absmax_bits >= 0x7f800000u) return 0;
+    const int e = (int)(absmax_bits >> 23) - 127; // (a subnormal maximum reads -127: the clamp below takes it)
+    int s = target - e;
+    s = s > kExpLim ? kExpLim : s;
+    s = s < -kExpLim ? -kExpLim : s;
+    return s;
+}
+__host__ __device__ __forceinline__ unsigned pow2_bits(int e) { return (unsigned)(127 + e) << 23; }
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float(pow2_bits(e)); }
+
+// MODE.FP16_OVFL: fp16 results that overflow are clamped to +-MAX_FP16 instead of becoming infinities.  The empty asm statements keep
+// the loads in front of the conversions and the stores behind them on their side of the switch (the conversions themselves read
+// MODE: the backend orders them against s_setreg).
+__device__ __forceinline__ void fp16_saturate_mode(bool on)
+{
+    asm volatile("" ::: "memory");
+    if (on) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+    else __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 0);
+    asm volatile("" ::: "memory");
+}
+
+// four fp32 values (already scaled) -> hi / lo fp16 quads: 2 x v_cvt_pk_f16_f32, 4 x v_cvt_f32_f16, 4 x v_sub_f32, 2 x v_cvt_pk_f16_f32
+__device__ __forceinline__ void split_f16x4(float x0, float x1, float x2, float x3, uint2 &hi, uint2 &lo)
+{
+    const f32x4v x = {x0, x1, x2, x3};
+    const f16x4 h = __builtin_convertvector(x, f16x4);
+    const f32x4v r = x - __builtin_convertvector(h, f32x4v);
+    const f16x4 l = __builtin_convertvector(r, f16x4);
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+// wave-wide maximum of an unsigned value (all lanes get it)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, m, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// host side, defined in vfa_integral.hip: the statistic of one scale from a finished integral image, folded into at most
+// `max_entries` entries (the frame entry points call it for callers that pass no statistics)
+constexpr int kFallbackStats = 1024;
+size_t feature_stats_count(int n_views, int C, int Hf);
+int integral_absmax_folded(const float *integral, unsigned *absmax, int n_views, int C, int Hf, int Wf, int max_entries, int *n_entries,
+                           void *stream);
+
+} // namespace vfa_dev
+#endif // VFA_SPLIT_H

@@ -95,26 +95,64 @@ def affine_relu_integral_image(x, scale, shift):
     return integral
 
 
+class IntegralImages(list):
+    """The integral images of a frame (a plain list of tensors, one per stride) + ``absmax``: per stride the partial maxima of
+    |feature| the row scan saw (uint32 bit patterns) -- what the fused frame kernels scale their fp16 operand split by
+    (``pool_collapse`` / ``pipe_collapse`` pick it up from here; a plain list works too and costs one extra pass per stride)."""
+    absmax = None
+
+
+def feature_stats_count(n_views, C, Hf):
+    return int(_lib.lib().vfa_feature_stats_count(int(n_views), int(C), int(Hf)))
+
+
+def integral_absmax(integral):
+    """Partial maxima of |feature| from a finished integral image (``vfa_integral_absmax_f32``): (n,Hf+2,Wf+2,C) -> int32 tensor."""
+    _lib.require_device(integral)
+    n, Hp, Wp, C = integral.shape
+    out = torch.empty(max(feature_stats_count(n, C, Hp - 2), 1), dtype=torch.int32, device=integral.device)
+    _launch("vfa_integral_absmax_f32", _lib.ptr(integral), _lib.ptr(out), n, C, Hp - 2, Wp - 2, _lib.current_stream_handle())
+    return out
+
+
+def _absmax_of(integrals, absmax):
+    """The statistics that belong to these integral images: given explicitly, or carried by an ``IntegralImages`` list."""
+    if absmax is None:
+        absmax = getattr(integrals, "absmax", None)
+    if absmax is None:
+        return None, None
+    absmax = list(absmax)
+    assert len(absmax) == len(integrals)
+    for i, t in zip(integrals, absmax):
+        assert t is None or (t.dtype == torch.int32 and t.is_contiguous()
+                             and t.numel() >= feature_stats_count(i.shape[0], i.shape[3], i.shape[1] - 2))
+    return absmax, _lib.ptr_array(absmax)
+
+
 def integral_images(features, scales=None, shifts=None, channels_last=False):
     """The integral images of every feature map of a frame in one launch pair (``vfa_integral_images_f32``): features = one
     (n,C,H_s,W_s) batch per stride -> one (n,H_s+2,W_s+2,C) image per stride, bit-identical to ``integral_image`` of each.
     ``scales`` / ``shifts`` (one (n,C) tensor per map): the fused GroupNorm affine + ReLU of ``affine_relu_integral_image``.
-    ``channels_last``: the inputs are (n,H_s,W_s,C) (``lateral_conv``'s output; ``vfa_integral_images_hwc_f32``)."""
+    ``channels_last``: the inputs are (n,H_s,W_s,C) (``lateral_conv``'s output; ``vfa_integral_images_hwc_f32``).
+    Returns an ``IntegralImages`` list (the images + the feature statistics of the fp16 operand split)."""
     features = [_f32c(f) for f in features]
     _lib.require_device(*features)
     n = features[0].shape[0]
     C = features[0].shape[3 if channels_last else 1]
     sizes = [tuple(f.shape[1:3]) if channels_last else tuple(f.shape[2:]) for f in features]
     assert all(f.shape[0] == n and f.shape[3 if channels_last else 1] == C for f in features)
-    outs = [torch.empty((n, h + 2, w + 2, C), dtype=torch.float32, device=f.device) for f, (h, w) in zip(features, sizes)]
+    outs = IntegralImages(torch.empty((n, h + 2, w + 2, C), dtype=torch.float32, device=f.device) for f, (h, w) in zip(features, sizes))
+    counts = [max(feature_stats_count(n, C, h), 1) for h, _ in sizes]
+    stats = torch.empty(sum(counts), dtype=torch.int32, device=features[0].device)  # (every entry is written: no initialisation)
+    outs.absmax = list(torch.split(stats, counts))
     affine = scales is not None
     if affine:
         scales, shifts = [_f32c(t) for t in scales], [_f32c(t) for t in shifts]
         assert all(tuple(t.shape) == (n, C) for t in scales + shifts)
     hw = _lib.int_array([v for hw_ in sizes for v in hw_])
     _launch("vfa_integral_images_hwc_f32" if channels_last else "vfa_integral_images_f32", _lib.ptr_array(features),
-            _lib.ptr_array(scales) if affine else None, _lib.ptr_array(shifts) if affine else None, _lib.ptr_array(outs), n, C,
-            len(features), hw, _lib.current_stream_handle(), tag=(n, C, tuple(sizes), affine))
+            _lib.ptr_array(scales) if affine else None, _lib.ptr_array(shifts) if affine else None, _lib.ptr_array(outs),
+            _lib.ptr_array(outs.absmax), n, C, len(features), hw, _lib.current_stream_handle(), tag=(n, C, tuple(sizes), affine))
     return outs
 
 
@@ -410,7 +448,7 @@ def collapse_gemm_relu_backward(vox, weight, bias, grad_out, terms=0, reserved_c
 
 
 def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_hws, weights=None, crange=(-1, 0.95),
-                  workspace=None, row_slots=None, cuts=True):
+                  workspace=None, row_slots=None, cuts=True, terms=0):
     """Geometry of one frame for the fused inference kernel (``pool_collapse``): box records of every (view, cell) for each
     feature scale + the split collapse weights -> workspace tensor (reference vfa_op.py:64-106, set-up of :112-115).
 
@@ -446,12 +484,12 @@ def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_
                 _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(), tag=(n, L, W, ns))
         return workspace
     _launch("vfa_frame_records_f32", _lib.ptr(calibs), _lib.ptr(grid), _lib.ptr(z_layers), _lib.ptr(corner_off), n, L, W,
-            int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), ns, hw, wts,
+            int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), ns, hw, wts, int(terms) & 0xf,
             _lib.ptr(workspace), workspace.numel(), _lib.current_stream_handle(), tag=(n, L, W, ns))
     return workspace
 
 
-def frame_cuts(workspace, n_views, grid_lw, n_scales, weights=None):
+def frame_cuts(workspace, n_views, grid_lw, n_scales, weights=None, terms=0):
     """Second half of ``frame_records(..., cuts=False)``: the work cuts of the persistent kernel + the split collapse weights."""
     _lib.require_device(workspace)
     wts = None
@@ -460,12 +498,13 @@ def frame_cuts(workspace, n_views, grid_lw, n_scales, weights=None):
         assert len(weights) == n_scales and all(tuple(w.shape) == (256, 256) for w in weights)
         _lib.require_device(*weights)
         wts = _lib.ptr_array(weights)
-    _launch("vfa_frame_cuts_f32", int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_scales), wts, _lib.ptr(workspace),
+    _launch("vfa_frame_cuts_f32", int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_scales), wts, int(terms) & 0xf, _lib.ptr(workspace),
             workspace.numel(), _lib.current_stream_handle(), tag=(int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_scales)))
     return workspace
 
 
-def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0, stage="all"):
+def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0, stage="all",
+                  absmax=None):
     """out (L*W, 256) (+)= sum_scale sum_view relu(vox . W^T + b): pooling + collapse + ReLU + view / scale sum in one
     persistent kernel, the voxel features never touch HBM (reference vfa_op.py:112-125, vfanet.py:79, 82).
 
@@ -486,7 +525,8 @@ def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=Fa
         "out must be a contiguous fp32 (L*W, 256) tensor"
     biases = [None if b is None else _f32c(b) for b in (biases if biases is not None else [None] * ns)]
     hw = _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)])
-    _launch("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array(biases), _lib.ptr(workspace),
+    absmax, absmax_ptrs = _absmax_of(integrals, absmax)
+    _launch("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), absmax_ptrs, _lib.ptr_array(biases), _lib.ptr(workspace),
             workspace.numel(), _lib.ptr(out) if out is not None else None, n, L, W, ns, hw, 1 if accumulate else 0,
             _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16) | stage_flag,  # debug: diagnostic build, tools/ only
             _lib.current_stream_handle(), tag=(n, L, W, tuple((i.shape[1] - 2, i.shape[2] - 2) for i in integrals), stage))
@@ -567,7 +607,7 @@ def pipe_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_h
     return workspace
 
 
-def pipe_cuts(workspace, n_views, grid_lw, n_layers, n_scales, weights=None):
+def pipe_cuts(workspace, n_views, grid_lw, n_layers, n_scales, weights=None, terms=0):
     """Second half of ``pipe_records(..., cuts=False)``: the work cuts of the persistent kernel + the split collapse weights."""
     _lib.require_device(workspace)
     wts = None
@@ -576,12 +616,13 @@ def pipe_cuts(workspace, n_views, grid_lw, n_layers, n_scales, weights=None):
         assert len(weights) == n_scales and all(tuple(w.shape) == (256, 256 * n_layers) for w in weights)
         _lib.require_device(*weights)
         wts = _lib.ptr_array(weights)
-    _launch("vfa_pipe_cuts_f32", int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_layers), int(n_scales), wts, _lib.ptr(workspace),
+    _launch("vfa_pipe_cuts_f32", int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_layers), int(n_scales), wts, int(terms) & 0xf, _lib.ptr(workspace),
             workspace.numel(), _lib.current_stream_handle(), tag=(int(n_views), int(grid_lw[0]), int(grid_lw[1]), int(n_layers), int(n_scales)))
     return workspace
 
 
-def pipe_collapse(integrals, biases, workspace, grid_lw, n_layers, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0):
+def pipe_collapse(integrals, biases, workspace, grid_lw, n_layers, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0,
+                  absmax=None):
     """out (L*W, 256) (+)= sum_scale sum_view relu(vox . W^T + b) for K = n_layers * 256: pooling, collapse, ReLU, view and scale
     sums in one persistent kernel (pooling waves and matrix waves side by side); the voxel features never touch HBM
     (reference vfa_op.py:110-125, vfanet.py:79, 82).  workspace = ``pipe_records`` of the same frame."""
@@ -596,7 +637,8 @@ def pipe_collapse(integrals, biases, workspace, grid_lw, n_layers, out=None, acc
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (L * W, 256)
     biases = [None if b is None else _f32c(b) for b in (biases if biases is not None else [None] * ns)]
     hw = _lib.int_array([v for i in integrals for v in (i.shape[1] - 2, i.shape[2] - 2)])
-    _launch("vfa_pipe_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), _lib.ptr_array(biases), _lib.ptr(workspace),
+    absmax, absmax_ptrs = _absmax_of(integrals, absmax)
+    _launch("vfa_pipe_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), absmax_ptrs, _lib.ptr_array(biases), _lib.ptr(workspace),
             workspace.numel(), _lib.ptr(out), n, L, W, int(n_layers), ns, hw, 1 if accumulate else 0,
             _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16), _lib.current_stream_handle(),
             tag=(n, L, W, int(n_layers), tuple((i.shape[1] - 2, i.shape[2] - 2) for i in integrals)))

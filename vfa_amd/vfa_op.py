@@ -40,7 +40,12 @@ USE_FUSED = os.environ.get("VFA_AMD_FUSED", "0") == "1"
 # on multi-layer grids and in training (K = nl*C a multiple of 128, N = 256) the product alone runs as the K-looped MFMA
 # tile GEMM `vfa_collapse_gemm_f32` in front of the epilogue kernels; "library" = fp32 library GEMM everywhere.
 COLLAPSE_KERNEL = os.environ.get("VFA_AMD_COLLAPSE", "mfma_bf16")
-COLLAPSE_TERMS = int(os.environ.get("VFA_AMD_COLLAPSE_TERMS", "3"))
+# Arithmetic of the product in the fused frame kernels (VFA_FLAG_TERMS): 2 (default) = two fp16 pieces per operand with a
+# power-of-two scale, three MFMA products -- the error of an fp32 sgemm, i.e. the arithmetic width of the reference's nn.Linear
+# (vfa_op.py:59, :123); 3 / 4 = two bf16 pieces (16 bits, ~4e-6 normwise), 6 = three bf16 pieces (pipelined kernel only).  The unfused
+# product kernels (`vfa_collapse_gemm_f32`, `vfa_collapse_relu_sum_f32`: the training backward's mask, VFA_AMD_PIPE=0 paths) have the
+# bf16 forms only and read 2 / 6 as 3.
+COLLAPSE_TERMS = int(os.environ.get("VFA_AMD_COLLAPSE_TERMS", "2"))
 # Inference on single-layer grids with C = 256: "1" (default) = geometry once per frame (`vfa_frame_records_f32`) + ONE
 # persistent kernel for pooling, collapse, bias, ReLU and the view / scale sums (`vfa_pool_collapse_relu_sum_f32`): the voxel
 # features never reach HBM.  "0" = pooling kernel -> vox in HBM -> MFMA collapse kernel, per scale (the round-1 path).
@@ -125,6 +130,17 @@ def _side_stream(dev):
     return _side_streams[key]
 
 
+def _fused_terms():
+    """``COLLAPSE_TERMS`` as the serial fused kernel takes it (it has no three-piece form: 6 runs as the fp16 default)."""
+    return 2 if COLLAPSE_TERMS in (0, 2, 6) else COLLAPSE_TERMS
+
+
+def _unfused_terms(terms=None):
+    """... and as the unfused bf16 product kernels take it (2 and 6 run as 3)."""
+    terms = COLLAPSE_TERMS if terms is None else terms
+    return 3 if terms in (0, 2, 6) else terms
+
+
 def fused_frame_ok(mods, n_views, mode="fused"):
     """The per-frame-records inference paths (``mode`` "fused": one persistent kernel for everything behind the integral
     images; "window": LDS-window pooling kernel + MFMA collapse kernel per scale) cover these projector modules (one per
@@ -164,7 +180,7 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
         feat_hws = [tuple(f.shape[-2:]) for f in features]
         if side is cur:
             ops.frame_records(calibs, grid, z_layers, corner_off, conv_kind, (img_w, img_h), feat_hws, weights=weights,
-                              crange=crange, workspace=ws)
+                              crange=crange, workspace=ws, terms=_fused_terms())
             boxes_done = None
         else:
             # two joins: the pre-pass over the direct items needs the boxes only; the work cuts (a single-workgroup kernel that
@@ -174,17 +190,17 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
                                   workspace=ws, cuts=False)
                 boxes_done = torch.cuda.Event()
                 boxes_done.record(side)
-                ops.frame_cuts(ws, calibs.shape[0], (length, width), len(mods), weights=weights)
+                ops.frame_cuts(ws, calibs.shape[0], (length, width), len(mods), weights=weights, terms=_fused_terms())
         if integrals is None:
             integrals = ops.integral_images(features)  # all strides in one launch pair
         biases = [m.collapse.bias for m in mods]
         if boxes_done is None:
-            return ops.pool_collapse(integrals, biases, ws, (length, width), out=out, accumulate=accumulate, terms=COLLAPSE_TERMS,
+            return ops.pool_collapse(integrals, biases, ws, (length, width), out=out, accumulate=accumulate, terms=_fused_terms(),
                                      reserved_cus=reserved_cus)
         cur.wait_event(boxes_done)
-        ops.pool_collapse(integrals, biases, ws, (length, width), terms=COLLAPSE_TERMS, reserved_cus=reserved_cus, stage="rows")
+        ops.pool_collapse(integrals, biases, ws, (length, width), terms=_fused_terms(), reserved_cus=reserved_cus, stage="rows")
         cur.wait_stream(side)
-        return ops.pool_collapse(integrals, biases, ws, (length, width), out=out, accumulate=accumulate, terms=COLLAPSE_TERMS,
+        return ops.pool_collapse(integrals, biases, ws, (length, width), out=out, accumulate=accumulate, terms=_fused_terms(),
                                  reserved_cus=reserved_cus, stage="main")
 
 
