@@ -206,6 +206,227 @@ __global__ __launch_bounds__(256) void cols_batched_kernel(MapArgs a, unsigned l
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// ONE pass: both cumsums of a (map, view, 16-channel block) inside one 512-thread workgroup, the map read once and the integral
+// image written once (the two-pass form above moves every byte twice: 544 MB per bench frame against 272 MB).
+//
+// Both scans keep ATen's order -- a double accumulator running left to right along every row, rounded to fp32 at every element,
+// then a double accumulator running top to bottom over those fp32 values --, so the only freedom is WHICH chains run side by side:
+//   phase R  thread (row r of 32, channel c of 16) runs the row scan of its (row, channel) over a strip of 32 columns -- 512
+//            independent chains -- and leaves the rounded fp32 values in LDS;
+//   phase C  thread (column x of 32, channel c of 16) picks its column of that tile up: the column accumulator (a double per
+//            (column, channel), kept in LDS between the row batches) takes the 32 rows in order, each sum is rounded in place;
+//   phase S  the finished tile goes to the channels-last image 16 bytes per lane (4 lanes = the 64 contiguous bytes of a
+//            pixel's channel block).
+// The loads of the next strip are issued (into registers) in front of phase R of this one and land under the phases; rows are
+// taken 32 at a time (a batch), the row carry of a thread lives in its registers across the strips of a batch.  Bit-identical to
+// the two-pass kernels by construction (the same operations in the same order per chain), checked by the same tests.
+// Statistics (absmax): the workgroup of channel block cb leaves its maximum in entry (view, row cb & 3, block cb >> 2) of the
+// two-pass layout and zeroes the entries of rows cb & 3 + 4 k: the consumers take the maximum over all entries of a map.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int kOpRows = 32, kOpCols = 32, kOpCh = 16, kOpThreads = kOpRows * kOpCh;
+constexpr int kOpRowPitch = kOpCols * kOpCh + 16; // floats per tile row: the padding puts rows r and r + 1 into different halves of the banks
+struct OnePassArgs {
+    MapDesc m[kMaxMaps];
+    unsigned unit_end[kMaxMaps]; // cumulative units (view, channel block, column part) per map
+    int split[kMaxMaps];         // 0: one unit per (view, channel block); s > 0: two -- part 0 takes the strips [0, s), part 1 the rest
+    int n_maps, n_views, C;
+};
+// A workgroup barrier that orders LDS accesses only: `__syncthreads()` also drains the vector-memory queue (vmcnt(0)) -- here the
+// loads of the next strip and the stores of the last one, a full memory round trip at every one of the four barriers of a strip.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <bool AFFINE>
+__global__ __launch_bounds__(kOpThreads) void integral_onepass_kernel(OnePassArgs a)
+{
+    extern __shared__ __align__(16) unsigned char op_lds[];
+    float *tile = reinterpret_cast<float *>(op_lds);                                  // [32 rows][kOpRowPitch]
+    double *colacc = reinterpret_cast<double *>(op_lds + kOpRows * kOpRowPitch * 4);  // [W][16]
+    const int tid = threadIdx.x;
+    unsigned u = blockIdx.x;
+    int mi = 0;
+    while (mi + 1 < a.n_maps && u >= a.unit_end[mi]) ++mi;
+    if (mi > 0) u -= a.unit_end[mi - 1];
+    const MapDesc &m = a.m[mi];
+    const int H = m.H, W = m.W, C = a.C, cblocks = C / kOpCh;
+    // A wide map is cut into TWO units by columns (the element costs four f32 <-> f64 conversions and two fp64 adds, ~80 cycles of
+    // a wave: one workgroup per (view, channel block) keeps 112 CUs busy for 80 us on the stride-8 maps of the bench frame while the
+    // rest of the chip idles).  The row scan of the right part needs the row sums of the left one: it runs the bare accumulation --
+    // conversion + add, no rounding, no LDS, a third of the work -- over the left part's strips first (those reads hit L2: the left
+    // unit streams the same lines).  No workgroup waits for another.
+    const int split = a.split[mi], part = split ? (int)(u & 1u) : 0;
+    if (split) u >>= 1;
+    const int v = (int)(u / (unsigned)cblocks), cb = (int)(u % (unsigned)cblocks), c0 = cb * kOpCh;
+    const int r = tid >> 4, c = tid & 15;     // phase R: row of the batch, channel; phase C: column of the strip (r), channel
+    const size_t plane = (size_t)H * W;
+    float *out_v = m.out + (size_t)v * (H + 2) * (W + 2) * C + c0; // padded pixel (0, 0) of the view, first channel of the block
+    const int n_strips = (W + kOpCols - 1) / kOpCols;
+    const int s_first = part ? split : 0, s_last = (split && !part) ? split : n_strips; // this unit's strips [s_first, s_last)
+    const int xa = s_first * kOpCols, xb = min(W, s_last * kOpCols);                     // ... = its columns [xa, xb)
+    {   // zero border: rows 0 and H + 1 over the unit's padded columns, column 0 / W + 1 of the rows in between
+        float *o = out_v + c;
+        const int pa = part ? xa + 1 : 0, pb = (split && !part) ? xb + 1 : W + 2;
+        for (int x = pa + r; x < pb; x += kOpRows) { o[(size_t)x * C] = 0.0f; o[((size_t)(H + 1) * (W + 2) + x) * C] = 0.0f; }
+        for (int y = r; y < H; y += kOpRows) {
+            if (!part) o[(size_t)(y + 1) * (W + 2) * C] = 0.0f;
+            if (!split || part) o[((size_t)(y + 1) * (W + 2) + W + 1) * C] = 0.0f;
+        }
+    }
+    for (int i = tid; i < (xb - xa) * kOpCh; i += kOpThreads) colacc[i] = 0.0;
+    float sa = 1.0f, sb = 0.0f;
+    if (AFFINE) { sa = m.scale[(size_t)v * C + c0 + c]; sb = m.shift[(size_t)v * C + c0 + c]; }
+    auto act = [&](float x) {
+        if (!AFFINE) return x;
+        float t = x * sa;
+        t = t + sb;
+        return (t < 0.0f) ? 0.0f : t; // NaN stays NaN
+    };
+    unsigned amax = 0u;
+    // Every global access of the loop is 16 bytes per lane (a 4-byte-per-lane store instruction moves 256 bytes and costs the
+    // issuing wave as much as a 1 KiB one: with them phase C alone took 70 us for the stride-8 map).
+    // The raw strip of a batch in registers: 8 x float4 along x.  Rows and columns beyond the map read clamped and are never used.
+    // (Row-contiguous NCHW maps only: on the channels-last output of vfa_lateral_conv_f32 this kernel measured 154 us per bench
+    // frame against 97 us for rows_hwc_kernel + cols_batched_kernel -- there every access of the two-pass kernels is a full
+    // 256-byte piece already -- so vfa_integral_images_hwc_f32 keeps the two passes.)
+    auto load_strip = [&](float4 (&buf)[kOpCols / 4], int y0, int x0) {
+        {
+            // eight lanes = the 128 bytes of one (row, channel) of the strip, eight such lines per wave instruction: with a whole
+            // line per LANE (64 lines per instruction, each touched by eight instructions) the address path of the CU, not its
+            // arithmetic, set the pace of the kernel
+            const int x4 = tid & 7;
+#pragma unroll
+            for (int j = 0; j < kOpCols / 4; ++j) {
+                const int line = (tid >> 3) + 64 * j, row = line >> 4, ch = line & 15;
+                buf[j] = *reinterpret_cast<const float4 *>(m.feat + ((size_t)v * C + c0 + ch) * plane + (size_t)min(y0 + row, H - 1) * W +
+                                                           min(x0 + 4 * x4, W - 4)); // (W is a multiple of 4 on this path)
+            }
+        }
+    };
+    // Order inside a strip: phase R consumes the raw strip, THEN the next strip is requested into the same registers (it lands under
+    // phases C and S), then C, then S.  The wait for a strip at the head of phase R is written by hand: vmcnt counts in order, behind
+    // the strip's eight loads sit exactly the eight stores of the last phase S (unconditional: rows and columns beyond the tile
+    // repeat the last valid ones), so `vmcnt(8)` leaves those stores draining under this strip.  Left to itself the compiler
+    // waited for nearly everything in flight in front of every element of phase R: a memory round trip per strip.
+    float4 cur[kOpCols / 4];
+    load_strip(cur, 0, 0);
+    __syncthreads(); // colacc is cleared
+    bool stores_behind = false; // the last thing this thread issued were the eight stores of a phase S (behind the loads of `cur`)
+    for (int y0 = 0; y0 < H; y0 += kOpRows) {
+        const int rows = min(kOpRows, H - y0);
+        double racc = 0.0;
+        for (int s = 0; s < s_last; ++s) {
+            const int x0 = s * kOpCols, nx = min(kOpCols, W - x0);
+            const bool carry_only = s < s_first; // (the right part, over the left part's strips: the row sums only)
+            const bool last_strip = s + 1 == s_last;
+            const bool more = !last_strip || y0 + kOpRows < H;
+            if (stores_behind) __builtin_amdgcn_s_waitcnt(0x0f78); // vmcnt(8)
+            else __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0)
+            float *trow = tile + r * kOpRowPitch + c;
+            {
+                // row-contiguous map: the strip as it was loaded -- thread (line, x quad) -- goes through LDS (512 lines of 33 floats:
+                // conflict-free both ways, the size of the tile) and comes back as this thread's own line (r, c) = line tid
+                float *raw = tile;
+#pragma unroll
+                for (int j = 0; j < kOpCols / 4; ++j) {
+                    float *p = raw + ((tid >> 3) + 64 * j) * 33 + 4 * (tid & 7);
+                    p[0] = cur[j].x; p[1] = cur[j].y; p[2] = cur[j].z; p[3] = cur[j].w;
+                }
+                lds_barrier();
+#pragma unroll
+                for (int j = 0; j < kOpCols / 4; ++j)
+                    cur[j] = make_float4(raw[tid * 33 + 4 * j], raw[tid * 33 + 4 * j + 1], raw[tid * 33 + 4 * j + 2], raw[tid * 33 + 4 * j + 3]);
+                lds_barrier();
+            }
+            auto raw_of = [&](int k) {
+                const float4 q = cur[k / 4];
+                return (k & 3) == 0 ? q.x : (k & 3) == 1 ? q.y : (k & 3) == 2 ? q.z : q.w;
+            };
+            if (carry_only) {
+                if (r < rows) {
+#pragma unroll
+                    for (int k = 0; k < kOpCols; ++k) racc += (double)act(raw_of(k)); // (a left strip is always full)
+                }
+                if (more) load_strip(cur, last_strip ? y0 + kOpRows : y0, last_strip ? 0 : x0 + kOpCols);
+                stores_behind = false;
+                continue;
+            }
+            // ---- phase R: row scan of (row r, channel c) over the strip, in place (full strips: no per-element branch)
+            if (r < rows) {
+                if (nx == kOpCols) {
+#pragma unroll
+                    for (int k = 0; k < kOpCols; ++k) {
+                        const float f = act(raw_of(k));
+                        amax = max(amax, __float_as_uint(f) & 0x7fffffffu);
+                        racc += (double)f;
+                        trow[k * kOpCh] = (float)racc;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kOpCols; ++k) {
+                        if (k < nx) {
+                            const float f = act(raw_of(k));
+                            amax = max(amax, __float_as_uint(f) & 0x7fffffffu);
+                            racc += (double)f;
+                            trow[k * kOpCh] = (float)racc;
+                        }
+                    }
+                }
+            }
+            // the next strip (of this batch, or the first of the next one): requested now, into the registers just consumed
+            if (more) load_strip(cur, last_strip ? y0 + kOpRows : y0, last_strip ? 0 : x0 + kOpCols);
+            lds_barrier();
+            // ---- phase C: column scan of (column x0 + r, channel c) over the rows of the batch, in place
+            if (r < nx) {
+                double acc = colacc[(x0 - xa + r) * kOpCh + c];
+                float *tcol = tile + r * kOpCh + c;
+                if (rows == kOpRows) {
+#pragma unroll
+                    for (int k = 0; k < kOpRows; ++k) {
+                        acc += (double)tcol[k * kOpRowPitch];
+                        tcol[k * kOpRowPitch] = (float)acc;
+                    }
+                } else {
+                    for (int k = 0; k < rows; ++k) {
+                        acc += (double)tcol[k * kOpRowPitch];
+                        tcol[k * kOpRowPitch] = (float)acc;
+                    }
+                }
+                colacc[(x0 - xa + r) * kOpCh + c] = acc;
+            }
+            lds_barrier();
+            // ---- phase S: the finished tile to the channels-last image, 16 bytes per lane, always eight stores per thread
+#pragma unroll
+            for (int j = 0; j < kOpCols / 4; ++j) {
+                const int idx = tid + kOpThreads * j, row = min(idx >> 7, rows - 1), x = min((idx >> 2) & 31, nx - 1), c4 = idx & 3;
+                *reinterpret_cast<float4 *>(out_v + ((size_t)(y0 + row + 1) * (W + 2) + (x0 + x + 1)) * C + 4 * c4) =
+                    *reinterpret_cast<const float4 *>(tile + row * kOpRowPitch + x * kOpCh + 4 * c4);
+            }
+            stores_behind = more; // (without a next strip the stores are the only thing in flight; nobody waits for them)
+            lds_barrier();
+        }
+    }
+    if (m.absmax) {
+        __shared__ unsigned s_max[kOpThreads / kWave];
+        amax = wave_max_u32(amax);
+        if ((tid & 63) == 0) s_max[tid >> 6] = amax;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned mx = 0u;
+            for (int k = 0; k < kOpThreads / kWave; ++k) mx = max(mx, s_max[k]);
+            // entry (view, row y, 64-channel block) of the two-pass layout: the units of a channel block own the rows q, q + 8, ... with
+            // q = 2 (cb & 3) + part (the maximum of a right part covers its own columns only: the left ones are its partner's)
+            unsigned *e = m.absmax + ((size_t)v * (C / kWave) + (cb >> 2)) * H;
+            const int q = 2 * (cb & 3) + part;
+            for (int y = q; y < H; y += 8) e[y] = y == q ? mx : 0u;
+            if (!split) for (int y = q + 1; y < H; y += 8) e[y] = 0u;
+        }
+    }
+}
+
 // The same statistic from a finished integral image (callers that have no feature map at hand, odd shapes): the feature value
 // of a pixel is the second difference of its four integral-image neighbours -- exact up to the rounding of the integral image
 // (~6e-8 of its largest value), which is all a power-of-two scale with a factor 32 of headroom needs.  One wave per entry =
@@ -282,6 +503,44 @@ static int integral_images_launch(const float *const *features, const float *con
     }
     if (row_blocks >= (1ull << 31) || (col_vecs + 255) / 256 >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    // One pass (integral_onepass_kernel) wherever its tiling fits: 16-channel blocks, the column accumulators of a map in LDS
+    // beside the tile, statistics entries for four row classes.  Otherwise the two-pass kernels (same bits).
+    bool onepass = !hwc && C % kOpCh == 0 && C % kWave == 0;
+    int w_max = 0;
+    for (int s = 0; s < n_maps && onepass; ++s) {
+        onepass = a.m[s].H >= 8 && a.m[s].W >= 4 && (size_t)kOpRows * kOpRowPitch * 4 + (size_t)a.m[s].W * kOpCh * 8 <= 160 * 1024 - 1024;
+        w_max = a.m[s].W > w_max ? a.m[s].W : w_max;
+    }
+    if (onepass) {
+        OnePassArgs oa = {};
+        oa.n_maps = n_maps; oa.n_views = n_views; oa.C = C;
+        unsigned long long units = 0;
+        for (int s = 0; s < n_maps; ++s) {
+            oa.m[s] = a.m[s];
+            const int n_strips = (a.m[s].W + kOpCols - 1) / kOpCols;
+            // two units by columns from four strips up; the left one takes 0.6 of the strips: s = 0.6 n balances s against
+            // s / 3 (the right unit's bare accumulation over the left strips) + n - s
+            oa.split[s] = n_strips >= 4 ? (6 * n_strips + 5) / 10 : 0;
+            units += (unsigned long long)n_views * (C / kOpCh) * (oa.split[s] ? 2 : 1);
+            oa.unit_end[s] = (unsigned)units;
+        }
+        if (units >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
+        // (the tile + the column accumulators of the widest unit: 79.9 KB on the bench frame, so that two workgroups share a CU --
+        // a wave issues one of these fp64 instructions every 6-8 cycles, a SIMD takes one every 2: tools/micro/dp_rates.hip)
+        int part_max = 0;
+        for (int s = 0; s < n_maps; ++s) {
+            const int left = oa.split[s] * kOpCols, wide = oa.split[s] ? (left > a.m[s].W - left ? left : a.m[s].W - left) : a.m[s].W;
+            part_max = wide > part_max ? wide : part_max;
+        }
+        const size_t lds = (size_t)kOpRows * kOpRowPitch * 4 + (size_t)part_max * kOpCh * 8;
+        auto launch = [&](auto kern) {
+            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e0 != hipSuccess) return (int)e0;
+            hipLaunchKernelGGL(kern, dim3((unsigned)units), dim3(kOpThreads), lds, st, oa);
+            return (int)hipGetLastError();
+        };
+        return scales ? launch(integral_onepass_kernel<true>) : launch(integral_onepass_kernel<false>);
+    }
     if (hwc) {
         if (scales) hipLaunchKernelGGL((rows_hwc_kernel<true>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
         else hipLaunchKernelGGL((rows_hwc_kernel<false>), dim3((unsigned)row_blocks), dim3(kWave), 0, st, a);
