@@ -586,7 +586,7 @@ def main():
                                         "vfa_integral_images_hwc_f32, against MIOpen conv + torch GroupNorm + ReLU x 3 + "
                                         "vfa_integral_images_f32; outside the timed region of `value`"}
     # ---- N > 1: what the collective costs.  The same steps without it (slowest rank's compute), and the three ways of fusing the
-    # map timed alone on a map-sized tensor: all-reduce, reduce -> rank 0, reduce-scatter over BEV rows + 4-row halo
+    # map timed alone on a map-sized tensor: all-reduce, reduce -> rank 0, reduce-scatter over BEV rows + the heads' 7-row halo
     if world > 1 and a.steps > 0:
         from vfa_amd.aggregate import all_reduce_ortho, reduce_ortho, reduce_scatter_ortho
         leg.collective = False
@@ -611,7 +611,7 @@ def main():
             "map_bytes": probe.numel() * 4,
             "collective_alone_ms": {"all_reduce": coll_ms(lambda: all_reduce_ortho(probe)),
                                     "reduce_to_rank0": coll_ms(lambda: reduce_ortho(probe, 0)),
-                                    "reduce_scatter_rows_halo4": coll_ms(lambda: reduce_scatter_ortho(probe, leg.L, leg.W, halo=4))},
+                                    "reduce_scatter_rows_halo7": coll_ms(lambda: reduce_scatter_ortho(probe, leg.L, leg.W, halo=7))},
             "note": "ms_compute: the same steps with the collective switched off (MAX over ranks); ms_collective_exposed = ms_per_step - "
                     "ms_compute (the collective of frame i -- config.collective -- runs beside the projection of frame i + 1); collective_alone_ms: one "
                     "collective of the map at a time, nothing else on the GPUs"}

@@ -147,8 +147,68 @@ def _collective_worker(rank, world, port, out_dir, length, width):
 @pytest.mark.parametrize("world,length,width", [(2, 21, 6), (3, 16, 5)])
 def test_reduce_and_reduce_scatter_with_halo(world, length, width, tmp_path):
     """The two alternatives to the all-reduce SURVEY section 8e names: `reduce` to the rank that runs the heads, and
-    `reduce_scatter` over bands of BEV rows with the 4-row halo of the heads' dilated convolutions
+    `reduce_scatter` over bands of BEV rows with a halo (4 rows here; what the heads need: test_band_local_heads_need_the_seven_row_halo)
     (reference vfa/model/vfanet.py:48, :52); ragged row counts (zero-padded shares)."""
     port = _free_port()
     mp.spawn(_collective_worker, args=(world, port, str(tmp_path), length, width), nprocs=world, join=True)
     assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(world)]
+
+
+def test_band_local_heads_need_the_seven_row_halo():
+    """What `reduce_scatter` is for: each rank runs the CONVOLUTIONS of `fuse` + the dilation-4 heatmap head on its band of the
+    fused map (reference vfa/model/vfanet.py:44-48: 3x3, 3x3 dilation 2, 3x3 dilation 4 -> 1 + 2 + 4 rows).  With
+    ``HEAD_HALO_ROWS`` = 7 halo rows the band-local outputs equal the full-map ones on every row of the band; with the 4 rows
+    the docs used to promise, rows near a band boundary differ."""
+    import torch.nn as nn
+    from vfa_amd.aggregate import HEAD_HALO_ROWS, row_bands
+    assert HEAD_HALO_ROWS == 7
+    torch.manual_seed(0)
+    C, L, W, world = 16, 40, 12, 3
+    fuse = nn.Sequential(nn.Conv2d(C, C, 3, padding=1), nn.BatchNorm2d(C), nn.ReLU(True),
+                         nn.Conv2d(C, C, 3, padding=2, dilation=2), nn.BatchNorm2d(C), nn.ReLU(True)).eval()
+    head = nn.Sequential(nn.Conv2d(C, 1, 3, padding=4, dilation=4, bias=False)).eval()
+    for m in fuse:
+        if isinstance(m, nn.BatchNorm2d):  # (eval mode: running statistics, band-independent)
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    ortho = torch.rand(1, C, L, W)
+    with torch.no_grad():
+        full = head(fuse(ortho))
+        bands, _ = row_bands(L, world)
+        for halo, exact in ((HEAD_HALO_ROWS, True), (4, False)):
+            worst = 0.0
+            for r0, r1 in bands:
+                top, bottom = min(halo, r0), min(halo, L - r1)
+                band = ortho[:, :, r0 - top:r1 + bottom]            # what reduce_scatter_ortho hands this rank
+                local = head(fuse(band))[:, :, top:top + (r1 - r0)]  # (zero padding at the band's outer edge: only the map's own edges are real)
+                worst = max(worst, (local - full[:, :, r0:r1]).abs().max().item())
+            if exact:
+                assert worst <= 1e-6, worst
+            else:
+                assert worst > 1e-3, worst  # the old 4-row halo is NOT enough
+
+
+def _subgroup_reduce_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vfa_amd.aggregate import reduce_ortho
+        group = dist.new_group([1, 2])  # (does not contain global rank 0)
+        if rank in (1, 2):
+            part = torch.full((6, 4), float(rank))
+            got = reduce_ortho(part, dst=0, group=group)  # group rank 0 = global rank 1
+            if rank == 1:
+                assert torch.all(got == 3.0)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reduce_onto_rank_zero_of_a_subgroup(tmp_path):
+    """`reduce_ortho(dst=0, group=g)` means rank 0 OF THE GROUP, also when the group does not contain global rank 0
+    (``distributed="reduce"`` of ``aggregate_views`` goes through it)."""
+    port = _free_port()
+    mp.spawn(_subgroup_reduce_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1", "ok2"]

@@ -39,7 +39,7 @@ def main():
         assert err <= 2e-5 * scale, (name, err, scale)
     if rank == 0:  # reduce: the fused map on rank 0
         assert (red - full).abs().max().item() <= 2e-5 * scale
-    # reduce_scatter: this rank's band of BEV rows + the 4-row halo of the heads
+    # reduce_scatter: this rank's band of BEV rows + the halo of the heads (HEAD_HALO_ROWS = 7)
     want = full[:, :, r0 - top:r1 + bottom]
     assert band.shape == want.shape, (band.shape, want.shape)
     assert (band - want).abs().max().item() <= 2e-5 * scale

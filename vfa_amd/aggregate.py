@@ -119,11 +119,18 @@ def all_reduce_ortho(ortho_nhwc, group=None):
 
 
 def reduce_ortho(ortho_nhwc, dst=0, group=None):
-    """Sum the partial BEV maps onto rank ``dst`` only (the BEV heads then run on one rank): half the traffic of an
-    all-reduce.  Other ranks get their buffer back with unspecified contents.  Returns the tensor."""
+    """Sum the partial BEV maps onto rank ``dst`` OF THE GROUP only (the BEV heads then run on one rank): half the traffic of an
+    all-reduce.  Other ranks get their buffer back with unspecified contents.  Returns the tensor.  (``dst`` is a group rank:
+    ``torch.distributed.reduce`` wants the global one, and a sub-group need not contain global rank ``dst``.)"""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(ortho_nhwc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        dist.reduce(ortho_nhwc, dst=dist.get_global_rank(group, dst) if group is not None else dst, op=dist.ReduceOp.SUM, group=group)
     return ortho_nhwc
+
+
+# Rows of the fused map a BEV row of the heads' outputs depends on, on either side (reference vfa/model/vfanet.py:44-52): `fuse`
+# is a 3x3 convolution (1 row) followed by a 3x3 with dilation 2 (2 rows); `map_classifier` / `orient_pred` add a 3x3 with
+# dilation 4 (4 rows): 1 + 2 + 4 = 7; `tytx_pred` / `thtwtl_pred` add two plain 3x3: 1 + 2 + 1 + 1 = 5.
+HEAD_HALO_ROWS = 7
 
 
 def row_bands(length, world):
@@ -134,9 +141,12 @@ def row_bands(length, world):
 
 def reduce_scatter_ortho(ortho_nhwc, length, width, halo=0, group=None):
     """Sum the partial maps and leave every rank with ONE band of BEV rows (+ ``halo`` rows of its neighbours on either side):
-    the BEV heads are convolutions with a receptive field of a few rows (dilation 4: reference vfa/model/vfanet.py:48, :52), so
-    each rank can run them on its band and only the small head outputs are gathered -- a reduce-scatter moves (p - 1) / p of the
-    map once instead of the all-reduce's twice.
+    the BEV heads are convolutions with a receptive field of a few rows, so each rank can run their CONVOLUTIONS on its band and
+    only the small head outputs are gathered -- a reduce-scatter moves (p - 1) / p of the map once instead of the all-reduce's
+    twice.  What a band-local head needs: ``HEAD_HALO_ROWS`` = 7 rows (`fuse`: 1 + 2, then the dilation-4 convolution of the heatmap
+    / orientation heads: reference vfa/model/vfanet.py:44-52); with fewer the outputs within (7 - halo) rows of a band boundary are
+    wrong.  NOT band-local at any halo: the GroupNorm layers of `tytx_pred` / `thtwtl_pred` and a train-mode BatchNorm in `fuse`
+    take their statistics over the WHOLE map -- run those heads on the gathered `fuse` output (or all-reduce their statistics).
 
     ortho_nhwc (L*W, C) partial map of this rank.  Returns ``(band, (row0, row1), (top, bottom))``: band ((row1 - row0 + top +
     bottom) * W, C) holds rows [row0 - top, row1 + bottom) of the fused map; top / bottom <= halo are the halo rows that exist
@@ -204,7 +214,7 @@ class PendingOrtho:
 
 
 def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange=(-1, 0.95), reduce_group=None,
-                    distributed=False, integrals=None):
+                    distributed=False, integrals=None, halo=None):
     """The camera loop of ``VFANet.forward`` for the cameras held by this process.
 
     lat* (n,C,h,w) lateral maps of the local cameras, calibs (n,3,4), grid (1,L,W,3)
@@ -212,8 +222,9 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
     With ``distributed=True`` the partial sums of all ranks are all-reduced before returning; with
     ``distributed="async"`` (inference) the all-reduce is only launched and a ``PendingOrtho`` is returned, so that
     the collective of frame i overlaps the projection of frame i+1 (``"async_reduce"``: the same with a reduce onto rank 0).  ``distributed="reduce"``: the fused map lands on rank 0
-    only; ``distributed="reduce_scatter"``: every rank gets its band of BEV rows plus the 4-row halo of the heads' dilated
-    convolutions and the call returns ``(band (1,C,rows,W), (row0, row1), (top, bottom))`` (``reduce_scatter_ortho``).
+    only; ``distributed="reduce_scatter"``: every rank gets its band of BEV rows plus ``halo`` rows of its neighbours (default
+    ``HEAD_HALO_ROWS`` = 7: what `fuse` + the dilation-4 heads read; see ``reduce_scatter_ortho`` for what is NOT band-local) and the
+    call returns ``(band (1,C,rows,W), (row0, row1), (top, bottom))``.
     ``integrals``: the three integral-image batches instead of the lateral maps (producer fusion, inference on the fused frame
     path only; ``lat*`` may then be None).
     """
@@ -289,8 +300,8 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
         return PendingOrtho(ortho, work, (length, width, c_out))
     if distributed == "reduce":  # the fused map on rank 0 only (the caller runs the heads there)
         ortho = reduce_ortho(ortho, 0, reduce_group)
-    elif distributed == "reduce_scatter":  # this rank's band of BEV rows + the heads' 4-row halo: (band (1,C,rows,W), rows, halo)
-        band, rows, halo = reduce_scatter_ortho(ortho, length, width, halo=4, group=reduce_group)
+    elif distributed == "reduce_scatter":  # this rank's band of BEV rows + the heads' halo: (band (1,C,rows,W), rows, halo)
+        band, rows, halo = reduce_scatter_ortho(ortho, length, width, halo=HEAD_HALO_ROWS if halo is None else int(halo), group=reduce_group)
         n_rows = rows[1] - rows[0] + halo[0] + halo[1]
         return band.view(1, n_rows, width, c_out).permute(0, 3, 1, 2), rows, halo
     elif distributed:

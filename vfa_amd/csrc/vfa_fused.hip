@@ -416,6 +416,10 @@ struct FusedArgs {
 };
 // diagnostic ablations (VFA_FLAG_DEBUG(mask), pool_collapse_kernel<TERMS, true> only)
 constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgOneW = 8, kDbgNoRecords = 16, kDbgNoExtra = 32, kDbgStamps = 128; // (64: only the direct-item launch)
+// VFA_DEBUG_DUMP_VOX: with ONE view and ONE scale, `out` receives the pooled fp32 voxel features (cell, channel) exactly as the
+// pooling code of THIS kernel forms them in front of the operand split -- (((lt + rb) - rt) - lb) * RN(1 / area), masked boxes their
+// masked value -- instead of the map: what tests/test_fused_frame.py compares with the reference's voxel features.
+constexpr int kDbgDumpVox = 0x800;
 
 struct Frag { bf16x8 hi, lo; };
 
@@ -593,6 +597,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 
     // output rows of a tile: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 MFMA block, column r
     auto write_tile = [&](int tile, const f32x16 &sum, bool have_sum) {
+        if (DIAG && (a.debug & kDbgDumpVox)) return; // (the output buffer holds the dumped voxel features)
         const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
         float extra = 0.0f; // fully masked (view, scale) items of this tile: vox = 0 -> relu(bias)
         if (!DIRECT && !(DIAG && (a.debug & kDbgNoExtra))) {
@@ -701,6 +706,12 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                                              (__attribute__((address_space(3))) void *)(s_taps + (kMaxSlots + k) * 64), 16, 0, 0);
         }
     };
+    // diagnostic (kDbgDumpVox): the voxel features of box `row` of `tile`, channels 4 c4 .. 4 c4 + 3, to the output buffer
+    auto dump_vox = [&](int tile, int row, int c4, float4 v) {
+        const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
+        const int cl = tl * kTileL + (row >> 3), cw = tw * kTileW + (row & 7);
+        if (cl < a.L && cw < a.W) *reinterpret_cast<float4 *>(a.out + (size_t)(cl * a.W + cw) * kC + 4 * c4) = v;
+    };
     auto pool = [&](const Item &it, int it_flags, int it_word1, float s_a) {
         if (!DIRECT && (it_flags & kTileRows)) {
             // a direct item of the main launch: its pooled rows arrived as its window (slot b = row of box b); only the
@@ -708,6 +719,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 v = s_taps[(4 * wave + grp) * 64 + q * 16 + cq];
+                if (DIAG && (a.debug & kDbgDumpVox)) dump_vox(it.tile, 4 * wave + grp, q * 16 + cq, v);
                 if constexpr (F16) v = mul4(v, s_a);
                 store_quad<F16>(s_planes, 4 * wave + grp, q * 16 + cq, v);
             }
@@ -767,6 +779,10 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             float4 v = make_float4(lt.x + rb.x, lt.y + rb.y, lt.z + rb.z, lt.w + rb.w);
             v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
             v = make_float4(v.x - lb.x, v.y - lb.y, v.z - lb.z, v.w - lb.w);
+            if (DIAG && (a.debug & kDbgDumpVox)) { // (the same product without the power-of-two factor of the fp16 split: the same bits / 2^ea)
+                const float sc0 = vis ? rcp : masked;
+                dump_vox(it.tile, row, q * 16 + cq, make_float4(v.x * sc0, v.y * sc0, v.z * sc0, v.w * sc0));
+            }
             store_quad_at<F16>(s_planes, plane0 ^ (q << 7), make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale));
         };
         if constexpr (DIRECT) {
@@ -879,15 +895,16 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             if (!(at_begin || at_end)) {
                 write_tile(pend_tile, sum, true);
             } else {
-                // every part goes to the workspace (sc1 stores, every storing wave drained, then one ticket per workgroup); the
-                // last arriver adds the parts in workgroup order -- one fixed association -- and stores the tile
+                // every part goes to the workspace (sc1 stores, every storing wave drained, then one acquire-release ticket per
+                // workgroup at agent scope: vfa_pipe.hip, finish_tile); the last arriver adds the parts in workgroup order -- one
+                // fixed association -- and stores the tile
                 const int which = at_begin ? 0 : 1;
                 float *pp = a.partial + (((size_t)lb * 2 + which) * 8 + wave) * 16 * 64 + lane;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) __hip_atomic_store(pp + i * 64, sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.tickets + pend_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.tickets + pend_tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
                 const int first = at_begin ? sh_b_first : sh_e_first, last = at_begin ? sh_b_last : sh_e_last;
                 const int parts = at_begin ? sh_b_parts : sh_e_parts;
@@ -1651,6 +1668,11 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
     a.tickets = reinterpret_cast<unsigned *>(const_cast<unsigned char *>(ws) + lay.tickets);
     a.debug = debug;
     a.diag = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(ws) + lay.diag);
+    if (debug & kDbgDumpVox) { // (one view, one scale: `out` has room for exactly one set of voxel features; masked tiles stay 0)
+        if (n_views != 1 || n_scales != 1 || accumulate || !out) return VFA_ERR_BAD_ARGUMENT;
+        const hipError_t e = hipMemsetAsync(out, 0, (size_t)L * W * kC * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
     int n_cu = 256;
     {
         int dev = 0, cus = 0;

@@ -73,6 +73,9 @@ constexpr int kBalTag = kMaxBlocks + 1, kBalSig = kMaxBlocks + 2, kBalCyclesAt =
 constexpr int kSigAt = kChunks + 1; // the cuts kernel leaves the frame's total cost behind the last entry of chunk_start (2 ints)
 constexpr int kVis = 1;
 constexpr int kTileLive = 1, kTileDirect = 2;
+// VFA_DEBUG_DUMP_VOX (diagnostic build): with ONE view, ONE scale and ONE layer `out` receives the pooled fp32 voxel features (cell,
+// channel) exactly as the pooling waves form them in front of the operand split, instead of the map (tests/test_pipe_frame.py)
+constexpr int kDbgDumpVox = 0x800;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -645,6 +648,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         };
         // output rows of a tile: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 block, column r
         auto write_tile = [&](int tile, const f32x16 &v, bool have) {
+            if (DIAG && (a.debug & kDbgDumpVox)) return; // (the output buffer holds the dumped voxel features)
             const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
             float extra = 0.0f; // fully masked (view, scale) of this tile: vox = 0 -> relu(bias)
 #pragma unroll
@@ -1039,7 +1043,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // the wave's 16 boxes x the 64 channels of quarter q: lane (box pb, piece pi) takes the 16-byte pieces
         // ((pb + m) & 3) * 4 + pi, m = 0..3, of its taps' quarter slots -- the four boxes of an LDS cycle read different 64-byte
         // quarters of the banks whatever slots they hold
-        auto pool = [&](auto glob_tag, const LaneBox &bx, int i, int x) {
+        auto pool = [&](auto glob_tag, const LaneBox &bx, int i, int x, int tile) {
             constexpr bool GLOB = decltype(glob_tag)::value;
             const int k = i & 7, set = k & 1;
             const unsigned char *win = s_win + (set * 2 + x) * kWinBytes;
@@ -1097,6 +1101,14 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
                 v = make_float4(v.x - lb2.x, v.y - lb2.y, v.z - lb2.z, v.w - lb2.w);
                 const float xs[4] = {v.x * bx.scl, v.y * bx.scl, v.z * bx.scl, v.w * bx.scl};
+                if (DIAG && (a.debug & kDbgDumpVox)) { // (one view: sub-tile 0 of set 0; the power-of-two factor of the fp16 split taken out again: exact)
+                    const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w, brow = phalf * 16 + pb;
+                    const int cl = tl * kTileL + (brow >> 3), cw = tw * kTileW + (brow & 7);
+                    const float back = F16 ? pow2f(64 - (int)(s_sc[0][9] >> 16)) : 1.0f;
+                    if (x == 0 && cl < a.L && cw < a.W)
+                        *reinterpret_cast<float4 *>(a.out + (size_t)(cl * a.W + cw) * kC + (k >> 1) * 64 + (int)piece * 16 + pi * 4) =
+                            make_float4(xs[0] * back, xs[1] * back, xs[2] * back, xs[3] * back);
+                }
                 // x = hi + lo + r, |r| <= 2^-17 |x|: hi = RNE bf16(x), lo = RNE bf16(x - hi)
                 // (three-piece variant: lo2 = RNE bf16(x - hi - lo), |x - hi - lo - lo2| <= 2^-25 |x|)
                 union { __bf16 b[4]; uint2 u; } hi, lo, lo2;
@@ -1118,7 +1130,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 if constexpr (TERMS == 6) *reinterpret_cast<uint2 *>(planes + 2 * kPlaneBytes + off) = lo2.u;
             }
         };
-        auto pool_step = [&](auto set_tag, int i) {
+        auto pool_step = [&](auto set_tag, int i, int tile) {
             constexpr int SET = decltype(set_tag)::value;
             const int n = i >> 3, k = i & 7, x = px;
             auto one = [&](LaneBox &bx, bool &glob, bool &live) { // (called with the registers of the step's set)
@@ -1142,8 +1154,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     return;
                 }
                 if (DIAG && (a.debug & 2)) return;
-                if (glob) pool(std::true_type{}, bx, i, x);
-                else pool(std::false_type{}, bx, i, x);
+                if (glob) pool(std::true_type{}, bx, i, x, tile);
+                else pool(std::false_type{}, bx, i, x, tile);
             };
             if constexpr (SET == 0) one(boxA, globA, liveA);
             else one(boxB, globB, liveB);
@@ -1156,7 +1168,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             } else {
                 // Whoever arrives LAST adds the parts (in workgroup order: one fixed association) and stores the tile; the
                 // others leave their sums in the workspace and go on.  sc1 stores and loads on both sides, every storing wave
-                // drained, then one ticket per workgroup (guide: inter-workgroup visibility, valid forms).
+                // drained, then one ticket per workgroup (guide: inter-workgroup visibility, valid forms).  The ticket is an
+                // acquire-release operation at agent scope: the memory model then orders the parts of every earlier arriver in
+                // front of the last arriver's loads (the sc1 forms alone rest on how gfx950 happens to treat them); it runs at most
+                // twice per workgroup and launch.
                 const int which = (tile == t_begin && k_begin > 0) ? 0 : 1;
                 if constexpr (!POOL) {
                     float *pp = a.partial + (((size_t)lb * 3 + which) * 8 + wave) * 16 * 64 + lane;
@@ -1170,7 +1185,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 const int last = tile == t_begin && k_begin > 0 ? sh_b_last : sh_e_last;
                 const int parts = tile == t_begin && k_begin > 0 ? sh_b_parts : sh_e_parts;
                 if (tid == 0) {
-                    const unsigned old = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned old = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                     s_misc[0] = old;
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1261,7 +1276,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 }
                 if (W16 && table_wave && m == 2) hdr_dma((i >> 3) + 2); // (first too: its 256 bytes land under the pooling)
                 if (!dma_matrix && (live & 4u) && !bare) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
-                if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i);
+                if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i, rec.tile);
                 // The tables (see `tables and DMA`), a phase further ahead than on twelve waves and behind the pooling: the descriptors
                 // of phase n + 1 (~1 000 cycles; its headers were requested a phase ago) in the FIRST step of phase n, where the
                 // matrix waves end a group (relu, view sum, tile store) and the pooling waves wait longest at the barrier; the record
@@ -1770,6 +1785,11 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
     a.debug = debug;
     a.balance = reinterpret_cast<int *>(ws + lay.balance);
     const int nblk = pipe_blocks(lay.n_tiles, reserved_cus);
+    if (debug & kDbgDumpVox) { // (one view, one scale, one layer: `out` has room for exactly one set of voxel features)
+        if (n_views != 1 || n_scales != 1 || n_layers != 1 || accumulate) return VFA_ERR_BAD_ARGUMENT;
+        const hipError_t e0 = hipMemsetAsync(out, 0, (size_t)L * W * kC * sizeof(float), s);
+        if (e0 != hipSuccess) return (int)e0;
+    }
     // every call takes its own tickets: a second pass over the same workspace (accumulate) must not see the first one's
     const hipError_t e = hipMemsetAsync(a.tickets, 0, (size_t)lay.n_tiles * 4, s);
     if (e != hipSuccess) return (int)e;

@@ -589,6 +589,11 @@ def pipe_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_h
     need = pipe_workspace_bytes(n, L, W, nl, ns)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=calibs.device)
+        # a fresh workspace has no balance state (the geometry calls never touch it: whoever allocates clears it, like
+        # `vfa_pipe_balance_f32` mode 0): garbage there could pass for bounds if its tag and signature happened to match
+        if need > 0:
+            bal = pipe_workspace_layout(n, L, W, nl, ns)["balance"]
+            workspace[bal:bal + BALANCE_STATE_BYTES].zero_()
     hw = _lib.int_array([v for f in feat_hws for v in f])
     args = (_lib.ptr(calibs), _lib.ptr(grid), _lib.ptr(z_layers), nl, _lib.ptr(corner_off), n, L, W, int(conv_kind),
             float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), ns, hw)

@@ -313,16 +313,22 @@ def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumu
 # "1" (default): the first frame of a geometry computes balanced work shares for the pipelined kernel's workgroups
 # (`vfa_pipe_balance_f32`), kept with the persistent workspace; "0": the uniform split of the work cuts.
 PIPE_BALANCE = os.environ.get("VFA_AMD_PIPE_BALANCE", "1") == "1"
-_pipe_states = {}  # (device, shapes) -> persistent workspace (+ balance state per band); the two most recent geometries are kept
+# (device, stream, shapes) -> persistent workspace (+ balance state per band).  The most recent geometries are kept: a caller that
+# loops over per-scale `project_sum` / `VFA.forward` calls cycles through one key per feature scale and camera set -- with two
+# entries every call missed, re-allocated, re-zeroed and re-balanced (a single-workgroup kernel of milliseconds per call)
+PIPE_STATES_KEPT = int(os.environ.get("VFA_AMD_PIPE_STATES", "8"))
+_pipe_states = {}
 _pipe_pinned = []  # ... and those a captured hipGraph replays into
 
 
 def _pipe_state(dev, key, ws_bytes, n_bands):
-    key = (dev.index,) + key
+    # one workspace per (geometry, stream): the geometry call of a frame on another stream must not overwrite records the
+    # previous frame's kernel on THIS stream is still reading (`side.wait_stream(cur)` only orders against the current one)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream) + key
     st = _pipe_states.pop(key, None)
     if st is None:
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-        lay = ops.pipe_workspace_layout(key[1], key[4], key[3], key[5], key[6])
+        lay = ops.pipe_workspace_layout(key[2], key[5], key[4], key[6], key[7])
         st = {"ws": ws, "frames": 0, "balance_off": lay["balance"],
               "bands": [torch.zeros(ops.BALANCE_STATE_BYTES, dtype=torch.uint8, device=dev) for _ in range(n_bands)] if n_bands > 1 else None}
         ws[lay["balance"]:lay["balance"] + ops.BALANCE_STATE_BYTES].zero_()  # (= vfa_pipe_balance_f32 mode 0)
@@ -331,7 +337,7 @@ def _pipe_state(dev, key, ws_bytes, n_bands):
         st["pinned"] = True
         _pipe_pinned.append(st)
     _pipe_states[key] = st  # (most recent last)
-    while len(_pipe_states) > 2:
+    while len(_pipe_states) > PIPE_STATES_KEPT:
         _pipe_states.pop(next(iter(_pipe_states)))
     return st
 
