@@ -20,7 +20,7 @@
  *     voxels.  The FUSED frame entry points (vfa_pool_collapse_relu_sum_f32, vfa_pipe_collapse_relu_sum_f32) never
  *     write voxel features; inside them the tap chains and the box sum are the same exact sequence, but the quotient is
  *     v * RN(1 / area) where the reference divides: their on-chip voxel features are within ONE unit in the last place of
- *     the reference's (79-87 % of them identical: VFA_FLAG_DEBUG(VFA_DEBUG_DUMP_VOX), tests/test_fused_frame.py), and
+ *     the reference's (79-87 % of them identical: VFA_FLAG_DUMP_VOX, tests/test_fused_frame.py), and
  *     their output is compared with the reference within the post-GEMM tolerance (rtol 1e-4, atol 1e-5 max|ref|);
  *   - `n_views` batches cameras that share feature-map and grid shapes (one scale of one frame).
  *
@@ -84,10 +84,10 @@ int vfa_abi_version(void);
 /* vfa_pool_collapse_relu_sum_f32 only, DIAGNOSTIC: bits 16-27 select a profiling build of the kernel (phase ablations,
  * in-kernel cycle stamps written behind the records in the workspace); its results are meaningless.  tools/ use it. */
 #define VFA_FLAG_DEBUG(mask) (((mask) & 0xfff) << 16)
-/* ... one debug bit that tests (not only tools) use, on both fused entry points: with ONE view, ONE scale (and one layer) `out`
- * receives the pooled fp32 voxel features (cell, channel) exactly as the kernel's own pooling code forms them in front of the operand
- * split, instead of the map.  That is how the fused kernels' pre-GEMM arithmetic is compared with the reference's. */
-#define VFA_DEBUG_DUMP_VOX 0x800
+/* Both fused entry points, for TESTS: with ONE view, ONE scale (and one layer) `out` receives the pooled fp32 voxel features (cell,
+ * channel) exactly as the kernel's own pooling code forms them in front of the operand split, instead of the map (a diagnostic
+ * build of the same source).  That is how the fused kernels' pre-GEMM arithmetic is compared with the reference's. */
+#define VFA_FLAG_DUMP_VOX (1 << 30)
 /* vfa_pool_collapse_relu_sum_f32 only: the entry point in two calls -- first ROWS_ONLY (the pre-pass over the direct items: needs
  * the box records of the frame, not its work cuts), later SKIP_ROWS (everything else).  Lets a caller that computes the geometry
  * on a second stream wait for vfa_frame_boxes_f32 before the first call and for vfa_frame_cuts_f32 only before the second. */

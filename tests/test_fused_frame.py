@@ -593,7 +593,7 @@ def _ulp_diff(a, b):
 
 @pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 7, None), ("wildtrack_480x1440x1", 2, (120, 1440))])
 def test_shipped_pooling_code_vs_the_reference_voxel_features(name, n_cam, crop):
-    """The voxel features AS THE FUSED KERNEL FORMS THEM (diagnostic VFA_DEBUG_DUMP_VOX: the pooled fp32 rows in front of the operand
+    """The voxel features AS THE FUSED KERNEL FORMS THEM (diagnostic VFA_FLAG_DUMP_VOX: the pooled fp32 rows in front of the operand
     split, written by the kernel's own pooling code) against the bit-pinned voxel features of ``vfa_project_gather_f32`` (= the
     reference's, tests/test_hip_parity.py).  The tap chains and the box sum are the reference's exact sequence; the quotient is
     v * RN(1 / area) where the reference divides (vfa_op.py:118-119), so the rows are NOT always the reference's bits: this test
@@ -618,9 +618,9 @@ def test_shipped_pooling_code_vs_the_reference_voxel_features(name, n_cam, crop)
                 integrals = ops.integral_images([lat])
                 ref = ops.project_gather(integrals[0], calib.reshape(1, 12).contiguous(), grid_flat, zl, co, kind, img_wh, kernel="direct")[0]
                 ws = ops.frame_records(calib, grid, zl, co, kind, img_wh, [tuple(lat.shape[-2:])], weights=[mods[s].layer_major_weight()])
-                got = ops.pool_collapse(integrals, [mods[s].collapse.bias], ws, (L, W), debug=0x800)
+                got = ops.pool_collapse(integrals, [mods[s].collapse.bias], ws, (L, W), dump_vox=True)
                 wsp = ops.pipe_records(calib, grid, zl, co, kind, img_wh, [tuple(lat.shape[-2:])], weights=[mods[s].collapse.weight])
-                gotp = ops.pipe_collapse(integrals, [mods[s].collapse.bias], wsp, (L, W), 1, debug=0x800)
+                gotp = ops.pipe_collapse(integrals, [mods[s].collapse.bias], wsp, (L, W), 1, dump_vox=True)
             for label, g in (("serial", got), ("pipelined", gotp)):
                 same_zero = (g == 0) & (ref == 0)  # (the sign of a masked zero is free)
                 d = torch.where(same_zero, torch.zeros_like(g, dtype=torch.int64), _ulp_diff(g, ref))

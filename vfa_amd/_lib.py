@@ -17,6 +17,7 @@ BWD_ACCUMULATE = 1
 
 
 FLAG_ROWS_ONLY, FLAG_SKIP_ROWS = 1 << 28, 1 << 29  # VFA_FLAG_ROWS_ONLY / VFA_FLAG_SKIP_ROWS (vfa_pool_collapse_relu_sum_f32)
+FLAG_DUMP_VOX = 1 << 30  # VFA_FLAG_DUMP_VOX (both fused entry points; tests)
 
 
 def collapse_flags(terms=0, reserved_cus=0):

@@ -24,6 +24,10 @@
 #include "vfa_geom.h"
 #include "vfa_split.h"
 
+#ifndef VFA_TICKET_ORDER
+#define VFA_TICKET_ORDER __ATOMIC_ACQ_REL // (the hand-off ticket of a tile cut between workgroups: see finish_tile / flush)
+#endif
+
 namespace {
 using namespace vfa_dev;
 
@@ -416,10 +420,10 @@ struct FusedArgs {
 };
 // diagnostic ablations (VFA_FLAG_DEBUG(mask), pool_collapse_kernel<TERMS, true> only)
 constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgOneW = 8, kDbgNoRecords = 16, kDbgNoExtra = 32, kDbgStamps = 128; // (64: only the direct-item launch)
-// VFA_DEBUG_DUMP_VOX: with ONE view and ONE scale, `out` receives the pooled fp32 voxel features (cell, channel) exactly as the
+// VFA_FLAG_DUMP_VOX: with ONE view and ONE scale, `out` receives the pooled fp32 voxel features (cell, channel) exactly as the
 // pooling code of THIS kernel forms them in front of the operand split -- (((lt + rb) - rt) - lb) * RN(1 / area), masked boxes their
 // masked value -- instead of the map: what tests/test_fused_frame.py compares with the reference's voxel features.
-constexpr int kDbgDumpVox = 0x800;
+constexpr int kDbgDumpVox = 0x1000; // (set by VFA_FLAG_DUMP_VOX; bits 0-11 are VFA_FLAG_DEBUG's)
 
 struct Frag { bf16x8 hi, lo; };
 
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                 for (int i = 0; i < 16; ++i) __hip_atomic_store(pp + i * 64, sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.tickets + pend_tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.tickets + pend_tile, 1u, VFA_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
                 const int first = at_begin ? sh_b_first : sh_e_first, last = at_begin ? sh_b_last : sh_e_last;
                 const int parts = at_begin ? sh_b_parts : sh_e_parts;
@@ -1611,8 +1615,9 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
                                    const void *workspace, size_t workspace_bytes, float *out, int n_views, int L, int W, int n_scales,
                                    const int *feat_hw, int accumulate, int flags, void *stream)
 {
-    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xfff;
-    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00 | VFA_FLAG_ROWS_ONLY | VFA_FLAG_SKIP_ROWS)) return VFA_ERR_BAD_ARGUMENT;
+    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
+    const int debug = ((flags >> 16) & 0xfff) | ((flags & VFA_FLAG_DUMP_VOX) ? kDbgDumpVox : 0);
+    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00 | VFA_FLAG_ROWS_ONLY | VFA_FLAG_SKIP_ROWS | VFA_FLAG_DUMP_VOX)) return VFA_ERR_BAD_ARGUMENT;
     if ((flags & VFA_FLAG_ROWS_ONLY) && (flags & VFA_FLAG_SKIP_ROWS)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales || !feat_hw || !integrals ||
         (terms != 0 && terms != 2 && terms != 3 && terms != 4))

@@ -30,6 +30,10 @@
 #include "vfa_pipe_seq.h"
 #include "vfa_split.h"
 
+#ifndef VFA_TICKET_ORDER
+#define VFA_TICKET_ORDER __ATOMIC_ACQ_REL // (the hand-off ticket of a tile cut between workgroups: see finish_tile / flush)
+#endif
+
 namespace {
 using namespace vfa_dev;
 using namespace vfa_pipe;
@@ -73,9 +77,9 @@ constexpr int kBalTag = kMaxBlocks + 1, kBalSig = kMaxBlocks + 2, kBalCyclesAt =
 constexpr int kSigAt = kChunks + 1; // the cuts kernel leaves the frame's total cost behind the last entry of chunk_start (2 ints)
 constexpr int kVis = 1;
 constexpr int kTileLive = 1, kTileDirect = 2;
-// VFA_DEBUG_DUMP_VOX (diagnostic build): with ONE view, ONE scale and ONE layer `out` receives the pooled fp32 voxel features (cell,
+// VFA_FLAG_DUMP_VOX (diagnostic build): with ONE view, ONE scale and ONE layer `out` receives the pooled fp32 voxel features (cell,
 // channel) exactly as the pooling waves form them in front of the operand split, instead of the map (tests/test_pipe_frame.py)
-constexpr int kDbgDumpVox = 0x800;
+constexpr int kDbgDumpVox = 0x1000; // (set by VFA_FLAG_DUMP_VOX; bits 0-11 are VFA_FLAG_DEBUG's)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -1185,7 +1189,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 const int last = tile == t_begin && k_begin > 0 ? sh_b_last : sh_e_last;
                 const int parts = tile == t_begin && k_begin > 0 ? sh_b_parts : sh_e_parts;
                 if (tid == 0) {
-                    const unsigned old = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned old = __hip_atomic_fetch_add(a.tickets + tile, 1u, VFA_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
                     s_misc[0] = old;
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1729,8 +1733,9 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
                                    void *workspace, size_t workspace_bytes, float *out, int n_views, int L, int W, int n_layers,
                                    int n_scales, const int *feat_hw, int accumulate, int flags, void *stream)
 {
-    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff, debug = (flags >> 16) & 0xfff;
-    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00)) return VFA_ERR_BAD_ARGUMENT;
+    const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
+    const int debug = ((flags >> 16) & 0xfff) | ((flags & VFA_FLAG_DUMP_VOX) ? kDbgDumpVox : 0);
+    if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00 | VFA_FLAG_DUMP_VOX)) return VFA_ERR_BAD_ARGUMENT;
     if (!dims_ok(n_views, L, W, n_layers, n_scales) || !feat_hw || !integrals ||
         (terms != 0 && terms != 2 && terms != 3 && terms != 4 && terms != 6))
         return VFA_ERR_BAD_ARGUMENT;

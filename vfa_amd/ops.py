@@ -504,7 +504,7 @@ def frame_cuts(workspace, n_views, grid_lw, n_scales, weights=None, terms=0):
 
 
 def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0, stage="all",
-                  absmax=None):
+                  absmax=None, dump_vox=False):
     """out (L*W, 256) (+)= sum_scale sum_view relu(vox . W^T + b): pooling + collapse + ReLU + view / scale sum in one
     persistent kernel, the voxel features never touch HBM (reference vfa_op.py:112-125, vfanet.py:79, 82).
 
@@ -528,7 +528,7 @@ def pool_collapse(integrals, biases, workspace, grid_lw, out=None, accumulate=Fa
     absmax, absmax_ptrs = _absmax_of(integrals, absmax)
     _launch("vfa_pool_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), absmax_ptrs, _lib.ptr_array(biases), _lib.ptr(workspace),
             workspace.numel(), _lib.ptr(out) if out is not None else None, n, L, W, ns, hw, 1 if accumulate else 0,
-            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16) | stage_flag,  # debug: diagnostic build, tools/ only
+            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16) | stage_flag | (_lib.FLAG_DUMP_VOX if dump_vox else 0),  # debug: diagnostic build, tools/ only
             _lib.current_stream_handle(), tag=(n, L, W, tuple((i.shape[1] - 2, i.shape[2] - 2) for i in integrals), stage))
     return out
 
@@ -627,7 +627,7 @@ def pipe_cuts(workspace, n_views, grid_lw, n_layers, n_scales, weights=None, ter
 
 
 def pipe_collapse(integrals, biases, workspace, grid_lw, n_layers, out=None, accumulate=False, terms=0, reserved_cus=0, debug=0,
-                  absmax=None):
+                  absmax=None, dump_vox=False):
     """out (L*W, 256) (+)= sum_scale sum_view relu(vox . W^T + b) for K = n_layers * 256: pooling, collapse, ReLU, view and scale
     sums in one persistent kernel (pooling waves and matrix waves side by side); the voxel features never touch HBM
     (reference vfa_op.py:110-125, vfanet.py:79, 82).  workspace = ``pipe_records`` of the same frame."""
@@ -645,8 +645,8 @@ def pipe_collapse(integrals, biases, workspace, grid_lw, n_layers, out=None, acc
     absmax, absmax_ptrs = _absmax_of(integrals, absmax)
     _launch("vfa_pipe_collapse_relu_sum_f32", _lib.ptr_array(list(integrals)), absmax_ptrs, _lib.ptr_array(biases), _lib.ptr(workspace),
             workspace.numel(), _lib.ptr(out), n, L, W, int(n_layers), ns, hw, 1 if accumulate else 0,
-            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16), _lib.current_stream_handle(),
-            tag=(n, L, W, int(n_layers), tuple((i.shape[1] - 2, i.shape[2] - 2) for i in integrals)))
+            _lib.collapse_flags(terms, reserved_cus) | ((int(debug) & 0xfff) << 16) | (_lib.FLAG_DUMP_VOX if dump_vox else 0),
+            _lib.current_stream_handle(), tag=(n, L, W, int(n_layers), tuple((i.shape[1] - 2, i.shape[2] - 2) for i in integrals)))
     return out
 
 
