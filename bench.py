@@ -61,6 +61,7 @@ def parse():
     p.add_argument("--c5-steps", type=int, default=3, help="timed steps of the synthetic4k_512x512x32 leg (0 disables)")
     p.add_argument("--rotate", type=int, default=4, help="input sets of the rotating-input leg (0 disables)")
     p.add_argument("--fp32-steps", type=int, default=20, help="timed steps of the fp32-arithmetic collapse leg (0 disables)")
+    p.add_argument("--proxy-steps", type=int, default=20, help="timed steps of the per-rank proxy legs (0 disables)")
     p.add_argument("--tune-gemm", type=int, default=0,
                    help="1: TunableOp selects the library GEMM in warm-up (only used with VFA_AMD_COLLAPSE=library)")
     return p.parse_args()
@@ -294,7 +295,7 @@ ROOFLINE_ENTRY_POINTS = tuple(KERNEL_NAMES)
 
 def committed_traffic(workload, kernel_substr):
     """HBM bytes per dispatch from the committed PMC passes of this command (profiles/rNN_pmc_traffic.json), or None."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         # (the PMC passes of the bench default, and -- per workload -- of `--workload <name>`)
         fname = f"{tag}_pmc_traffic.json" if workload == PRIMARY else f"{tag}_{workload}_pmc_traffic.json"
         tpath = os.path.join(REPO, "profiles", fname)
@@ -342,7 +343,17 @@ def live_products(leg, ops, _lib):
     return live, total
 
 
-def roofline_fused(g, workload, entry, live=None, pieces=2, products=3):
+ARITHMETIC = {
+    2: ("fp16x2", 2, 3, "two fp16 pieces per operand with a power-of-two scale, three MFMA products (v_mfma_f32_32x32x16_f16), fp32 "
+                        "accumulation: 1e-7 ... 3e-7 normwise against float64, the error of an fp32 sgemm on the same operands "
+                        "(tests/test_pipe_frame.py, tests/test_fused_frame.py) -- the arithmetic width of the reference's nn.Linear"),
+    3: ("bf16x2", 2, 3, "two bf16 pieces per operand, three MFMA products: 16-bit operands, ~2e-6 ... 4e-6 normwise (inside the path's "
+                        "tolerance, NARROWER than the reference's fp32 product)"),
+    6: ("bf16x3", 3, 6, "three bf16 pieces per operand, six MFMA products: sgemm-class at twice the matrix work"),
+}
+
+
+def roofline_fused(g, workload, entry, live=None, terms=2):
     """Roofline of the fused pooling + collapse kernel (the bound becomes the matrix pipe).  One launch
     covers every (view, scale, layer) of the frame (or of one band of grid rows).  `achieved` = the bf16 MFMA flops the
     kernel ISSUES per launch / mean launch time: `products` bf16 products (3 of a two-piece split, 6 of a three-piece split)
@@ -366,24 +377,25 @@ def roofline_fused(g, workload, entry, live=None, pieces=2, products=3):
     g = dict(g, launches=frames)
     avg_s = g["ms"] / g["launches"] * 1e-3
     per_launch = ref_flops / g["launches"]
+    label, pieces, products, _ = ARITHMETIC[terms]
     live_frac = (live[0] / live[1]) if live and live[1] else 1.0
     issued = products * per_launch * live_frac
     achieved = issued / avg_s / 1e12
-    kname = ("pipe_kernel<%d, false> (persistent; 8 matrix waves + 4 pooling waves per CU: box pooling from LDS tap windows beside "
-             "the bf16-split MFMA collapse of the previous 64 rows x 64 channels; accumulators of four views in registers across "
-             "all z-layers; bias + ReLU + view / scale sum)" % (6 if products == 6 else 3)) if pipe else \
-            ("pool_collapse_kernel<3, false, false> (persistent, one launch per frame: box pooling of all views x scales from LDS "
-             "tap windows -> bf16-split MFMA collapse -> bias + ReLU + view / scale sum); the HIP events bracket the call that "
+    waves = "8 matrix waves + 4 pooling waves" if terms == 6 else "8 matrix waves + 8 pooling waves"
+    kname = (f"pipe_kernel<{terms}, false> (persistent; {waves} per CU: box pooling from LDS tap windows beside the {label}-split MFMA "
+             "collapse of the previous 64 rows x 64 channels; accumulators of four views in registers across all z-layers; bias + "
+             "ReLU + view / scale sum)") if pipe else \
+            (f"pool_collapse_kernel<{terms}, false, false> (persistent, one launch per frame: box pooling of all views x scales from LDS "
+             f"tap windows -> {label}-split MFMA collapse -> bias + ReLU + view / scale sum); the HIP events bracket the call that "
              "launches it (+ the empty launch for direct items without a row slot, ~5 us); its pre-pass pool_rows_kernel (the 4 % "
              "of items whose window exceeds LDS, ~28 us) is a separate, untimed call of the entry point")
-    traffic, src = committed_traffic(workload, "pipe_kernel<3, false>" if pipe else "pool_collapse_kernel<3, false, false>")
-    if products == 6:
-        traffic, src = None, None
+    traffic, src = committed_traffic(workload, f"pipe_kernel<{terms}, false>" if pipe else f"pool_collapse_kernel<{terms}, false, false>")
     return {"bound": "mfma", "kernel": entry + ": " + kname, "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note(src),
             "avg_launch_us": avg_s * 1e6, "mfma_flops_per_launch": issued,
-            "flops_note": f"{products} bf16 products per fp32 product ({pieces}-piece split) x the {live_frac:.3f} of the 32-row items "
-                          "that have a live box (the kernel skips the rest)",
+            "arithmetic": label,
+            "flops_note": f"{products} 16-bit MFMA products per fp32 product ({pieces}-piece {label[:4]} split; fp16 and bf16 MFMA have the same "
+                          f"dense peak) x the {live_frac:.3f} of the 32-row items that have a live box (the kernel skips the rest)",
             "fp32_flops_per_launch": per_launch, "fp32_equivalent_tflops": per_launch / avg_s / 1e12,
             "fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TFLOPS, "frac_of_fp32_mfma_peak": per_launch / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             "hbm_algorithmic_bytes_per_launch": bytes_alg / g["launches"],
@@ -391,14 +403,28 @@ def roofline_fused(g, workload, entry, live=None, pieces=2, products=3):
             "launches": g["launches"]}
 
 
-def roofline_of(ks, ops, workload, live=None, products=3):
+def roofline_integral(g):
+    """The integral-image entry point (HBM-bound): algorithmic bytes = every feature map read once + every
+    zero-bordered integral image written once, over the mean time of the call (HIP events on the launch stream)."""
+    alg = 0.0
+    for (nv, C, sizes, _affine), rec in g["by_tag"].items():
+        alg += rec["launches"] * sum(nv * C * h * w * 4 + nv * C * (h + 2) * (w + 2) * 4 for h, w in sizes)
+    avg_s = g["ms"] / g["launches"] * 1e-3
+    per = alg / g["launches"]
+    return {"bound": "hbm", "kernel": "vfa_integral_images_f32: integral_onepass_kernel (both cumsums of a (view, 16-channel block, column "
+            "part) in one workgroup; one launch for the three maps of the frame)", "achieved": per / avg_s / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": per / avg_s / 1e9 / HBM_PEAK_GBS, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": per,
+            "launches": g["launches"], "traffic": None}
+
+
+def roofline_of(ks, ops, workload, live=None, terms=2):
     """Roofline of the dominant kernel of the step.  Fused path: see `roofline_fused`.  Unfused paths: the pooling kernel
     (HBM-bound by SURVEY.md 8d): algorithmic bytes of one launch = integral images read once + voxel features written once
     + grid + calibs; achieved = those bytes / mean launch time from HIP events recorded on the launch stream inside the
     timed loop."""
     for entry in ("vfa_pipe_collapse_relu_sum_f32", "vfa_pool_collapse_relu_sum_f32"):
         if ks.get(entry, {}).get("launches"):
-            return roofline_fused(ks[entry], workload, entry, live, 3 if products == 6 else 2, products)
+            return roofline_fused(ks[entry], workload, entry, live, terms)
     entry = "vfa_pool_windows_f32" if ks.get("vfa_pool_windows_f32", {}).get("launches") else "vfa_project_gather_f32"
     g = ks.get(entry, dict(launches=0, ms=0.0, by_tag={}))
     if not g["launches"]:
@@ -482,21 +508,25 @@ def main():
     # (a sampled launch costs two event records in the queue and two event creations on the host: every 4th launch, and the
     # K-step block is repeated until >= 100 ms are timed, so also the driver's 20-step run collects >= 10 samples)
     min_ms = 100.0 if a.steps > 0 else 0.0
-    kt = ops.KernelTimer(only=ROOFLINE_ENTRY_POINTS, every=4 if a.steps >= 8 else 1)
+    # (every entry point of the step is sampled in the TIMED blocks -- every 4th launch of each: the `kernels` table and both
+    # rooflines come from the region `value` is measured in, not from the warm-up)
+    kt = ops.KernelTimer(every=4 if a.steps >= 8 else 1)
     dt = leg.timed(a.steps, kt, lead_in=conditioning, min_ms=min_ms)
     timing = leg.block_stats(a.steps)
     ks = kt.summary()
     live = live_products(leg, ops, _lib)
-    roofline = roofline_of(ks, ops, a.workload, live)
+    primary_terms = 2 if vfa_op.COLLAPSE_TERMS in (0, 2) or (leg.nl == 1 and vfa_op.COLLAPSE_TERMS == 6) else vfa_op.COLLAPSE_TERMS
+    roofline = roofline_of(ks, ops, a.workload, live, terms=primary_terms)
     if roofline is not None:
         roofline["sampled"] = (f"HIP events around every {kt.every}th launch of the timed region ({roofline['launches']} samples over "
                                f"{timing['blocks']} blocks of {a.steps} steps)")
-    ks_all = kt_warm.summary() if a.warmup > 0 else ks
+    integral_roofline = roofline_integral(ks["vfa_integral_images_f32"]) if ks.get("vfa_integral_images_f32", {}).get("launches") else None
+    ks_all = ks if ks else kt_warm.summary()
     def calls_per_frame(v):  # (the fused entry point is called twice per frame: "rows" pre-pass + the rest; count frames)
         rows = sum(r["launches"] for t, r in v["by_tag"].items() if isinstance(t, tuple) and t and t[-1] == "rows")
         return max(v["launches"] - rows, 1)
     kernels = {k: {"launches": calls_per_frame(v), "avg_us": 1e3 * v["ms"] / calls_per_frame(v)} for k, v in ks_all.items()}
-    hip_ms = sum(v["ms"] for v in ks_all.values()) / max(a.warmup, 1)
+    hip_ms = sum(v["ms"] / max(calls_per_frame(v), 1) for v in ks_all.values())  # (mean time per call, summed over the entry points of a frame)
     n, L, W, nl, C = len(leg.cams), leg.L, leg.W, leg.nl, a.channels
     gemm_flops = 3 * 2.0 * n * L * W * (C * nl) * C
 
@@ -528,29 +558,51 @@ def main():
             vfa_op.COLLAPSE_KERNEL = saved
         extra["collapse_fp32_ms_per_step"] = 1e3 * dtf / a.fp32_steps
         extra["collapse_fp32_value"] = leg.units_step * a.fp32_steps / dtf
-    # ---- the pipelined kernel (vfa_pipe.hip) on this workload: as it is used on multi-layer grids (three products of a
-    # two-piece split), and with THREE bf16 pieces per operand / six products: the collapse product at the arithmetic width of
-    # the reference's fp32 nn.Linear (<= 5e-7 normwise against float64), fused like the default -- each with its own roofline
+    # ---- the same frame through the other fused forms, each with its own roofline: the pipelined kernel (vfa_pipe.hip: the kernel of
+    # multi-layer grids) in the default arithmetic; the NARROWER two-piece bf16 product that was the default until round 3
+    # (`bf16x2_16bit`: not a creditable figure for the reference's fp32 path); three bf16 pieces / six products (pipelined kernel)
     if a.fp32_steps > 0 and a.channels == 256 and len(leg.cams) > 0 and vfa_op.COLLAPSE_KERNEL != "library":
         saved = (vfa_op.PIPE, vfa_op.PIPE_SINGLE_LAYER, vfa_op.COLLAPSE_TERMS)
         try:
-            for key, terms in (("pipelined_kernel", 3), ("fused_fp32_equiv", 6)):
-                vfa_op.PIPE, vfa_op.PIPE_SINGLE_LAYER, vfa_op.COLLAPSE_TERMS = True, True, terms
+            for key, single, terms in (("pipelined_kernel", True, 2), ("bf16x2_16bit", False, 3), ("bf16x3_six_products", True, 6)):
+                vfa_op.PIPE, vfa_op.PIPE_SINGLE_LAYER, vfa_op.COLLAPSE_TERMS = True, single, terms
                 if key == "pipelined_kernel" and roofline is not None and "vfa_pipe_" in roofline["kernel"]:
                     continue  # (the primary leg already ran this kernel)
                 for _ in range(3):
                     leg.step()
                 ktp = ops.KernelTimer(only=ROOFLINE_ENTRY_POINTS, every=4)
                 dtp = leg.timed(a.fp32_steps, ktp, lead_in=conditioning // 3, min_ms=min_ms)
-                rp = roofline_of(ktp.summary(), ops, a.workload, live, products=6 if terms == 6 else 3)
+                rp = roofline_of(ktp.summary(), ops, a.workload, live, terms=terms)
                 extra[key + "_ms_per_step"] = 1e3 * dtp / a.fp32_steps
                 extra[key] = {"ms_per_step": 1e3 * dtp / a.fp32_steps, "value": leg.units_step * a.fp32_steps / dtp,
-                              "timing": leg.block_stats(a.fp32_steps), "roofline": rp,
-                              "arithmetic": ("three bf16 pieces per operand (x = p0 + p1 + p2 to 2^-25), six MFMA products, fp32 accumulation: "
-                                             "1e-7 ... 3e-7 normwise against float64 (tests/test_pipe_frame.py), the class of an fp32 sgemm")
-                              if terms == 6 else "two bf16 pieces per operand, three MFMA products (the default arithmetic)"}
+                              "timing": leg.block_stats(a.fp32_steps), "roofline": rp, "arithmetic": ARITHMETIC[terms][3]}
         finally:
             vfa_op.PIPE, vfa_op.PIPE_SINGLE_LAYER, vfa_op.COLLAPSE_TERMS = saved
+    # ---- what ONE RANK of an N-GPU camera-sharded run computes per frame, measured on this one GPU (no collective): the cameras
+    # `camera_shard(n, 0, N)` gives rank 0, for N = 2, 4, 8, on this workload and on BASELINE.json configs[4].  A PROJECTION of the
+    # per-rank compute time -- the scaling curve itself needs the node (the driver's SCALE run)
+    if a.proxy_steps > 0 and world == 1 and a.channels == 256 and a.workload == PRIMARY:
+        proxy = {}
+        for wname, steps in ((a.workload, a.proxy_steps), (C5, max(1, a.proxy_steps // 10)) if a.c5_steps > 0 else (None, 0)):
+            if wname is None:
+                continue
+            per = {}
+            full = None
+            for nranks in (1, 2, 4, 8):
+                lg = Leg(wname, a, 0, nranks, dev, "strong")
+                lg.collective = False  # (rank 0's share of the cameras; nothing to reduce with on one GPU)
+                lg.world = 1
+                lg.step()
+                t = lg.timed(steps, lead_in=conditioning // 3 if wname == a.workload else 1, min_ms=min_ms if wname == a.workload else 0.0)
+                ms = 1e3 * t / steps
+                full = ms if nranks == 1 else full
+                per[str(nranks)] = {"cameras_of_rank0": len(lg.cams), "ms_per_frame": ms,
+                                    "vs_full_rig_share": ms / (full * len(lg.cams) / lg.n_frame) if full and lg.cams else None}
+                del lg
+            proxy[wname] = per
+        extra["per_rank_proxy"] = dict(proxy, note="one GPU, rank 0's cameras of an N-rank camera-sharded frame, no collective: ms_per_frame "
+                                       "and its ratio to (time of the full rig on one GPU) x (share of the cameras); a projection of the "
+                                       "per-rank compute time, NOT a scaling measurement")
     # ---- the producer in front of the path, NOT part of `value` (the path starts at lateral maps resident in HBM):
     # trunk outputs -> the three integral images through the hand-written lateral branch (fp32-MFMA 1x1 convolution, channels-last,
     # GroupNorm statistics in its epilogue; affine + ReLU inside the row scan) and through the library's operations
@@ -635,11 +687,12 @@ def main():
         us = 1e3 * fk["ms"] / fk["launches"]
         collapse_info = {"flops_per_step": gemm_flops, "backend": "fused into " + ("vfa_pool_collapse_relu_sum_f32" if "vfa_pool_collapse_relu_sum_f32" in ks_all
                                                                     else "vfa_pipe_collapse_relu_sum_f32") + " (pooled rows go "
-                         "from registers to LDS bf16 hi/lo planes to 3xbf16-split MFMA, fp32 accumulate; bias + ReLU + "
+                         "from registers to LDS fp16 hi/lo planes to the three-product fp16-split MFMA, fp32 accumulate; bias + ReLU + "
                          "view/scale sum in the epilogue; the voxel features never reach HBM)", "avg_us": us,
                          "fp32_equivalent_tflops": gemm_flops / (us * 1e-6) / 1e12,
-                         "bf16_mfma_tflops": 3 * gemm_flops / (us * 1e-6) / 1e12,
-                         "max_rel_error_vs_fp64": "~3e-6 of max|out| (tests/test_fused_frame.py), tolerance 1e-5"}
+                         "mfma_16bit_tflops": 3 * gemm_flops / (us * 1e-6) / 1e12,
+                         "error_vs_fp64": "1e-7 ... 3e-7 normwise, at or below an fp32 library GEMM on the same voxel features "
+                                          "(tests/test_fused_frame.py, tests/test_pipe_frame.py); the path tolerates rtol 1e-4 / atol 1e-5 max"}
     elif ck and ck["launches"]:
         collapse_info = {"flops_per_step": gemm_flops, "backend": "vfa_collapse_relu_sum_f32 (3xbf16-split MFMA, fp32 "
                          "accumulate, fused bias+ReLU+view sum)", "avg_us": 1e3 * ck["ms"] / ck["launches"],
@@ -664,11 +717,12 @@ def main():
             "lead_in_frames": conditioning,  # untimed frames queued in front of the opening barrier + synchronize (clock ramp of an idle device)
             "ms_per_step": 1e3 * dt / a.steps, "timing": timing, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 in / out and fp32 accumulation everywhere; pre-GEMM stages bit-exact with the reference's CPU path; the "
-                          "collapse product forms each fp32 product from three bf16 MFMA products of a two-piece (16-bit) split of "
-                          "both operands (error ~3e-6 of max|out|, the path tolerates 1e-5); `fused_fp32_equiv` is the same fused "
-                          "step with a three-piece split / six products (sgemm-class, 1e-7 ... 3e-7 normwise), "
-                          "`collapse_fp32_ms_per_step` the unfused step with the fp32 library GEMM",
+            "dtype_note": "fp32 in / out, fp32 accumulation everywhere.  Pre-GEMM: the reference's exact fp32 rounding sequence (the fused "
+                          "kernels' pooled rows within 1 ulp of the reference's voxel features, 79-87 % identical: tests/test_fused_frame.py). "
+                          "The collapse product (reference: fp32 nn.Linear) = " + ARITHMETIC[primary_terms][3] + ".  Extra keys: "
+                          "`bf16x2_16bit` = the narrower two-piece bf16 product (the default until round 3; NOT reference width), "
+                          "`bf16x3_six_products` = three bf16 pieces, `collapse_fp32_ms_per_step` = the unfused step with the fp32 library GEMM",
+            "arithmetic": ARITHMETIC[primary_terms][0],
             "config": {"workload": a.workload, "cameras_per_rank": n,
                        "cameras_total": n * world if scaling == "weak" else leg.n_frame, "channels": C,
                        "feature_maps": [list(s) for s in leg.wl["feat_sizes"]], "grid": [L, W, nl],
@@ -681,9 +735,10 @@ def main():
                        **({"collective": leg.mode} if world > 1 else {})},
             "bev_cells_per_s": nl * L * W * a.steps / dt,
             "roofline": roofline,
+            "roofline_integral": integral_roofline,
             "kernels": kernels,
-            "kernels_note": f"HIP events around every entry point during the {a.warmup} warm-up steps; the timed steps "
-                            "time only the roofline kernel",
+            "kernels_note": f"mean time per call of every entry point of the step, from HIP events around every {kt.every}th call inside the "
+                            "TIMED blocks (the geometry calls run on a second stream beside the integral images)",
             "hip_kernel_ms_per_step": hip_ms,
             "collapse_gemm": collapse_info,
         }

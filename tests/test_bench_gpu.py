@@ -11,7 +11,7 @@ from conftest import REPO
 
 pytestmark = pytest.mark.gpu
 
-FAST = ["--steps", "3", "--warmup", "1", "--c5-steps", "0", "--cpu-seconds", "0", "--rotate", "0", "--fp32-steps", "0"]
+FAST = ["--steps", "3", "--warmup", "1", "--c5-steps", "0", "--cpu-seconds", "0", "--rotate", "0", "--fp32-steps", "0", "--proxy-steps", "0"]
 
 
 def _run(args, env=None, timeout=900):
@@ -38,7 +38,7 @@ def test_bench_spawns_its_own_ranks_and_shards_cameras():
     assert line["value"] > 0 and line["ms_per_step"] > 0
     mg = line["multi_gpu"]  # what the collective costs: compute-only time of the slowest rank, and the three collectives alone
     assert mg["ms_compute"] > 0 and mg["map_bytes"] == 200 * 200 * 256 * 4
-    assert set(mg["collective_alone_ms"]) == {"all_reduce", "reduce_to_rank0", "reduce_scatter_rows_halo4"}
+    assert set(mg["collective_alone_ms"]) == {"all_reduce", "reduce_to_rank0", "reduce_scatter_rows_halo7"}
 
 
 def test_bench_refuses_a_world_size_mismatch():
@@ -57,7 +57,7 @@ def test_two_rank_rccl_sum_matches_single_gpu():
 
 
 def test_bench_single_gpu_line_has_the_contract_fields():
-    p = _run(["--steps", "5", "--warmup", "2", "--c5-steps", "0", "--cpu-seconds", "2", "--rotate", "2", "--fp32-steps", "2"])
+    p = _run(["--steps", "5", "--warmup", "2", "--c5-steps", "0", "--cpu-seconds", "2", "--rotate", "2", "--fp32-steps", "2", "--proxy-steps", "2"])
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -72,9 +72,17 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     t = line["timing"]  # the K-step block is repeated until >= 100 ms are timed; the line carries the median block
     assert t["blocks"] >= 1 and t["timed_ms_total"] >= 100.0 and t["ms_per_step_min"] <= line["ms_per_step"] <= t["ms_per_step_max"]
     assert r["launches"] >= 10  # HIP-event samples of the roofline kernel
-    # the same fused step at the reference's arithmetic width (three bf16 pieces, six products), with its own roofline
-    f = line["fused_fp32_equiv"]
+    # the headline runs the reference-width product (two fp16 pieces, three products); the narrower bf16 form and the six-product
+    # form of the same fused step ride along, each with its own roofline
+    assert line["arithmetic"] == "fp16x2" and "pool_collapse_kernel<2" in r["kernel"] and r["arithmetic"] == "fp16x2"
+    f = line["bf16x3_six_products"]
     assert f["ms_per_step"] > 0 and f["roofline"]["bound"] == "mfma" and "pipe_kernel<6" in f["roofline"]["kernel"]
-    assert line["pipelined_kernel"]["roofline"]["frac"] > 0
+    assert "pool_collapse_kernel<3" in line["bf16x2_16bit"]["roofline"]["kernel"]
+    assert "pipe_kernel<2" in line["pipelined_kernel"]["roofline"]["kernel"] and line["pipelined_kernel"]["roofline"]["frac"] > 0
+    ri = line["roofline_integral"]
+    assert ri["bound"] == "hbm" and 0 < ri["frac"] < 1 and ri["launches"] >= 1
+    assert "vfa_integral_images_f32" in line["kernels"] and "vfa_frame_cuts_f32" in line["kernels"]
+    pr = line["per_rank_proxy"]["multiviewc_200x200x1"]
+    assert pr["8"]["cameras_of_rank0"] == 1 and pr["2"]["cameras_of_rank0"] == 4 and pr["1"]["ms_per_frame"] > pr["8"]["ms_per_frame"] > 0
     pf = line["producer_f3"]  # the producer in front of the path (f3): hand-written lateral branch against the library's operations
     assert 0 < pf["hand_written_ms_per_frame"] < pf["library_ms_per_frame"] and pf["cameras"] == 7

@@ -29,10 +29,10 @@ using namespace vfa_dev;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kCo = 256;        // output channels (the path's channel count)
-constexpr int kCoPad = kCo + 1;
 constexpr int kGroups = 16;     // GroupNorm(16, 256): 16 channels per group
 constexpr int kTilePx = 128;    // pixels per workgroup
-constexpr int kKc = 32;         // k per LDS chunk
+constexpr int kKc = 16;         // k per chunk (one v_mfma_f32_32x32x16_bf16 deep)
+constexpr int kMaxK = 1024;     // input channels the workspace has room for (ResNet laterals: 128, 256, 512)
 constexpr int kThreads = 256;
 
 struct LateralArgs {
@@ -41,27 +41,57 @@ struct LateralArgs {
     const float *bias;    // (256)
     float *out;           // (n_views, H * W, 256)
     double *partial;      // (n_views, 16 groups, parts, 2): sum, sum of squares of 32 pixels x 16 channels; parts = blocks * PXW
+    const uint4 *wfrag;   // the weight as three bf16 planes in MFMA fragment order (lateral_split_weight_kernel)
     int K, HW, blocks;
 };
 
+// The weight as three bf16 planes (x = p0 + p1 + p2, exact to 2^-25 |x|) in MFMA fragment order, once per call:
+//   frag[((chunk * 8 + cb) * 3 + plane) * 64 + lane] (16 B) = W[co = 32 cb + (lane & 31)][k = 16 chunk + 8 (lane >> 5) + j], j = 0..7
+__global__ __launch_bounds__(256) void lateral_split_weight_kernel(const float *__restrict__ w, uint4 *__restrict__ frag, int K)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x; // (chunk, cb, lane)
+    if (idx >= (K / 16) * 8 * 64) return;
+    const int lane = idx & 63, cb = (idx >> 6) & 7, chunk = idx >> 9;
+    const float *src = w + (size_t)(32 * cb + (lane & 31)) * K + 16 * chunk + 8 * (lane >> 5);
+    union { __bf16 b[8]; uint4 u; } p0, p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = src[j];
+        p0.b[j] = (__bf16)x;
+        const float r1 = x - (float)p0.b[j];
+        p1.b[j] = (__bf16)r1;
+        p2.b[j] = (__bf16)(r1 - (float)p1.b[j]);
+    }
+    uint4 *o = frag + (size_t)(chunk * 8 + cb) * 3 * 64 + lane;
+    o[0] = p0.u; o[64] = p1.u; o[128] = p2.u;
+}
+
 // PXW = 32-pixel blocks per workgroup (4, 2 or 1): wave w owns pixel block w % PXW and 8 PXW / 4 of the eight 32-channel
-// blocks.  PXW = 4: a wave holds all 256 channels of its pixels (the A operand is loaded once); the small maps of strides 16
+// blocks.  PXW = 4: a wave holds all 256 channels of its pixels (the pixel operand is loaded once); the small maps of strides 16
 // and 32 take 2 or 1 so that the launch still has a few hundred workgroups.
+//
+// Arithmetic (round 4): the fp32 product as SIX bf16 MFMA products of a three-piece split of both operands -- p0 p0, p0 p1, p1 p0,
+// p0 p2, p2 p0, p1 p1: everything down to 2^-16 of the largest, what is dropped is <= 2^-23 of a product (vfa_pipe.hip,
+// VFA_FLAG_TERMS 6; tests/test_split_arithmetic.py: <= 3e-8 normwise from the split) -- with fp32 accumulation: the class of an
+// sgemm, no scale needed (bf16 has fp32's exponent range), at 6 / 16 of the matrix-pipe time of v_mfma_f32_32x32x2_f32 (whose
+// 64 cycles per instruction left the three convolutions of a bench frame at 221 us against 75 us of pipe time and 28 us of HBM
+// time).  The pixel operand is split in registers as it arrives; the weight planes come pre-split (lateral_split_weight_kernel)
+// through LDS, one 16-k chunk (24 KB) ahead.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kChunkK = 16;                    // k per MFMA (v_mfma_f32_32x32x16_bf16)
+constexpr int kFragChunk = 8 * 3 * 64;         // uint4 per 16-k chunk of the split weight: 8 channel blocks x 3 planes x 64 lanes
 template <int PXW>
 __global__ __launch_bounds__(kThreads, 2) void lateral_conv_kernel(LateralArgs a)
 {
     constexpr int CBW = 8 * PXW / 4; // channel blocks per wave: 8, 4, 2
-    __shared__ float s_w[2][kKc][kCoPad]; // [buffer][k][co]: 64.25 KB (rows padded by one bank: the transposing stores)
+    constexpr int D = CBW >= 4 ? 4 : 2; // weight fragments are requested D channel blocks ahead of the products that take them
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int col = lane & 31, kh = lane >> 5;
+    const int col = lane & 31, kg = lane >> 5;
     const int v = blockIdx.y, blk = blockIdx.x;
     const int pbw = wave % PXW, cb0 = (wave / PXW) * CBW;
     const int p0 = (blk * PXW + pbw) * 32;
     const int px = min(p0 + col, a.HW - 1); // (tail: a clamped pixel is computed and thrown away)
-    const float *src = a.feat + (size_t)v * a.K * a.HW + px;
-    // weight staging: eight lanes read one 128-byte piece of a weight row (32 k of one output channel), a wave eight rows
-    const int wk = (tid & 7) * 4, wco = tid >> 3; // k offset inside the chunk, output channel 32 j + wco
-    const float *wrow = a.weight + (size_t)wco * a.K + wk;
+    const float *src = a.feat + (size_t)v * a.K * a.HW + (size_t)(8 * kg) * a.HW + px;
 
     f32x16 acc[CBW];
 #pragma unroll
@@ -69,68 +99,78 @@ __global__ __launch_bounds__(kThreads, 2) void lateral_conv_kernel(LateralArgs a
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[cb][i] = 0.0f;
 
-    float4 wreg[8];
-    float areg[16], anext[16];
-    auto load_w = [&](int k0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wreg[j] = *reinterpret_cast<const float4 *>(wrow + (size_t)(32 * j) * a.K + k0);
+    // No LDS and no workgroup barrier: every wave streams the pre-split weight fragments it needs straight from L2 (fragment
+    // order: one coalesced 1 KiB load per (channel block, plane); the four waves of a workgroup ask for the same lines within a few
+    // hundred cycles, so most of it is a vector-L1 hit) and the pixel operand from HBM, two chunks ahead.  (Staged through LDS with
+    // a barrier per 16-k chunk the small maps -- 12 or 24 MFMAs per wave and chunk -- spent their time at the barrier: 79 and 91 us
+    // for the stride-32 / stride-16 maps of the bench frame.)
+    const int chunks = a.K / kChunkK;
+    const bf16x8 *wbase = reinterpret_cast<const bf16x8 *>(a.wfrag) + (size_t)cb0 * 3 * 64 + lane;
+    bf16x8 fr[D][3];
+    auto load_frag = [&](int slot, int c, int cb) { // fragments of channel block cb0 + cb of chunk c (clamped: the last ones are re-read, unused)
+        const bf16x8 *p = wbase + (size_t)min(c, chunks - 1) * kFragChunk + cb * 192;
+        fr[slot][0] = p[0]; fr[slot][1] = p[64]; fr[slot][2] = p[128];
     };
-    auto store_w = [&](int buf) {
+    constexpr int AD = 2;              // the pixel operand is requested AD chunks ahead (4: 256 registers and spills at PXW = 4, no faster)
+    float an[AD][8];                   // the pixel operand of chunks c + 1 .. c + AD, on their way from HBM (ring: chunk c + 1 + d in slot (c + d) % AD)
+    bf16x8 a0, a1, a2;                 // ... and of chunk c, split: lane (pixel col, k group kg), k = 8 kg + j
+    auto load_a = [&](float (&dst)[8], int c) {
+        const int cc = min(c, chunks - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = src[(size_t)(cc * kChunkK + j) * a.HW];
+    };
+    auto split_a = [&](const float (&x)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            s_w[buf][wk + 0][32 * j + wco] = wreg[j].x; s_w[buf][wk + 1][32 * j + wco] = wreg[j].y;
-            s_w[buf][wk + 2][32 * j + wco] = wreg[j].z; s_w[buf][wk + 3][32 * j + wco] = wreg[j].w;
+            const __bf16 q0 = (__bf16)x[j];
+            const float r1 = x[j] - (float)q0;
+            const __bf16 q1 = (__bf16)r1;
+            a0[j] = q0; a1[j] = q1; a2[j] = (__bf16)(r1 - (float)q1);
         }
     };
-    auto load_a = [&](float *dst, int k0) {
+    load_a(an[AD - 1], 0);
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) dst[kk] = src[(size_t)(k0 + 2 * kk + kh) * a.HW];
-    };
-
-    const int chunks = a.K / kKc;
-    load_w(0);
-    load_a(areg, 0);
-    store_w(0);
-    __syncthreads();
-    for (int c = 0; c < chunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < chunks) { // the next chunk's operands: requested now, used after this chunk's MFMAs
-            load_w((c + 1) * kKc);
-            load_a(anext, (c + 1) * kKc);
+    for (int d = 0; d < AD - 1; ++d) load_a(an[d], 1 + d);
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_frag(d, 0, d);
+    split_a(an[AD - 1]);
+    load_a(an[AD - 1], AD);
+    // (chunks = K / 16 is a multiple of AD for K = 128, 256, 512: the ring position is a compile-time fact of the unrolled body)
+    for (int c4 = 0; c4 < chunks; c4 += AD) {
+#pragma unroll
+      for (int ci = 0; ci < AD; ++ci) {
+        const int c = c4 + ci;
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+            const bf16x8 w0 = fr[cb % D][0], w1 = fr[cb % D][1], w2 = fr[cb % D][2];
+            // the fragments D blocks ahead (of this chunk or of the next one) into the registers just read
+            if (cb + D < CBW) load_frag(cb % D, c, cb + D);
+            else load_frag(cb % D, c + 1, cb + D - CBW);
+            // D[channel][pixel]: the weight is the row operand; small terms first
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a2, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a0, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, acc[cb], 0, 0, 0);
         }
-        // B operands one k pair ahead of the MFMAs that take them (an LDS round trip in front of every pair of MFMAs otherwise)
-        const float *wl = &s_w[buf][kh][cb0 * 32 + col];
-        float bcur[CBW], bnxt[CBW];
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb) bcur[cb] = wl[cb * 32];
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            if (kk + 1 < 16) {
-#pragma unroll
-                for (int cb = 0; cb < CBW; ++cb) bnxt[cb] = wl[(2 * (kk + 1)) * kCoPad + cb * 32];
-            }
-            __builtin_amdgcn_sched_barrier(0); // (the scheduler otherwise sinks every read to just in front of its MFMA)
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bcur[cb], areg[kk], acc[cb], 0, 0, 0); // D[channel][pixel]
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cb = 0; cb < CBW; ++cb) bcur[cb] = bnxt[cb];
-        }
-        if (c + 1 < chunks) {
-            store_w(buf ^ 1); // (the buffer last read two chunks ago: every wave passed the barrier of chunk c - 1 since)
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) areg[kk] = anext[kk];
-        }
-        __syncthreads();
+        split_a(an[ci]);          // chunk c + 1 (requested AD chunks ago)
+        load_a(an[ci], c + 1 + AD); // ... and its slot takes chunk c + 1 + AD
+      }
     }
 
     // epilogue: + bias, channels-last store, GroupNorm partial sums (double: the variance is a difference of two of them).
-    // The weight is the MFMA's row operand, so lane (col, kh) holds PIXEL p0 + col and register i of block cb is channel
-    // 32 cb + (i & 3) + 8 (i >> 2) + 4 kh: four consecutive channels per i >> 2 -- one 16-byte store each (with the pixels as rows a
+    // The weight is the MFMA's row operand, so lane (col, kg) holds PIXEL p0 + col and register i of block cb is channel
+    // 32 cb + (i & 3) + 8 (i >> 2) + 4 kg: four consecutive channels per i >> 2 -- one 16-byte store each (with the pixels as rows a
     // lane held one channel of 16 pixels and stored 4 bytes at a time: 70 of the 255 us of the stride-8 map).
+    // Stores go through a wave-private LDS tile (32 pixels x 32 channels): straight from the accumulators a store instruction
+    // wrote 64 scattered 16-byte pieces (one per lane, 1 KiB apart) -- with the MFMAs switched off the stride-8 convolution of the
+    // bench frame still took 69 of its 94 us --; from the tile it writes the 128 contiguous bytes of eight pixels.
+    __shared__ float4 s_out[kThreads / 64][32 * 9]; // [wave][pixel][8 channel quads + 1 pad]
+    const int kh = kg;
     const int p = p0 + col;
     const bool on = p < a.HW;
-    float *orow = a.out + ((size_t)v * a.HW + (on ? p : 0)) * kCo;
+    float4 *tile = s_out[wave];
     const int parts = a.blocks * PXW;
 #pragma unroll
     for (int cbi = 0; cbi < CBW; ++cbi) {
@@ -142,12 +182,22 @@ __global__ __launch_bounds__(kThreads, 2) void lateral_conv_kernel(LateralArgs a
             const float4 bc = *reinterpret_cast<const float4 *>(a.bias + c);
             const float4 y = make_float4(acc[cbi][4 * g + 0] + bc.x, acc[cbi][4 * g + 1] + bc.y, acc[cbi][4 * g + 2] + bc.z,
                                          acc[cbi][4 * g + 3] + bc.w);
+            tile[col * 9 + 2 * g + kh] = y;
             if (on) {
-                *reinterpret_cast<float4 *>(orow + c) = y;
-                s1[g >> 1] += ((double)y.x + (double)y.y) + ((double)y.z + (double)y.w);
-                s2[g >> 1] += ((double)y.x * (double)y.x + (double)y.y * (double)y.y) + ((double)y.z * (double)y.z + (double)y.w * (double)y.w);
+                const double y0 = (double)y.x, y1 = (double)y.y, y2 = (double)y.z, y3 = (double)y.w;
+                s1[g >> 1] += (y0 + y1) + (y2 + y3);
+                s2[g >> 1] += __builtin_fma(y0, y0, y1 * y1) + __builtin_fma(y2, y2, y3 * y3);
             }
         }
+        // (one wave: LDS operations complete in order; the wait makes the tile visible to the reads below)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {
+            const int pl = 8 * r2 + (lane >> 3), q = lane & 7; // pixel of the block, channel quad
+            if (p0 + pl < a.HW)
+                *reinterpret_cast<float4 *>(a.out + ((size_t)v * a.HW + p0 + pl) * kCo + cb * 32 + 4 * q) = tile[pl * 9 + q];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the tile is overwritten by the next channel block)
         // over the wave's 32 pixels x 2 channel halves: a fixed butterfly
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -207,20 +257,21 @@ __global__ __launch_bounds__(kWave) void lateral_stats_kernel(FinalArgs a)
 
 extern "C" {
 
-// 32-pixel blocks per workgroup: the largest of 4, 2, 1 that still gives the launch two workgroups per CU
+// 32-pixel blocks per workgroup.  Measured on the three maps of the bench frame (rocprofv3, 7 cameras): stride 8 (K = 128) 79 / 68 /
+// 72 us at 4 / 2 / 1 blocks, strides 16 and 32 (K = 256, 512) 28-32 us at 1 block against 33-36 at 2: two blocks where that still
+// gives the launch a thousand workgroups (more waves per SIMD hide more than the pixel operand loaded twice costs), else one.
 static int blocks_per_workgroup(int n_views, int H, int W)
 {
     const long long px32 = ((long long)H * W + 31) / 32;
-    for (int pxw = 4; pxw > 1; pxw >>= 1)
-        if ((long long)n_views * ((px32 + pxw - 1) / pxw) >= 512) return pxw;
-    return 1;
+    return (long long)n_views * ((px32 + 1) / 2) >= 1024 ? 2 : 1;
 }
 
 size_t vfa_lateral_conv_workspace_bytes(int n_views, int H, int W)
 {
     if (n_views < 0 || H <= 0 || W <= 0) return 0;
     const size_t parts = ((size_t)H * W + 31) / 32 + 4; // (32-pixel blocks, rounded up to whole workgroups)
-    return (size_t)n_views * kGroups * parts * 2 * sizeof(double);
+    // GroupNorm partial sums + the split weight (three bf16 planes of up to kMaxK input channels)
+    return ((size_t)n_views * kGroups * parts * 2 * sizeof(double) + 255) / 256 * 256 + (size_t)kCo * kMaxK * 3 * 2;
 }
 
 int vfa_lateral_conv_f32(const float *feat, const float *weight, const float *bias, const float *gamma, const float *beta, float eps,
@@ -229,7 +280,7 @@ int vfa_lateral_conv_f32(const float *feat, const float *weight, const float *bi
 {
     if (!feat || !weight || !bias || !gamma || !beta || !out_hwc || !scale || !shift || n_views < 0 || K <= 0 || H <= 0 || W <= 0)
         return VFA_ERR_BAD_ARGUMENT;
-    if (K % kKc != 0 || ((reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(out_hwc)) & 15) != 0)
+    if (K % (2 * kKc) != 0 || K > kMaxK || ((reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(out_hwc)) & 15) != 0)
         return VFA_ERR_UNSUPPORTED; // (ResNet laterals: K = 128, 256, 512; 16-byte loads / stores)
     if (n_views == 0) return 0;
     if ((long long)H * W >= (1ll << 31) - kTilePx || n_views > 65535) return VFA_ERR_UNSUPPORTED;
@@ -240,6 +291,15 @@ int vfa_lateral_conv_f32(const float *feat, const float *weight, const float *bi
     LateralArgs a;
     a.feat = feat; a.weight = weight; a.bias = bias; a.out = out_hwc; a.partial = reinterpret_cast<double *>(workspace);
     a.K = K; a.HW = H * W; a.blocks = (a.HW + 32 * pxw - 1) / (32 * pxw);
+    {
+        const size_t parts = ((size_t)H * W + 31) / 32 + 4;
+        uint4 *frag = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(workspace) +
+                                                ((size_t)n_views * kGroups * parts * 2 * sizeof(double) + 255) / 256 * 256);
+        hipLaunchKernelGGL(lateral_split_weight_kernel, dim3((unsigned)((K / 16) * 8 * 64 + 255) / 256), dim3(256), 0, s, weight, frag, K);
+        const int e0 = (int)hipGetLastError();
+        if (e0) return e0;
+        a.wfrag = frag;
+    }
     const dim3 grid((unsigned)a.blocks, (unsigned)n_views);
     if (pxw == 4) hipLaunchKernelGGL(lateral_conv_kernel<4>, grid, dim3(kThreads), 0, s, a);
     else if (pxw == 2) hipLaunchKernelGGL(lateral_conv_kernel<2>, grid, dim3(kThreads), 0, s, a);
