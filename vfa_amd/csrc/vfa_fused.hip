@@ -1702,7 +1702,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
         ra.row_counter = a.row_counter;
         ra.rows = reinterpret_cast<float *>(const_cast<unsigned char *>(ws) + lay.rows);
         ra.n_tiles = lay.n_tiles; ra.rows_cap = rows_cap;
-        hipLaunchKernelGGL(pool_rows_kernel, dim3(1024), dim3(512), 0, s, ra);
+        hipLaunchKernelGGL(pool_rows_kernel, dim3(4096), dim3(512), 0, s, ra); // (a unit per block for up to 1024 direct items: a unit is a chain of dependent round trips)
         const int st0 = (int)hipGetLastError();
         if (st0 || (flags & VFA_FLAG_ROWS_ONLY)) return st0;
     }

@@ -505,7 +505,9 @@ static int integral_images_launch(const float *const *features, const float *con
     hipStream_t st = (hipStream_t)stream;
     // One pass (integral_onepass_kernel) wherever its tiling fits: 16-channel blocks, the column accumulators of a map in LDS
     // beside the tile, statistics entries for four row classes.  Otherwise the two-pass kernels (same bits).
-    bool onepass = !hwc && C % kOpCh == 0 && C % kWave == 0;
+    // (... and where there are units to fill the chip: a unit takes ~55 us on a 90 x 160 map however few there are -- one camera of
+    // the bench rig: 32 + 16 + 16 units -- while the two-pass kernels scale down with the bytes)
+    bool onepass = !hwc && C % kOpCh == 0 && C % kWave == 0 && (long long)n_views * (C / kOpCh) >= 64;
     int w_max = 0;
     for (int s = 0; s < n_maps && onepass; ++s) {
         onepass = a.m[s].H >= 8 && a.m[s].W >= 4 && (size_t)kOpRows * kOpRowPitch * 4 + (size_t)a.m[s].W * kOpCh * 8 <= 160 * 1024 - 1024;
