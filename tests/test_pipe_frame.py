@@ -162,6 +162,46 @@ def test_pipe_multi_layer_vs_float64_and_the_vox_through_hbm_path(name, n_cam, c
     assert torch.equal(again, piped)
 
 
+@pytest.mark.parametrize("name,n_cam,crop,origin", [
+    ("multiviewc_156x156x5", 1, (40, 64), (60, 40)),      # one camera per rank: every group has ONE sub-tile
+    ("multiviewc_156x156x5", 2, (37, 53), (10, 100)),     # two cameras, ragged grid: groups of one and of two views
+    ("multiviewc_200x200x1", 2, None, None),              # single layer, 1250 tiles, tiles cut between workgroups
+    ("wildtrack_120x360x8", 2, (24, 96), (50, 130)),      # eight layers, many masked boxes
+])
+def test_four_step_phase_of_one_and_two_view_frames_equals_the_eight_step_form(name, n_cam, crop, origin):
+    """A frame of at most two views (a rank's share of a camera-sharded rig) runs ``pipe_kernel<.., SMALL>``: four steps per phase, no
+    empty set-1 steps.  Same pooling, same product sequence, same association of the view sum as the eight-step form -- which the
+    diagnostic build still runs (VFA_FLAG_DEBUG 8: "no wave priorities", nothing else) --: bit for bit the same map."""
+    from vfa_amd import _lib, ops
+    dev = _dev()
+    wl, grid, lats, calibs = _frame(name, n_cam, crop, dev, origin=origin or (11, 5))
+    mods = _mods(wl, dev)
+    nl = mods[0].num_grid_layer
+    L, W = grid.shape[1:3]
+    zl, co = mods[0]._kernel_geometry(dev)
+    with torch.no_grad():
+        integrals = ops.integral_images(lats)
+        ws = ops.pipe_records(calibs, grid, zl, co, _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1],
+                              [tuple(l.shape[-2:]) for l in lats], weights=[m.collapse.weight for m in mods])
+        biases = [m.collapse.bias for m in mods]
+        with ops.KernelTimer() as kt:
+            small = ops.pipe_collapse(integrals, biases, ws, (L, W), nl, absmax=integrals.absmax)
+        eight = ops.pipe_collapse(integrals, biases, ws, (L, W), nl, absmax=integrals.absmax, debug=8)
+        small8 = ops.pipe_collapse(integrals, biases, ws, (L, W), nl, absmax=integrals.absmax, reserved_cus=248)
+        eight8 = ops.pipe_collapse(integrals, biases, ws, (L, W), nl, absmax=integrals.absmax, reserved_cus=248, debug=8)
+        bf = ops.pipe_collapse(integrals, biases, ops.pipe_records(
+            calibs, grid, zl, co, _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1], [tuple(l.shape[-2:]) for l in lats],
+            weights=[m.collapse.weight for m in mods], terms=3), (L, W), nl, terms=3)
+        want = _float64_reference(mods, lats, calibs, grid, wl)
+    torch.cuda.synchronize()
+    assert PIPE_ENTRY in kt.summary()
+    assert torch.isfinite(small).all() and small.abs().max() > 0
+    assert torch.equal(small, eight), (small - eight).abs().max().item()
+    assert torch.equal(small8, eight8), (small8 - eight8).abs().max().item()
+    _check(f"{name} x{nl}, {n_cam} views, four-step phase vs float64", small, want)
+    _check(f"{name} x{nl}, {n_cam} views, four-step phase (bf16 x 2) vs float64", bf, want)
+
+
 @pytest.mark.parametrize("data,image_size,cube,gh,world,step,cam", [
     ("MultiviewC", (720, 1280), (75.0, 75.0, 40), 160, (3750, 3750), (75.0, 75.0), "ring"),       # 4 layers
     ("MultiviewX", (1080, 1920), (8, 8, 16), 64, (640, 1000), (8, 8), "mx"),                        # 4 layers

@@ -116,6 +116,30 @@ with torch.no_grad():
             print(f"  wave {wave:2d}: barrier wait per workgroup by step position 0..7 (thousand cycles): "
                   + " ".join(f"{v / 1e3:.0f}" for v in d.mean(0)) + f" | total {d.sum(1).mean() / 1e3:.0f}")
 
+    if "--groups" in sys.argv:
+        # live views per (tile, scale), groups by size, steps by kind: what the step sequence of this frame is made of
+        host = ws.cpu().numpy()
+        live = [host[lay["live"][s]:lay["live"][s] + 4 * tiles].view(np.uint32) for s in range(3)]
+        hist = np.zeros(33, np.int64)
+        by_nj = np.zeros(5, np.int64)
+        for s in range(3):
+            pc = np.array([bin(int(m)).count("1") for m in live[s]])
+            hist += np.bincount(pc, minlength=33)[:33]
+            for c in pc:
+                full, rest = divmod(int(c), 4)
+                by_nj[4] += full
+                if rest:
+                    by_nj[rest] += 1
+        steps_full = by_nj[4] * 8 + by_nj[3] * 4
+        steps_half = by_nj[3] * 4
+        steps_small_full = by_nj[2] * 4
+        steps_small_half = by_nj[1] * 4
+        steps_empty = (by_nj[1] + by_nj[2]) * 4
+        print("  live views per (tile, scale): " + " ".join(f"{k}:{int(v)}" for k, v in enumerate(hist) if v))
+        print(f"  groups by views: 1:{by_nj[1]} 2:{by_nj[2]} 3:{by_nj[3]} 4:{by_nj[4]} | steps per layer: full {steps_full}, half (set 1 of three views) {steps_half}, "
+              f"set 0 of a two-view group {steps_small_full}, of a one-view group {steps_small_half}, empty {steps_empty} "
+              f"(empty share {steps_empty / max(1, steps_full + steps_half + steps_small_full + steps_small_half + steps_empty):.3f})")
+
     if "--fit" in sys.argv:
         # Per-workgroup cycles against what the workgroup had to do: the constants of the work-cut cost model (vfa_pipe_seq.h).
         ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws, terms=terms)

@@ -483,9 +483,16 @@ __device__ __forceinline__ void read_frags3(unsigned pa, bf16x8 &p0, bf16x8 &p1,
                  : "memory");
 }
 
-template <int TERMS, bool DIAG>
+// SMALL: a frame of at most TWO views (a rank's share of a camera-sharded rig): no group has a second set, so a phase is FOUR steps
+// -- one per channel quarter, all in the registers of set 0 -- instead of eight of which every other one is empty (a barrier, and the
+// exposed landing of the next step's windows: ~3 100 cycles).  The LDS buffers alternate by quarter, the weight slice is reloaded
+// behind every step.  Same arithmetic in the same order as the eight-step form.
+template <int TERMS, bool DIAG, bool SMALL = false>
 __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 {
+    static_assert(!SMALL || TERMS != 6, "the four-step phase exists in the sixteen-wave layout only");
+    constexpr int kPS = SMALL ? 4 : 8, kPSh = SMALL ? 2 : 3; // steps of a phase; step i: phase i >> kPSh, position i & (kPS - 1)
+    auto quarter_of = [](int k) { return SMALL ? k : k >> 1; }; // position k of a phase -> channel quarter (the LDS parity is k & 1 either way)
     // separate objects: one per role of the data (hipcc orders LDS-DMA against every LDS access it cannot prove disjoint)
     constexpr int kPieces = TERMS == 6 ? 3 : 2;                             // 16-bit pieces of an operand
     constexpr bool F16 = TERMS == 2;                                        // ... fp16 pieces with a scale (vfa_split.h) instead of bf16 ones
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         };
         // entry (k, x): {image address of (view, quarter), record address, flags | slots << 8, weight slice address (lanes x = 0)}
         auto make_desc = [&](int n) { // (table wave) lanes 0..15 = (step k, sub-tile x) of phase n
-            const int k = (lane >> 1) & 7, x = lane & 1, q = k >> 1, j = 2 * (k & 1) + x;
+            const int k = (lane >> 1) & (kPS - 1), x = lane & 1, q = quarter_of(k), j = SMALL ? x : 2 * (k & 1) + x;
             // the phase record and its scale constants in one round trip
             const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
             const uint4 c0 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][4]), c1 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][8]),
@@ -807,7 +814,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const unsigned long long wsl = ((unsigned long long)c1.y << 32 | c1.x) +
                                            (unsigned long long)(((unsigned)layer * 8u * kSteps + (unsigned)q * 4u) * (unsigned)kWPlanes * 64u) * 16u;
             const unsigned fw = j < nj ? ((flags & 0xffu) | (n_slots << 8)) : 0u;
-            if (lane < 16) {
+            if (lane < 2 * kPS) {
                 uint4 *d = reinterpret_cast<uint4 *>(&s_desc[n & 3][k][x][0]);
                 d[0] = make_uint4((unsigned)img, (unsigned)(img >> 32), (unsigned)rec, (unsigned)(rec >> 32));
                 d[1] = make_uint4(fw, (unsigned)wsl, (unsigned)(wsl >> 32), (unsigned)(Wf + 2) | ea64);
@@ -817,15 +824,15 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // the first sub-tile of the set, 4-7 for the second (the matrix waves are the longer role at four waves per SIMD: the fetch
         // cost each of them 1 500-2 400 cycles per step).  Addresses stay in vector registers (the same value in every lane).
         auto step_dma = [&](auto set_tag, int i) { // (set_tag: i & 1, a fact of the caller's position in the unrolled loop)
-            constexpr int DSET = decltype(set_tag)::value;
-            const int n = i >> 3, k = i & 7, x = dw >> 2, wq4 = dw & 3, j = 2 * DSET + x;
+            constexpr int DSET = SMALL ? 0 : decltype(set_tag)::value; // (the tag is the parity of i: the set, except in the four-step phase)
+            const int n = i >> kPSh, k = i & (kPS - 1), x = dw >> 2, wq4 = dw & 3, j = 2 * DSET + x;
             const uint4 *dp = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0]);
             const uint4 d0 = dp[0], d1 = dp[1];
             const uint4 *hp = reinterpret_cast<const uint4 *>(&s_hdr[n & 3][j * 8]);
             const uint4 h0 = hp[0], h1 = hp[1];
             const int fw = uniform_i((int)d1.x);
             if (!(fw & kTileLive)) return;
-            if ((k >> 1) == 0 && (wq4 == 0 || (wq4 == 1 && lane < 32))) { // (32 boxes x 48 bytes = a load and a half)
+            if (quarter_of(k) == 0 && (wq4 == 0 || (wq4 == 1 && lane < 32))) { // (32 boxes x 48 bytes = a load and a half)
                 const unsigned long long p = ((unsigned long long)d0.w << 32 | d0.z) + (unsigned)(wq4 * 1024 + lane * 16);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                                  (__attribute__((address_space(3))) void *)((DSET ? s_rec1 : s_rec0) + x * kTileBoxes * kRecBytes + wq4 * 1024), 16, 0, 0);
@@ -852,7 +859,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // (the slice address of the step sits in scalar registers -- the same for every lane --, the lane's part is one add)
         unsigned w_lo = 0, w_hi = 0;
         auto w_addr = [&](int i) {
-            const uint4 d1 = reinterpret_cast<const uint4 *>(&s_desc[(i >> 3) & 3][i & 7][0][0])[1];
+            const uint4 d1 = reinterpret_cast<const uint4 *>(&s_desc[(i >> kPSh) & 3][i & (kPS - 1)][0][0])[1];
             w_lo = (unsigned)uniform_i((int)d1.y); w_hi = (unsigned)uniform_i((int)d1.z);
         };
         auto w_load = [&](int ks) {
@@ -878,8 +885,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         };
         auto multiply = [&](auto set_tag, const PhaseRec &ph, int k, int par, bool next_chunk) {
             constexpr int SET = decltype(set_tag)::value;
-            constexpr bool reload = SET == 1;
-            const int q = k >> 1;
+            constexpr bool reload = SET == 1 || SMALL; // (four-step phase: every step ends its chunk)
+            const int q = quarter_of(k);
             const bool grp_first = ph.layer() == 0 && q == 0;
             if (q == 0) {
                 // The bias rides in the accumulator: at the first step of a group both accumulators of the set restart from it.  A
@@ -970,7 +977,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             tick(3);
             // A group of one or two views has nothing in set 1: that step is a barrier and little else, too short to cover a weight
             // load.  The next slice is then requested HERE, behind set 0 (whole, not interleaved: its registers are free now).
-            if (SET == 0 && ph.nj() <= 2 && next_chunk) {
+            if (!SMALL && SET == 0 && ph.nj() <= 2 && next_chunk) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) w_load(ks);
             }
@@ -983,6 +990,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         auto group_begin = [&](const PhaseRec &ph) {
             const float *slot = a.partial + (((size_t)lb * 3 + 2) * 8 + wave) * 16 * 64 + lane;
             const bool two = ph.nj() > 1;
+            if constexpr (SMALL) { // (the last step still adds to acc[0], acc[1]: the running sum waits in the unused registers of set 1)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[2][i] = slot[i * 64];
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float r0 = relu_t(acc[0][i]), r1 = relu_t(acc[1][i]);
@@ -995,6 +1007,22 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             float *slot = a.partial + (((size_t)lb * 3 + 2) * 8 + wave) * 16 * 64 + lane;
             const bool three = ph.nj() > 2, four = ph.nj() > 3, more = ph.more(), open = tile_open;
             const float inv = inv_of(ph.scale());
+            if constexpr (SMALL) { // tile = s + (r0 + r1): the association of the eight-step form for a group of one or two views
+                const bool two = ph.nj() > 1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float r0 = relu_t(acc[0][i]), r1 = relu_t(acc[1][i]);
+                    const float g = two ? r0 + r1 : r0;
+                    const float s0 = open ? acc[2][i] : 0.0f;
+                    if constexpr (F16) acc[0][i] = fmaf(g, inv, s0);
+                    else acc[0][i] = s0 + g;
+                }
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) slot[i * 64] = acc[0][i];
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float g = acc[0][i];
@@ -1047,13 +1075,15 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // the wave's 16 boxes x the 64 channels of quarter q: lane (box pb, piece pi) takes the 16-byte pieces
         // ((pb + m) & 3) * 4 + pi, m = 0..3, of its taps' quarter slots -- the four boxes of an LDS cycle read different 64-byte
         // quarters of the banks whatever slots they hold
-        auto pool = [&](auto glob_tag, const LaneBox &bx, int i, int x, int tile) {
+        // (m_first, m_count: the wave's 16-byte pieces of the quarter -- {mpar, mpar + mstep, ...}, or, in a set that has ONE sub-tile,
+        // a single piece: all eight pooling waves then share that sub-tile, see pool_step)
+        auto pool = [&](auto glob_tag, const LaneBox &bx, int i, int x, int tile, int m_first, int m_count) {
             constexpr bool GLOB = decltype(glob_tag)::value;
-            const int k = i & 7, set = k & 1;
+            const int k = i & (kPS - 1), set = k & 1; // (`set`: the parity of the step = its LDS buffers)
             const unsigned char *win = s_win + (set * 2 + x) * kWinBytes;
             const char *img = nullptr;
             if constexpr (GLOB) { // (image address of (view, quarter): descriptor of the step)
-                const uint4 d0 = reinterpret_cast<const uint4 *>(&s_desc[(i >> 3) & 3][k][x][0])[0];
+                const uint4 d0 = reinterpret_cast<const uint4 *>(&s_desc[(i >> kPSh) & 3][k][x][0])[0];
                 img = reinterpret_cast<const char *>((size_t)((unsigned long long)(unsigned)uniform_i((int)d0.y) << 32 | (unsigned)uniform_i((int)d0.x)));
             }
             const int row = x * 32 + phalf * 16 + pb;
@@ -1064,7 +1094,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             // scheduling barriers it needs keep the compiler from interleaving arithmetic and reads.
 #pragma unroll
             for (int mm = 0; mm < mcount; ++mm) {
-                const int m = mpar + mstep * mm; // (eight pooling waves: the partner wave, same boxes, takes the other two)
+                if (mm >= m_count) break; // (uniform)
+                const int m = m_first + mstep * mm; // (eight pooling waves: the partner wave, same boxes, takes the other two)
                 const unsigned piece = (unsigned)((pb + m) & 3);
                 const unsigned rot = piece << 6;
                 float4 lt, rb, rt, lb2;
@@ -1110,7 +1141,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     const int cl = tl * kTileL + (brow >> 3), cw = tw * kTileW + (brow & 7);
                     const float back = F16 ? pow2f(64 - (int)(s_sc[0][9] >> 16)) : 1.0f;
                     if (x == 0 && cl < a.L && cw < a.W)
-                        *reinterpret_cast<float4 *>(a.out + (size_t)(cl * a.W + cw) * kC + (k >> 1) * 64 + (int)piece * 16 + pi * 4) =
+                        *reinterpret_cast<float4 *>(a.out + (size_t)(cl * a.W + cw) * kC + quarter_of(k) * 64 + (int)piece * 16 + pi * 4) =
                             make_float4(xs[0] * back, xs[1] * back, xs[2] * back, xs[3] * back);
                 }
                 // x = hi + lo + r, |r| <= 2^-17 |x|: hi = RNE bf16(x), lo = RNE bf16(x - hi)
@@ -1134,22 +1165,28 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 if constexpr (TERMS == 6) *reinterpret_cast<uint2 *>(planes + 2 * kPlaneBytes + off) = lo2.u;
             }
         };
-        auto pool_step = [&](auto set_tag, int i, int tile) {
-            constexpr int SET = decltype(set_tag)::value;
-            const int n = i >> 3, k = i & 7, x = px;
+        // A set with ONE sub-tile (set 0 of a one-view group, set 1 of a three-view group: one step in five on a seven-camera rig): the
+        // waves that would pool the missing sub-tile take half of the pieces of the one there is -- wave (px, phalf, mpar) pools boxes
+        // phalf of sub-tile 0, piece mpar + 2 px --, so the step's pooling takes half the time instead of leaving four waves idle.
+        auto pool_step = [&](auto set_tag, int i, int tile, int nj) {
+            constexpr int SET = SMALL ? 0 : decltype(set_tag)::value; // (the tag is the parity of i)
+            const bool single = W16 && nj == 2 * SET + 1;
+            const int n = i >> kPSh, k = i & (kPS - 1), x = single ? 0 : px;
+            const int m_first = single ? mpar + 2 * px : mpar, m_count = single ? 1 : mcount;
             auto one = [&](LaneBox &bx, bool &glob, bool &live) { // (called with the registers of the step's set)
-                if ((k >> 1) == 0) { // first quarter of the layer: this wave's 16 boxes for the whole layer
+                if (quarter_of(k) == 0) { // first quarter of the layer: this wave's 16 boxes for the whole layer
                     const uint4 d1 = reinterpret_cast<const uint4 *>(&s_desc[n & 3][k][x][0])[1];
                     const int fw = uniform_i((int)d1.x);
                     live = (fw & kTileLive) != 0;
-                    if (live) live = unpack(set_tag, bx, glob, d1.w, x, (fw & kTileDirect) != 0);
+                    if (live) live = unpack(std::integral_constant<int, SET>{}, bx, glob, d1.w, x, (fw & kTileDirect) != 0);
                 }
                 if (!live) { // no live box in this layer (or no such sub-tile in the group): the matrix waves multiply zeros
                     const int row = x * 32 + phalf * 16 + pb;
-                    unsigned char *planes = s_planes + SET * kPieces * kPlaneBytes;
+                    unsigned char *planes = s_planes + (k & 1) * kPieces * kPlaneBytes;
 #pragma unroll
                     for (int mm = 0; mm < mcount; ++mm) {
-                        const int m = mpar + mstep * mm;
+                        if (mm >= m_count) break;
+                        const int m = m_first + mstep * mm;
                         const int off = (2 * m + (pi >> 1)) * kChunkStride + row * 16 + (pi & 1) * 8;
                         *reinterpret_cast<uint2 *>(planes + off) = make_uint2(0u, 0u);
                         *reinterpret_cast<uint2 *>(planes + kPlaneBytes + off) = make_uint2(0u, 0u);
@@ -1158,8 +1195,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     return;
                 }
                 if (DIAG && (a.debug & 2)) return;
-                if (glob) pool(std::true_type{}, bx, i, x, tile);
-                else pool(std::false_type{}, bx, i, x, tile);
+                if (glob) pool(std::true_type{}, bx, i, x, tile, m_first, m_count);
+                else pool(std::false_type{}, bx, i, x, tile, m_first, m_count);
             };
             if constexpr (SET == 0) one(boxA, globA, liveA);
             else one(boxB, globB, liveB);
@@ -1257,11 +1294,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         unsigned live = 2u | 4u;
         auto body = [&](auto pset_tag, int i) {
             constexpr int PSET = decltype(pset_tag)::value, MSET = PSET ^ 1;
-            const int m = i & 7;
+            const int m = i & (kPS - 1);
             dbg_pos = m;
             tick(0);
             if constexpr (POOL) {
-                if (m == 0 && i > 0) rec = phase_rec(i >> 3);
+                if (m == 0 && i > 0) rec = phase_rec(i >> kPSh);
                 // the next step's windows (and records) first, so that they land under this step's pooling
                 const bool bare = DIAG && (a.debug & 64); // (diagnostic 64: the loop, the tables and the barrier only)
                 // The tables of the next phase (see `tables and DMA`: steps 4, 5, 6 of this one), FIRST in the step: make_desc reads
@@ -1272,22 +1309,22 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 if (W16 && table_wave && m == 0) {
                     unsigned long long t_tab = 0;
                     if (DIAG && (a.debug & 32) && (a.debug & 16)) t_tab = __builtin_amdgcn_s_memtime();
-                    make_desc((i >> 3) + 1);
+                    make_desc((i >> kPSh) + 1);
                     if (DIAG && (a.debug & 32) && (a.debug & 16)) { // (diagnostic 32 + 16: the time of make_desc, in the upper bits of slot 0)
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         stamp[0] += (__builtin_amdgcn_s_memtime() - t_tab) << 24;
                     }
                 }
-                if (W16 && table_wave && m == 2) hdr_dma((i >> 3) + 2); // (first too: its 256 bytes land under the pooling)
+                if (W16 && table_wave && m == 2) hdr_dma((i >> kPSh) + 2); // (first too: its 256 bytes land under the pooling)
                 if (!dma_matrix && (live & 4u) && !bare) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
-                if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i, rec.tile);
+                if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i, rec.tile, rec.nj());
                 // The tables (see `tables and DMA`), a phase further ahead than on twelve waves and behind the pooling: the descriptors
                 // of phase n + 1 (~1 000 cycles; its headers were requested a phase ago) in the FIRST step of phase n, where the
                 // matrix waves end a group (relu, view sum, tile store) and the pooling waves wait longest at the barrier; the record
                 // of phase n + 2 (~550) and the request for its headers (~300) in the two steps behind.  In one step (any) the three
                 // together made every wave wait for the table wave.
                 if (W16 && table_wave) {
-                    if (m == 1) gen_phase((i >> 3) + 2);
+                    if (m == 1) gen_phase((i >> kPSh) + 2);
                 }
                 tick(1); // (pooling waves: slot 1 = requests + pooling, slot 2 = waiting for the next step's windows to land)
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1298,7 +1335,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 // of the first MFMA: a memory round trip per step
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 tick(1);
-                if (m == 1 && i > 1) rec = phase_rec((i - 1) >> 3);
+                if (m == 1 && i > 1) rec = phase_rec((i - 1) >> kPSh);
                 if (!W16 && table_wave) { // the tables of the next phase (see `tables and DMA`)
                     if (m == 4) gen_phase((i >> 3) + 1);
                     else if (m == 5) hdr_dma((i >> 3) + 1);
@@ -1329,10 +1366,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 const PhaseRec &pr = rec; // matrix waves: the record of step i - 1; pooling waves hold the record of step i
                 if constexpr (POOL) {
                     // the pooling waves only need to know whether the hand-off barriers of a SHARED tile are due
-                    if (__builtin_expect(((i - 1) & 7) == 7 && (live & 1u), 0)) {
-                        const PhaseRec prev = phase_rec((i - 1) >> 3);
+                    if (__builtin_expect(((i - 1) & (kPS - 1)) == kPS - 1 && (live & 1u), 0)) {
+                        const PhaseRec prev = phase_rec((i - 1) >> kPSh);
                         if (prev.layer() == a.nl - 1 && !prev.more()) {
-                            const PhaseRec nxt = phase_rec(((i - 1) >> 3) + 1);
+                            const PhaseRec nxt = phase_rec(((i - 1) >> kPSh) + 1);
                             finish_tile(prev.tile, nxt.valid() ? nxt.tile : t_end, acc[0]);
                         }
                     }
@@ -1353,7 +1390,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             if (DIAG && !(a.debug & 32)) stamp[7] += 1;
             // the step that enters at i + 2: a new phase when (i + 2) & 7 == 0 (its record was written at step 4 of this phase)
             unsigned next_live = (live >> 2) & 1u;
-            if (((i + 2) & 7) == 0 && next_live) next_live = uniform_i((int)s_phase[((i + 2) >> 3) & 3][0]) >= 0 ? 1u : 0u;
+            if (((i + 2) & (kPS - 1)) == 0 && next_live) next_live = uniform_i((int)s_phase[((i + 2) >> kPSh) & 3][0]) >= 0 ? 1u : 0u;
             live = (live >> 1) | (next_live << 2);
         };
         if constexpr (W16 && !POOL) {
@@ -1379,36 +1416,36 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             for (;;) {
                 PhaseRec nx = rec;
                 auto iter = [&](auto j_tag) {
-                    constexpr int J = decltype(j_tag)::value, SET = J & 1;
-                    dbg_pos = (J + 1) & 7;
+                    constexpr int J = decltype(j_tag)::value, SET = SMALL ? 0 : J & 1, PAR = J & 1;
+                    dbg_pos = (J + 1) & (kPS - 1);
                     tick(0);
                     __builtin_amdgcn_s_waitcnt(0x0f70); // the weight slice requested during the last step (see `body`)
                     tick(1);
                     // (the tables of the next phase are the last pooling wave's job in this layout: `body`)
-                    if constexpr (J == 6) nx = phase_rec(n + 1); // (written at J == 3, behind two barriers by now)
-                    const bool group_ends = J == 7 && rec.layer() == a.nl - 1;
+                    if constexpr (J == kPS - 2) nx = phase_rec(n + 1); // (written a phase ago)
+                    const bool group_ends = J == kPS - 1 && rec.layer() == a.nl - 1;
                     // the windows of step 8 n + J + 2 (the pooling waves are at 8 n + J + 1): the two matrix waves of a SIMD take
                     // their two jobs in opposite order (waves 0-3 request and then multiply, waves 4-7 multiply first)
-                    const bool dma_now = dma_matrix && (J < 6 || nx.valid()) && !(DIAG && (a.debug & 64));
-                    if (dma_now && wave < 4) step_dma(std::integral_constant<int, J & 1>{}, 8 * n + J + 2);
+                    const bool dma_now = dma_matrix && (J < kPS - 2 || nx.valid()) && !(DIAG && (a.debug & 64));
+                    if (dma_now && wave < 4) step_dma(std::integral_constant<int, J & 1>{}, kPS * n + J + 2);
                     if (!(DIAG && (a.debug & 64))) {
-                        if (J == 7 && group_ends) group_begin(rec);
+                        if (J == kPS - 1 && group_ends) group_begin(rec);
                         // the slice of the next chunk: behind the k-steps of set 1, or, when set 1 of the group is empty, already
                         // behind set 0; the chunk after quarter 3 is the next phase's first
                         bool next_chunk = false;
-                        if (SET == 1 || rec.nj() <= 2) {
-                            const int jn = SET == 1 ? J + 1 : J + 2; // first step of the next chunk
-                            if (jn < 8) { w_set(rec.scale(), rec.layer(), jn >> 1); next_chunk = true; }
+                        if (SMALL || SET == 1 || rec.nj() <= 2) {
+                            const int jn = (SMALL || SET == 1) ? J + 1 : J + 2; // first step of the next chunk
+                            if (jn < kPS) { w_set(rec.scale(), rec.layer(), quarter_of(jn)); next_chunk = true; }
                             else if (nx.valid()) { w_set(nx.scale(), nx.layer(), 0); next_chunk = true; }
                         }
-                        multiply(std::integral_constant<int, SET>{}, rec, J, SET, next_chunk);
-                        if (J == 7 && group_ends) group_end(rec);
+                        multiply(std::integral_constant<int, SET>{}, rec, J, PAR, next_chunk);
+                        if (J == kPS - 1 && group_ends) group_end(rec);
                     }
-                    if (dma_now && wave >= 4) step_dma(std::integral_constant<int, J & 1>{}, 8 * n + J + 2);
+                    if (dma_now && wave >= 4) step_dma(std::integral_constant<int, J & 1>{}, kPS * n + J + 2);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (dma_matrix) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (what this wave requested has landed)
                     tick(4);
-                    if constexpr (J == 7) {
+                    if constexpr (J == kPS - 1) {
                         if (__builtin_expect(group_ends, 0)) {
                             tile_open = rec.more();
                             if (!rec.more()) finish_tile(rec.tile, nx.valid() ? nx.tile : t_end, acc[0]);
@@ -1424,10 +1461,12 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 iter(std::integral_constant<int, 1>{});
                 iter(std::integral_constant<int, 2>{});
                 iter(std::integral_constant<int, 3>{});
-                iter(std::integral_constant<int, 4>{});
-                iter(std::integral_constant<int, 5>{});
-                iter(std::integral_constant<int, 6>{});
-                iter(std::integral_constant<int, 7>{});
+                if constexpr (!SMALL) {
+                    iter(std::integral_constant<int, 4>{});
+                    iter(std::integral_constant<int, 5>{});
+                    iter(std::integral_constant<int, 6>{});
+                    iter(std::integral_constant<int, 7>{});
+                }
                 if (!nx.valid()) break;
                 rec = nx;
                 ++n;
@@ -1804,8 +1843,12 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
         hipLaunchKernelGGL((pipe_kernel<4, false>), dim3(nblk), dim3(threads_of(4)), 0, s, a);
     else if (terms == 6)
         hipLaunchKernelGGL((pipe_kernel<6, false>), dim3(nblk), dim3(threads_of(6)), 0, s, a);
+    else if (terms == 3 && n_views <= 2)
+        hipLaunchKernelGGL((pipe_kernel<3, false, true>), dim3(nblk), dim3(threads_of(3)), 0, s, a);
     else if (terms == 3)
         hipLaunchKernelGGL((pipe_kernel<3, false>), dim3(nblk), dim3(threads_of(3)), 0, s, a);
+    else if (n_views <= 2) // (one or two views: the four-step phase)
+        hipLaunchKernelGGL((pipe_kernel<2, false, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     else
         hipLaunchKernelGGL((pipe_kernel<2, false>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     return (int)hipGetLastError();
