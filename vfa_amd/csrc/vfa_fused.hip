@@ -409,7 +409,7 @@ struct FusedArgs {
     float *out;                     // (L * W, 256)
     const int *chunk_start, *chunk_rank; // (kChunks + 1) each: tile_chunks_kernel
     float *partial;                 // (kMaxBlocks, 2) x 8 waves x 16 registers x 64 lanes: a workgroup's part of a tile it shares (first / last tile)
-    unsigned *tickets;              // (n_tiles): parts of a shared tile that have arrived (zeroed by the host call before every launch)
+    unsigned *tickets;              // (n_tiles): parts of a shared tile that have arrived (zero between launches: see layout_of)
     const float *rows;              // pooled rows of the direct items (pool_rows_kernel): slot x 32 boxes x 256 channels
     const unsigned *row_counter;    // direct items of the frame
     int rows_cap;                   // row slots in the workspace
@@ -913,6 +913,8 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                 const int first = at_begin ? sh_b_first : sh_e_first, last = at_begin ? sh_b_last : sh_e_last;
                 const int parts = at_begin ? sh_b_parts : sh_e_parts;
                 if (uniform_i((int)s_ticket) == parts - 1) {
+                    // (the last arriver: nobody else touches this ticket in this launch -- clear it for the next one)
+                    if (tid == 0) __hip_atomic_store(a.tickets + pend_tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     f32x16 tot;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
@@ -1396,6 +1398,10 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
         w.overflow[s] = off; off = align_up(off + (on ? (size_t)w.n_tiles * 4 : 0), 256);
     }
     w.counter = off; off += 256; // direct items numbered so far
+    // hand-off of tiles cut between workgroups of the persistent kernel: a ticket per tile (two 32 KiB parts per workgroup: `partial`).
+    // Zeroed with the masks by the geometry call; the workgroup that draws a tile's last ticket puts it back to zero, so every later
+    // call on the same workspace finds them clear without a memset of its own (two fill kernels, ~13 us, in front of every launch).
+    w.tickets = off; off = align_up(off + (size_t)w.n_tiles * sizeof(unsigned), 256);
     w.masks_bytes = off;
     for (int s = 0; s < kMaxScales; ++s) {
         const bool on = s < n_scales;
@@ -1407,8 +1413,6 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     off = align_up(off + (kChunks + 1) * sizeof(int), 256);
     w.ranks = off;
     off = align_up(off + (kChunks + 1) * sizeof(int), 256);
-    w.tickets = off; // hand-off of tiles cut between workgroups of the persistent kernel: a ticket per tile, two 32 KiB parts per workgroup
-    off = align_up(off + (size_t)w.n_tiles * sizeof(unsigned), 256);
     w.partial = off;
     off = align_up(off + (size_t)kMaxBlocks * 2 * 8 * 16 * 64 * sizeof(float), 256);
     w.diag = off;
@@ -1706,10 +1710,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
         const int st0 = (int)hipGetLastError();
         if (st0 || (flags & VFA_FLAG_ROWS_ONLY)) return st0;
     }
-    { // every call takes its own tickets (a second pass over the same workspace must not see the first one's)
-        const hipError_t e = hipMemsetAsync(a.tickets, 0, (size_t)lay.n_tiles * sizeof(unsigned), s);
-        if (e != hipSuccess) return (int)e;
-    }
+    // (the tickets are clear: zeroed by the geometry call, and put back by the last arriver of every earlier launch)
     if (debug & 64) { // diagnostic: only the second launch (direct items without a row slot)
         hipLaunchKernelGGL((pool_collapse_kernel<2, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
         return (int)hipGetLastError();

@@ -359,7 +359,7 @@ struct PipeArgs {
     float *out;                     // (L * W, 256)
     const int *chunk_start, *chunk_rank;
     float *partial;                 // (kMaxBlocks, 2) x 8 waves x 16 registers x 64 lanes: sums of a workgroup's part of a shared tile
-    unsigned *tickets;              // (n_tiles): parts of a shared tile that have arrived (zeroed by the geometry call)
+    unsigned *tickets;              // (n_tiles): parts of a shared tile that have arrived (zero between launches: the geometry call, then the last arriver)
     int accumulate;
     unsigned long long *diag;       // per workgroup 8 counters (VFA_FLAG_DEBUG)
     int debug;
@@ -1234,6 +1234,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 const bool am_last = uniform_i((int)s_misc[0]) == parts - 1;
                 if constexpr (!POOL) {
                     if (am_last) {
+                        // (nobody else touches this ticket in this launch: clear it for the next call on the same workspace)
+                        if (tid == 0) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         f32x16 tot;
 #pragma unroll
                         for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
@@ -1834,9 +1836,7 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
         const hipError_t e0 = hipMemsetAsync(out, 0, (size_t)L * W * kC * sizeof(float), s);
         if (e0 != hipSuccess) return (int)e0;
     }
-    // every call takes its own tickets: a second pass over the same workspace (accumulate) must not see the first one's
-    const hipError_t e = hipMemsetAsync(a.tickets, 0, (size_t)lay.n_tiles * 4, s);
-    if (e != hipSuccess) return (int)e;
+    // (the tickets are clear: zeroed with the masks by the geometry call, and put back by the last arriver of every earlier launch)
     if (debug) // (diagnostic build of the default arithmetic)
         hipLaunchKernelGGL((pipe_kernel<2, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     else if (terms == 4)
