@@ -172,7 +172,9 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
     with torch.no_grad():
         # geometry (camera + grid only) on a second HIP stream, beside the integral images (bandwidth-bound, feature maps only)
         cur = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if SIDE_STREAM and integrals is None else cur
+        # (inside a hipGraph capture the frame stays on ONE stream: a replayed graph pays more for its cross-stream edges than the
+        # overlap of geometry and integral images gives -- 0.44 against 0.20 ms per frame on a one-camera bench frame)
+        side = _side_stream(dev) if SIDE_STREAM and integrals is None and not torch.cuda.is_current_stream_capturing() else cur
         weights = [m.layer_major_weight() for m in mods]
         ws = torch.empty(max(_lib.lib().vfa_frame_workspace_bytes(calibs.shape[0], length, width, len(mods)), 1),
                          dtype=torch.uint8, device=dev)
@@ -271,7 +273,9 @@ def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumu
         rows = max(4, ((rows + 1) // 2 + 3) // 4 * 4)
     with torch.no_grad():
         cur = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if SIDE_STREAM and integrals is None else cur
+        # (inside a hipGraph capture the frame stays on ONE stream: a replayed graph pays more for its cross-stream edges than the
+        # overlap of geometry and integral images gives -- 0.44 against 0.20 ms per frame on a one-camera bench frame)
+        side = _side_stream(dev) if SIDE_STREAM and integrals is None and not torch.cuda.is_current_stream_capturing() else cur
         weights = [m.collapse.weight for m in mods]  # reference layout: the weight-split kernel reads column c * nl + layer
         biases = [m.collapse.bias for m in mods]
         band_rows = min(rows, length)
@@ -279,7 +283,7 @@ def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumu
         st = _pipe_state(dev, (n, length, width, band_rows, nl, ns, terms, int(reserved_cus), conv_kind, tuple(feat_hws)),
                          ops.pipe_workspace_bytes(n, band_rows, width, nl, ns), n_bands)
         ws = st["ws"]
-        balancing = PIPE_BALANCE and st["frames"] == 0
+        balancing = PIPE_BALANCE and st["frames"] == 0 and not torch.cuda.is_current_stream_capturing()  # (a one-off: never part of a graph)
         for b, r0 in enumerate(range(0, length, rows)):
             r1 = min(length, r0 + rows)
             band = grid[r0:r1]
@@ -326,6 +330,13 @@ def _pipe_state(dev, key, ws_bytes, n_bands):
     # previous frame's kernel on THIS stream is still reading (`side.wait_stream(cur)` only orders against the current one)
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream) + key
     st = _pipe_states.pop(key, None)
+    if st is None and torch.cuda.is_current_stream_capturing():
+        # A capture runs on a stream of its own: it takes over the workspace a warm-up frame of the same geometry left on another
+        # stream -- with its balanced shares; a fresh one would have the one-off balance kernel (milliseconds) captured into the graph
+        for k2 in list(_pipe_states):
+            if k2[0] == key[0] and k2[2:] == key[2:] and _pipe_states[k2]["frames"] > 0 and not _pipe_states[k2].get("pinned"):
+                st = _pipe_states.pop(k2)
+                break
     if st is None:
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
         lay = ops.pipe_workspace_layout(key[2], key[5], key[4], key[6], key[7])
