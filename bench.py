@@ -616,7 +616,7 @@ def main():
         gns = [torch.nn.GroupNorm(16, 256).to(dev) for _ in shapes]
 
         def hand():
-            parts = [ops.lateral_conv(f, c.weight, c.bias, g.weight, g.bias, g.eps) for f, c, g in zip(feats, convs, gns)]
+            parts = ops.lateral_convs([(f, c.weight, c.bias, g.weight, g.bias, g.eps) for f, c, g in zip(feats, convs, gns)])
             return ops.integral_images([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts], channels_last=True)
 
         def library():
@@ -634,7 +634,7 @@ def main():
             return 1e3 * (time.perf_counter() - t0) / reps
 
         extra["producer_f3"] = {"hand_written_ms_per_frame": ms_of(hand), "library_ms_per_frame": ms_of(library), "cameras": n,
-                                "note": "trunk outputs (n, 128/256/512, h, w) -> three integral images: vfa_lateral_conv_f32 x 3 + "
+                                "note": "trunk outputs (n, 128/256/512, h, w) -> three integral images: vfa_lateral_convs_f32 (the three scales in one launch) + "
                                         "vfa_integral_images_hwc_f32, against MIOpen conv + torch GroupNorm + ReLU x 3 + "
                                         "vfa_integral_images_f32; outside the timed region of `value`"}
     # ---- N > 1: what the collective costs.  The same steps without it (slowest rank's compute), and the three ways of fusing the

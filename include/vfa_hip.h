@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VFA_ABI_VERSION 6
+#define VFA_ABI_VERSION 7
 
 /* world-unit conversion of the grid, reference vfa_op.py:23-44 (chosen by args.data) */
 #define VFA_CONV_MULTIVIEWC 0 /* x / 1.0                                   */
@@ -138,14 +138,24 @@ int vfa_integral_images_hwc_f32(const float *const *features_hwc, const float *c
  *   out_hwc (n_views, Hf, Wf, 256) = y, channels-last;   scale, shift (n_views, 256): the nn.GroupNorm(16, 256) affine of y,
  *   scale = gamma * rstd(group), shift = beta - mean(group) * scale   (biased variance, eps inside the root)
  * so that relu(y * scale + shift) = relu(bn(lat(feat))) -- applied by vfa_integral_images_hwc_f32 while it scans the rows.
- * The product runs on v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain over k (sgemm arithmetic); the statistics are gathered in
- * the epilogue (double partial sums, added in a fixed order: the same bits on every run).  K a multiple of 32.
+ * The product: six bf16 MFMA products of a three-piece split of both operands, fp32 accumulation (x = p0 + p1 + p2 to 2^-25 |x|; what
+ * is dropped is <= 2^-23 of a product: the class of an sgemm); the statistics are gathered in the epilogue (double partial sums, added
+ * in a fixed order: the same bits on every run).  K a multiple of 32, <= 1024.
  * workspace: vfa_lateral_conv_workspace_bytes(n_views, Hf, Wf).
  *   replaces vfa/model/vfanet.py:37-42, 72-74 (self.lat8/16/32 + self.bn8/16/32; the ReLU rides in the integral image) */
 size_t vfa_lateral_conv_workspace_bytes(int n_views, int Hf, int Wf);
 int vfa_lateral_conv_f32(const float *feat, const float *weight, const float *bias, const float *gamma, const float *beta, float eps,
                          float *out_hwc, float *scale, float *shift, void *workspace, size_t workspace_bytes, int n_views, int K,
                          int Hf, int Wf, void *stream);
+/* The lateral branches of ALL the feature scales of a frame (n_maps <= 3) in three launches instead of three per scale: HOST arrays
+ * of n_maps device pointers / values with the meaning of vfa_lateral_conv_f32's arguments, Ks[s], feat_hw = {H_0, W_0, H_1, W_1, ...},
+ * workspaces[s] of vfa_lateral_conv_workspace_bytes(n_views, H_s, W_s) bytes each.  Bit-identical to the per-scale calls; the small
+ * maps' workgroups fill the tail of the first (largest) map's instead of paying a launch of their own (ABI v7).
+ *   replaces vfa/model/vfanet.py:72-74 for the three scales */
+int vfa_lateral_convs_f32(int n_maps, const float *const *feats, const float *const *weights, const float *const *biases,
+                          const float *const *gammas, const float *const *betas, const float *eps, float *const *outs_hwc,
+                          float *const *scales, float *const *shifts, void *const *workspaces, const size_t *workspace_bytes, int n_views,
+                          const int *Ks, const int *feat_hw, void *stream);
 
 /* Cube corners -> world units -> 3x4 projection -> normalise/clamp -> 2-D bounding box, area and
  * visibility of every (view, layer, cell).                      replaces vfa_op.py:64-88, 104-106

@@ -344,9 +344,9 @@ def test_producer_fusion_integral_is_bitwise_and_vfanet_agrees(monkeypatch):
         torch.cuda.synchronize()
         ran = kt.summary()
         if fuse:  # hand-written conv (statistics in its epilogue) + the channels-last row scan with affine + ReLU
-            assert "vfa_lateral_conv_f32" in ran and all(tag[-1] for tag in ran["vfa_integral_images_hwc_f32"]["by_tag"]), sorted(ran)
+            assert "vfa_lateral_convs_f32" in ran and all(tag[-1] for tag in ran["vfa_integral_images_hwc_f32"]["by_tag"]), sorted(ran)
         else:     # library conv + GroupNorm + ReLU, plain integral images
-            assert "vfa_lateral_conv_f32" not in ran and not any(tag[-1] for tag in ran["vfa_integral_images_f32"]["by_tag"])
+            assert "vfa_lateral_convs_f32" not in ran and not any(tag[-1] for tag in ran["vfa_integral_images_f32"]["by_tag"])
     scale = outs[1].abs().max().item()
     assert scale > 0
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-3, atol=1e-4 * scale)

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFA_AMD_LIB") or os.path.join(_HERE, "csrc", "libvfa_hip.so")  # (override: A/B runs of two builds)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 CONV_KIND = {"MultiviewC": 0, "MultiviewX": 1, "Wildtrack": 2}
 VOX_REFERENCE, VOX_LAYER_MAJOR = 0, 1
@@ -60,6 +60,7 @@ SIGNATURES = {
     "vfa_integral_absmax_f32": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_lateral_conv_workspace_bytes": [_c_int, _c_int, _c_int],
     "vfa_lateral_conv_f32": [_vp, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
+    "vfa_lateral_convs_f32": [_c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp],
     "vfa_sort_vertices_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp],
     "vfa_bev_nms_f32": [_vp, _vp, _c_int, _c_int, _vp],
     "vfa_frame_workspace_bytes": [_c_int, _c_int, _c_int, _c_int],

@@ -47,7 +47,7 @@ struct LateralArgs {
 
 // The weight as three bf16 planes (x = p0 + p1 + p2, exact to 2^-25 |x|) in MFMA fragment order, once per call:
 //   frag[((chunk * 8 + cb) * 3 + plane) * 64 + lane] (16 B) = W[co = 32 cb + (lane & 31)][k = 16 chunk + 8 (lane >> 5) + j], j = 0..7
-__global__ __launch_bounds__(256) void lateral_split_weight_kernel(const float *__restrict__ w, uint4 *__restrict__ frag, int K)
+__device__ __forceinline__ void lateral_split_weight(const float *__restrict__ w, uint4 *__restrict__ frag, int K)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x; // (chunk, cb, lane)
     if (idx >= (K / 16) * 8 * 64) return;
@@ -65,6 +65,18 @@ __global__ __launch_bounds__(256) void lateral_split_weight_kernel(const float *
     uint4 *o = frag + (size_t)(chunk * 8 + cb) * 3 * 64 + lane;
     o[0] = p0.u; o[64] = p1.u; o[128] = p2.u;
 }
+__global__ __launch_bounds__(256) void lateral_split_weight_kernel(const float *__restrict__ w, uint4 *__restrict__ frag, int K)
+{
+    lateral_split_weight(w, frag, K);
+}
+constexpr int kMaxMaps = 3; // feature scales of a frame in one launch (vfa_lateral_convs_f32)
+struct SplitBatch { const float *w[kMaxMaps]; uint4 *frag[kMaxMaps]; int K[kMaxMaps]; };
+__global__ __launch_bounds__(256) void lateral_split_weight_batched_kernel(SplitBatch b) // blockIdx.y = map
+{
+    const int m = blockIdx.y;
+    lateral_split_weight(m == 0 ? b.w[0] : (m == 1 ? b.w[1] : b.w[2]), m == 0 ? b.frag[0] : (m == 1 ? b.frag[1] : b.frag[2]),
+                         m == 0 ? b.K[0] : (m == 1 ? b.K[1] : b.K[2]));
+}
 
 // PXW = 32-pixel blocks per workgroup (4, 2 or 1): wave w owns pixel block w % PXW and 8 PXW / 4 of the eight 32-channel
 // blocks.  PXW = 4: a wave holds all 256 channels of its pixels (the pixel operand is loaded once); the small maps of strides 16
@@ -81,13 +93,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kChunkK = 16;                    // k per MFMA (v_mfma_f32_32x32x16_bf16)
 constexpr int kFragChunk = 8 * 3 * 64;         // uint4 per 16-k chunk of the split weight: 8 channel blocks x 3 planes x 64 lanes
 template <int PXW>
-__global__ __launch_bounds__(kThreads, 2) void lateral_conv_kernel(LateralArgs a)
+__device__ __forceinline__ void lateral_body(const LateralArgs &a, const int v, const int blk, float4 (*s_out)[32 * 9])
 {
     constexpr int CBW = 8 * PXW / 4; // channel blocks per wave: 8, 4, 2
     constexpr int D = CBW >= 4 ? 4 : 2; // weight fragments are requested D channel blocks ahead of the products that take them
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int col = lane & 31, kg = lane >> 5;
-    const int v = blockIdx.y, blk = blockIdx.x;
     const int pbw = wave % PXW, cb0 = (wave / PXW) * CBW;
     const int p0 = (blk * PXW + pbw) * 32;
     const int px = min(p0 + col, a.HW - 1); // (tail: a clamped pixel is computed and thrown away)
@@ -166,7 +177,6 @@ __global__ __launch_bounds__(kThreads, 2) void lateral_conv_kernel(LateralArgs a
     // Stores go through a wave-private LDS tile (32 pixels x 32 channels): straight from the accumulators a store instruction
     // wrote 64 scattered 16-byte pieces (one per lane, 1 KiB apart) -- with the MFMAs switched off the stride-8 convolution of the
     // bench frame still took 69 of its 94 us --; from the tile it writes the 128 contiguous bytes of eight pixels.
-    __shared__ float4 s_out[kThreads / 64][32 * 9]; // [wave][pixel][8 channel quads + 1 pad]
     const int kh = kg;
     const int p = p0 + col;
     const bool on = p < a.HW;
@@ -216,6 +226,31 @@ __global__ __launch_bounds__(kThreads, 2) void lateral_conv_kernel(LateralArgs a
     }
 }
 
+template <int PXW>
+__global__ __launch_bounds__(kThreads, 2) void lateral_conv_kernel(LateralArgs a)
+{
+    __shared__ float4 s_out[kThreads / 64][32 * 9]; // [wave][pixel][8 channel quads + 1 pad]
+    lateral_body<PXW>(a, blockIdx.y, blockIdx.x, s_out);
+}
+// The scales of a frame in ONE launch (vfa_lateral_convs_f32): workgroup id -> (map, view, block), the maps by DESCENDING K -- the
+// deep maps are few workgroups with long chains (K = 512: 32 chunks each; 35 us as a launch of their own, latency-bound): they start
+// first and the many short workgroups of the large shallow map run beside and behind them.  Same body, same bits as the per-map
+// launches.
+struct LateralBatch { LateralArgs m[kMaxMaps]; int pxw[kMaxMaps]; int end[kMaxMaps]; };
+__global__ __launch_bounds__(kThreads, 2) void lateral_conv_batched_kernel(LateralBatch b)
+{
+    __shared__ float4 s_out[kThreads / 64][32 * 9];
+    const int id = blockIdx.x;
+    const int map = id >= b.end[1] ? 2 : (id >= b.end[0] ? 1 : 0);
+    const int local = id - (map == 0 ? 0 : (map == 1 ? b.end[0] : b.end[1]));
+    const LateralArgs a = map == 0 ? b.m[0] : (map == 1 ? b.m[1] : b.m[2]);
+    const int pxw = map == 0 ? b.pxw[0] : (map == 1 ? b.pxw[1] : b.pxw[2]);
+    const int v = local / a.blocks, blk = local - v * a.blocks;
+    // (blocks_per_workgroup chooses 2 or 1; the 4-block body -- 242 registers, two waves per SIMD -- stays out of this kernel: 160, three)
+    if (pxw == 2) lateral_body<2>(a, v, blk, s_out);
+    else lateral_body<1>(a, v, blk, s_out);
+}
+
 struct FinalArgs {
     const double *partial;
     const float *gamma, *beta; // (256)
@@ -228,7 +263,7 @@ struct FinalArgs {
 // thread took 200 us on the bench frame, 16 chains per group 15), then a fixed butterfly (no atomics: the same bits on every run), then
 // lanes 0..15 write scale = gamma * rstd, shift = beta - mean * scale of the group's channels (the affine of nn.GroupNorm,
 // vfanet.py:40-42)
-__global__ __launch_bounds__(kWave) void lateral_stats_kernel(FinalArgs a)
+__device__ __forceinline__ void lateral_stats(const FinalArgs &a)
 {
     const int v = blockIdx.x / kGroups, g = blockIdx.x % kGroups, j = threadIdx.x;
     const double *pp = a.partial + ((size_t)v * kGroups + g) * (size_t)a.parts * 2;
@@ -252,6 +287,13 @@ __global__ __launch_bounds__(kWave) void lateral_stats_kernel(FinalArgs a)
     a.scale[(size_t)v * kCo + c] = sc;
     a.shift[(size_t)v * kCo + c] = (float)((double)a.beta[c] - mean * (double)a.gamma[c] * rstd);
 }
+__global__ __launch_bounds__(kWave) void lateral_stats_kernel(FinalArgs a) { lateral_stats(a); }
+struct FinalBatch { FinalArgs m[kMaxMaps]; };
+__global__ __launch_bounds__(kWave) void lateral_stats_batched_kernel(FinalBatch b) // blockIdx.y = map
+{
+    const FinalArgs a = blockIdx.y == 0 ? b.m[0] : (blockIdx.y == 1 ? b.m[1] : b.m[2]);
+    lateral_stats(a);
+}
 
 } // namespace
 
@@ -274,27 +316,92 @@ size_t vfa_lateral_conv_workspace_bytes(int n_views, int H, int W)
     return ((size_t)n_views * kGroups * parts * 2 * sizeof(double) + 255) / 256 * 256 + (size_t)kCo * kMaxK * 3 * 2;
 }
 
-int vfa_lateral_conv_f32(const float *feat, const float *weight, const float *bias, const float *gamma, const float *beta, float eps,
-                         float *out_hwc, float *scale, float *shift, void *workspace, size_t workspace_bytes, int n_views, int K,
-                         int H, int W, void *stream)
+static int lateral_check(const float *feat, const float *weight, const float *bias, const float *gamma, const float *beta,
+                         float *out_hwc, float *scale, float *shift, void *workspace, size_t workspace_bytes, int n_views, int K, int H, int W)
 {
     if (!feat || !weight || !bias || !gamma || !beta || !out_hwc || !scale || !shift || n_views < 0 || K <= 0 || H <= 0 || W <= 0)
         return VFA_ERR_BAD_ARGUMENT;
     if (K % (2 * kKc) != 0 || K > kMaxK || ((reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(out_hwc)) & 15) != 0)
         return VFA_ERR_UNSUPPORTED; // (ResNet laterals: K = 128, 256, 512; 16-byte loads / stores)
-    if (n_views == 0) return 0;
     if ((long long)H * W >= (1ll << 31) - kTilePx || n_views > 65535) return VFA_ERR_UNSUPPORTED;
-    const size_t need = vfa_lateral_conv_workspace_bytes(n_views, H, W);
-    if (!workspace || workspace_bytes < need) return VFA_ERR_BAD_ARGUMENT;
+    if (n_views > 0 && (!workspace || workspace_bytes < vfa_lateral_conv_workspace_bytes(n_views, H, W))) return VFA_ERR_BAD_ARGUMENT;
+    return 0;
+}
+static uint4 *lateral_frag_of(void *workspace, int n_views, int H, int W)
+{
+    const size_t parts = ((size_t)H * W + 31) / 32 + 4;
+    return reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(workspace) + ((size_t)n_views * kGroups * parts * 2 * sizeof(double) + 255) / 256 * 256);
+}
+
+int vfa_lateral_convs_f32(int n_maps, const float *const *feats, const float *const *weights, const float *const *biases,
+                          const float *const *gammas, const float *const *betas, const float *eps, float *const *outs_hwc,
+                          float *const *scales, float *const *shifts, void *const *workspaces, const size_t *workspace_bytes, int n_views,
+                          const int *Ks, const int *feat_hw, void *stream)
+{
+    if (n_maps < 1 || n_maps > kMaxMaps || !feats || !weights || !biases || !gammas || !betas || !eps || !outs_hwc || !scales || !shifts ||
+        !workspaces || !workspace_bytes || !Ks || !feat_hw)
+        return VFA_ERR_BAD_ARGUMENT;
+    for (int m = 0; m < n_maps; ++m) {
+        const int st = lateral_check(feats[m], weights[m], biases[m], gammas[m], betas[m], outs_hwc[m], scales[m], shifts[m], workspaces[m],
+                                     workspace_bytes[m], n_views, Ks[m], feat_hw[2 * m], feat_hw[2 * m + 1]);
+        if (st) return st;
+    }
+    if (n_views == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    SplitBatch sb;
+    LateralBatch lb;
+    FinalBatch fb;
+    int max_split = 0, total = 0;
+    int order[kMaxMaps] = {0, 1, 2}; // dispatch order: descending K (stable)
+    for (int i = 1; i < n_maps; ++i)
+        for (int j = i; j > 0 && Ks[order[j]] > Ks[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    for (int m = 0; m < kMaxMaps; ++m) {
+        const int q = m < n_maps ? order[m] : order[0];
+        const int H = feat_hw[2 * q], W = feat_hw[2 * q + 1], K = Ks[q];
+        const int pxw = blocks_per_workgroup(n_views, H, W);
+        uint4 *frag = lateral_frag_of(workspaces[q], n_views, H, W);
+        sb.w[m] = weights[q]; sb.frag[m] = frag; sb.K[m] = K;
+        LateralArgs &a = lb.m[m];
+        a.feat = feats[q]; a.weight = weights[q]; a.bias = biases[q]; a.out = outs_hwc[q]; a.partial = reinterpret_cast<double *>(workspaces[q]);
+        a.wfrag = frag; a.K = K; a.HW = H * W; a.blocks = (a.HW + 32 * pxw - 1) / (32 * pxw);
+        lb.pxw[m] = pxw;
+        if (m < n_maps) {
+            if ((long long)total + (long long)a.blocks * n_views >= (1ll << 31)) return VFA_ERR_UNSUPPORTED;
+            total += a.blocks * n_views;
+            const int sblk = ((K / 16) * 8 * 64 + 255) / 256;
+            max_split = sblk > max_split ? sblk : max_split;
+        }
+        lb.end[m] = total; // (maps beyond n_maps: empty ranges)
+        FinalArgs &f = fb.m[m];
+        f.partial = a.partial; f.gamma = gammas[q]; f.beta = betas[q]; f.scale = scales[q]; f.shift = shifts[q];
+        f.parts = a.blocks * pxw; f.count = (double)a.HW * (kCo / kGroups); f.eps = eps[q];
+    }
+    hipLaunchKernelGGL(lateral_split_weight_batched_kernel, dim3((unsigned)max_split, (unsigned)n_maps), dim3(256), 0, s, sb);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    hipLaunchKernelGGL(lateral_conv_batched_kernel, dim3((unsigned)total), dim3(kThreads), 0, s, lb);
+    e = (int)hipGetLastError();
+    if (e) return e;
+    hipLaunchKernelGGL(lateral_stats_batched_kernel, dim3((unsigned)n_views * kGroups, (unsigned)n_maps), dim3(kWave), 0, s, fb);
+    return (int)hipGetLastError();
+}
+
+int vfa_lateral_conv_f32(const float *feat, const float *weight, const float *bias, const float *gamma, const float *beta, float eps,
+                         float *out_hwc, float *scale, float *shift, void *workspace, size_t workspace_bytes, int n_views, int K,
+                         int H, int W, void *stream)
+{
+    {
+        const int st = lateral_check(feat, weight, bias, gamma, beta, out_hwc, scale, shift, workspace, workspace_bytes, n_views, K, H, W);
+        if (st) return st;
+    }
+    if (n_views == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int pxw = blocks_per_workgroup(n_views, H, W);
     LateralArgs a;
     a.feat = feat; a.weight = weight; a.bias = bias; a.out = out_hwc; a.partial = reinterpret_cast<double *>(workspace);
     a.K = K; a.HW = H * W; a.blocks = (a.HW + 32 * pxw - 1) / (32 * pxw);
     {
-        const size_t parts = ((size_t)H * W + 31) / 32 + 4;
-        uint4 *frag = reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(workspace) +
-                                                ((size_t)n_views * kGroups * parts * 2 * sizeof(double) + 255) / 256 * 256);
+        uint4 *frag = lateral_frag_of(workspace, n_views, H, W);
         hipLaunchKernelGGL(lateral_split_weight_kernel, dim3((unsigned)((K / 16) * 8 * 64 + 255) / 256), dim3(256), 0, s, weight, frag, K);
         const int e0 = (int)hipGetLastError();
         if (e0) return e0;

@@ -3,6 +3,7 @@
 Tensors are device tensors; every call is asynchronous on the current torch HIP stream.
 """
 import os
+import ctypes
 
 import torch
 
@@ -182,6 +183,41 @@ def lateral_conv(feat, weight, bias, gamma, beta, eps=1e-5):
             _lib.ptr(out), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(ws), ws.numel(), n, K, h, w, _lib.current_stream_handle(),
             tag=(n, K, h, w))
     return out, scale, shift
+
+
+def lateral_convs(branches):
+    """``lateral_conv`` for ALL the scales of a frame in three launches (``vfa_lateral_convs_f32``): branches = [(feat, weight, bias,
+    gamma, beta, eps), ...] (at most three; the largest map first) -> [(y, scale, shift), ...], bit for bit the per-scale calls
+    (reference vfanet.py:72-74 for the three scales).  The small maps' workgroups fill the tail of the large map's launch."""
+    if not branches:
+        return []
+    if len(branches) > 3:
+        return [lateral_conv(*b) for b in branches]
+    dev = branches[0][0].device
+    feats, weights, biases, gammas, betas, epss, outs, scales, shifts, wss, Ks, hws = [], [], [], [], [], [], [], [], [], [], [], []
+    n = branches[0][0].shape[0]
+    for feat, weight, bias, gamma, beta, eps in branches:
+        _lib.require_device(feat, weight, bias, gamma, beta)
+        feat, weight = _f32c(feat), _f32c(weight.reshape(weight.shape[0], -1))
+        assert feat.shape[0] == n and tuple(weight.shape) == (256, feat.shape[1])
+        _, K, h, w = feat.shape
+        feats.append(feat), weights.append(weight), biases.append(_f32c(bias)), gammas.append(_f32c(gamma)), betas.append(_f32c(beta))
+        epss.append(float(eps)), Ks.append(int(K)), hws.extend((int(h), int(w)))
+        outs.append(torch.empty((n, h, w, 256), dtype=torch.float32, device=dev))
+        scales.append(torch.empty((n, 256), dtype=torch.float32, device=dev))
+        shifts.append(torch.empty((n, 256), dtype=torch.float32, device=dev))
+        need = _lib.lib().vfa_lateral_conv_workspace_bytes(n, h, w)
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, need, len(wss))  # (one per scale: they are in flight together)
+        ws = _lateral_ws.get(key)
+        if ws is None:
+            ws = _lateral_ws[key] = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+        wss.append(ws)
+    m = len(branches)
+    _launch("vfa_lateral_convs_f32", m, _lib.ptr_array(feats), _lib.ptr_array(weights), _lib.ptr_array(biases), _lib.ptr_array(gammas),
+            _lib.ptr_array(betas), (ctypes.c_float * m)(*epss), _lib.ptr_array(outs), _lib.ptr_array(scales), _lib.ptr_array(shifts),
+            _lib.ptr_array(wss), (ctypes.c_size_t * m)(*[w.numel() for w in wss]), n, _lib.int_array(Ks), _lib.int_array(hws),
+            _lib.current_stream_handle(), tag=(n, tuple(Ks), tuple(hws)))
+    return list(zip(outs, scales, shifts))
 
 
 def box_params(calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh, feat_hw, crange=(-1, 0.95)):

@@ -156,16 +156,14 @@ class VFANet(nn.Module):
 
     def lateral_integrals(self, images):
         """images (n,3,iH,iW) -> the three zero-bordered channels-last integral images of the lateral maps, without
-        materialising those maps (reference vfanet.py:72-74 + vfa_op.py:110, 172-173).  Per scale ONE hand-written kernel for
-        the 1x1 convolution (``ops.lateral_conv``: fp32 on the matrix pipe, channels-last output, GroupNorm statistics in its
-        epilogue) + a tiny statistics kernel; then one launch pair for the three integral images, whose row scan applies the
+        materialising those maps (reference vfanet.py:72-74 + vfa_op.py:110, 172-173).  ONE hand-written kernel for the three
+        1x1 convolutions (``ops.lateral_convs``: six bf16 MFMA products of a three-piece split, channels-last output, GroupNorm
+        statistics in its epilogue) + a tiny statistics kernel; then one launch pair for the three integral images, whose row scan applies the
         GroupNorm affine and the ReLU (``vfa_integral_images_hwc_f32``).  No NCHW lateral tensor exists."""
         x = (images - self.mean.view(3, 1, 1)) / self.std.view(3, 1, 1)
-        ys, scales, shifts = [], [], []
-        for feat, conv, gn in zip(self.base(x), (self.lat8, self.lat16, self.lat32), (self.bn8, self.bn16, self.bn32)):
-            y, scale, shift = ops.lateral_conv(feat, conv.weight, conv.bias, gn.weight, gn.bias, gn.eps)
-            ys.append(y), scales.append(scale), shifts.append(shift)
-        return ops.integral_images(ys, scales, shifts, channels_last=True)
+        parts = ops.lateral_convs([(feat, conv.weight, conv.bias, gn.weight, gn.bias, gn.eps) for feat, conv, gn in
+                                   zip(self.base(x), (self.lat8, self.lat16, self.lat32), (self.bn8, self.bn16, self.bn32))])
+        return ops.integral_images([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts], channels_last=True)
 
     def ortho_features(self, images, calibs, grid, distributed=False):
         """The fused BEV map (1,256,L,W) entering the heads (reference vfanet.py:64-82, 131)."""
