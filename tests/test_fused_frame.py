@@ -632,3 +632,36 @@ def test_shipped_pooling_code_vs_the_reference_voxel_features(name, n_cam, crop)
             assert torch.equal(got, gotp), (cam, s)  # the two kernels pool with the same operations: the same bits
     print(f"[pooled rows] {name}: {equal / total:.4%} of {total} voxel features bit-identical to the reference's, worst {worst} ulp")
     assert equal / total >= 0.70
+
+
+@pytest.mark.gpu
+def test_repeated_launches_on_one_workspace_find_clear_hand_off_tickets():
+    """No memset in front of a launch any more: the geometry call zeroes the tile tickets, the workgroup that draws a tile's last
+    ticket puts it back.  Launches of 8, 256 and 40 workgroups on ONE workspace (different tiles cut every time), serial and pipelined
+    kernel, accumulate on and off: every launch must find its tickets clear -- a stale one would drop or double a shared tile."""
+    import vfa_amd
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    dev = torch.device("cuda:0")
+    wl = make_workload("multiviewc_200x200x1", channels=256, seed=11, n_cam=5, device=dev)
+    grid = wl["grid"][:, 20:92, 30:126].contiguous()
+    L, W = grid.shape[1:3]
+    torch.manual_seed(4)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
+    lats = [torch.cat([wl["features"][c][s] for c in range(5)]) for s in range(3)]
+    zl, co = mods[0]._kernel_geometry(dev)
+    kind, img_wh, sizes = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1], [tuple(l.shape[-2:]) for l in lats]
+    biases = [m.collapse.bias for m in mods]
+    with torch.no_grad():
+        integrals = ops.integral_images(lats)
+        ws_s = ops.frame_records(wl["calibs"], grid, zl, co, kind, img_wh, sizes, weights=[m.layer_major_weight().contiguous() for m in mods])
+        ws_p = ops.pipe_records(wl["calibs"], grid, zl, co, kind, img_wh, sizes, weights=[m.collapse.weight for m in mods])
+        for run, ws in ((lambda **kw: ops.pool_collapse(integrals, biases, ws_s, (L, W), absmax=integrals.absmax, **kw), ws_s),
+                        (lambda **kw: ops.pipe_collapse(integrals, biases, ws_p, (L, W), 1, absmax=integrals.absmax, **kw), ws_p)):
+            first = {r: run(reserved_cus=r) for r in (248, 0, 216)}
+            for r in (0, 216, 248, 248, 0):
+                assert torch.equal(run(reserved_cus=r), first[r]), r
+            acc = first[0].clone()
+            run(reserved_cus=248, out=acc, accumulate=True)
+            torch.testing.assert_close(acc, first[0] + first[248], rtol=1e-6, atol=0)
+        torch.cuda.synchronize()
