@@ -4,25 +4,28 @@
 //   reference                                                              here
 //   corners, convert, project, clamp, bbox, area, visibility               pipe_records_kernel: once per frame for all scales
 //     vfa/model/vfa_op.py:64-88, 104-106; vfa/utils.py:50-59                 and ALL z-layers (box records + tap windows)
-//   4 x grid_sample of the integral image, box mean, mask  :112-120        pooling waves 8-11 of pipe_kernel (fp32, the
+//   4 x grid_sample of the integral image, box mean, mask  :112-120        pooling waves 8-15 of pipe_kernel (fp32, the
 //                                                                            reference's FMA chains, bit for bit)
-//   collapse = Linear(C * nl -> C)                          :50-59, :123   matrix waves 0-7: bf16-split MFMA, K = nl * 256
+//   collapse = Linear(C * nl -> C)                          :50-59, :123   matrix waves 0-7: split-operand MFMA, K = nl * 256
 //   relu; f8 + f16 + f32; ortho += ...       :124; vfa/model/vfanet.py:79,82  in registers of the matrix waves
 //
 // Why this shape.  `relu` follows the sum over the whole K = nl * 256, so the 32 x 256 accumulator of a (tile, view, scale)
-// has to stay on the CU while all nl layers are pooled and multiplied, and one layer of `collapse.weight` (256 KiB as bf16
-// hi + lo) cannot stay in registers beside it.  A workgroup therefore keeps the accumulators of a GROUP of four views of a
+// has to stay on the CU while all nl layers are pooled and multiplied, and one layer of `collapse.weight` (256 KiB as two
+// 16-bit planes) cannot stay in registers beside it.  A workgroup therefore keeps the accumulators of a GROUP of four views of a
 // tile (128 rows) and streams the weight through registers in slices of 64 k x 256 n, each used for all 128 rows: 64 KiB of
 // weight traffic per 32 x 256 x 256 product instead of 256.  Pooling (VALU + LDS) and the products (matrix pipe) run
-// CONCURRENTLY on different waves: three waves per SIMD -- two matrix waves, one pooling wave -- one barrier per step of
-// 64 rows x 64 channels (vfa_pipe_seq.h has the step order).  Tap windows arrive by LDS-DMA one step ahead, issued by the matrix
-// waves between their MFMAs; boxes whose window does not fit (right in front of a camera) are pooled from L2 by the same
-// pooling code (no pre-pass, no row scratch).  A tile cut between workgroups is finished by whichever of them arrives
-// LAST (a ticket per tile: no workgroup ever waits for another).
+// CONCURRENTLY on different waves: four waves per SIMD -- two matrix waves, two pooling waves, 128 registers each (the
+// six-product variant: three per SIMD, 168) -- one barrier per step of 64 rows x 64 channels (vfa_pipe_seq.h has the step
+// order).  Tap windows arrive by LDS-DMA one step ahead, issued by the pooling waves; boxes whose window does not fit (right in
+// front of a camera) are pooled from L2 by the same pooling code (no pre-pass, no row scratch).  A tile cut between workgroups
+// is finished by whichever of them arrives LAST (a ticket per tile: no workgroup ever waits for another; the last arriver
+// puts the ticket back to zero).  Frames of one or two views run the four-step phase (template parameter SMALL).
 //
-// Numerics: pooling = the reference's exact fp32 sequence up to `v * RN(1 / area)` (<= 1.5 ulp from its division); product =
-// three bf16 MFMA products of a two-piece (16-bit) split of both operands, fp32 accumulation, k ascending -- on a single-layer
-// grid the SAME sequence as vfa_fused.hip, so the two kernels agree bit for bit there.
+// Numerics: pooling = the reference's exact fp32 sequence up to `v * RN(1 / area)` (<= 1 ulp from its division;
+// VFA_FLAG_DUMP_VOX stores the rows this code forms); product, default: both operands scaled by a power of two and split into two
+// fp16 pieces, three MFMA products hi.lo + hi.hi + lo.hi with fp32 accumulation, k ascending (vfa_split.h: the width of the
+// reference's fp32 nn.Linear); VFA_FLAG_TERMS 3 / 4: two bf16 pieces (16-bit operands), 6: three bf16 pieces, six products.  On a
+// single-layer grid the product sequence is vfa_fused.hip's; the two kernels differ by the association of the view sum only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
