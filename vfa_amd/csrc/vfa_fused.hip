@@ -7,16 +7,19 @@
 //                             of the integral image that holds all of the tile's taps.
 //   2. pool_collapse_kernel   one persistent 512-thread workgroup per CU walks tiles; per (tile, scale, view) it brings the
 //                             tile's tap window into LDS by LDS-DMA (each DISTINCT tap is read from L2 / HBM once), pools
-//                             the 32 boxes with the reference's FMA chains (vfa_op.py:112-119) straight into bf16 hi/lo
+//                             the 32 boxes with the reference's FMA chains (vfa_op.py:112-119) straight into two 16-bit
 //                             planes in LDS, multiplies them with `collapse.weight` on the matrix cores (vfa_op.py:123, three
-//                             bf16 MFMA products per fp32 product, fp32 accumulation), adds bias + ReLU (:124) and sums
+//                             MFMA products per fp32 product, fp32 accumulation), adds bias + ReLU (:124) and sums
 //                             views and scales in registers (vfa/model/vfanet.py:79, 82).  The voxel features never touch
 //                             HBM and the BEV map is written exactly once.
+//      (+ pool_rows_kernel, a pre-pass over the few items whose window exceeds LDS, and an empty second launch for those of them
+//       that found no row slot)
 //
 // Numerics: tap chains and the box sum are the reference's exact fp32 sequence (same device code as the bit-exact pooling
-// kernels); the quotient is v * RN(1 / area) (<= 1.5 ulp from the reference's division -- far below the 2^-17 of the bf16
-// split that follows) and the product is the bf16-split MFMA arithmetic of vfa_collapse.hip: within the path's post-GEMM
-// tolerance (rtol 1e-4, atol 1e-5 max|ref|), not bitwise -- no GEMM order is.
+// kernels); the quotient is v * RN(1 / area) (<= 1 ulp from the reference's division: VFA_FLAG_DUMP_VOX stores the rows this
+// code forms, tests/test_fused_frame.py); the product, default (TERMS 2): both operands scaled by a power of two and split into two
+// fp16 pieces, hi.lo + hi.hi + lo.hi -- the width of the reference's fp32 nn.Linear (vfa_split.h) --; TERMS 3 / 4: two bf16
+// pieces (16-bit operands).  Within the path's post-GEMM tolerance (rtol 1e-4, atol 1e-5 max|ref|), not bitwise -- no GEMM order is.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>

@@ -5,18 +5,17 @@
 // image applies together with the ReLU (vfa_integral.hip, rows_hwc_kernel).  The normalised lateral map itself is never stored,
 // and no NCHW copy of the convolution output exists.
 //
-// The convolution is a (pixels x K) . (K x 256) product in fp32 ON THE MATRIX PIPE: v_mfma_f32_32x32x2_f32 is an exact fp32
-// FMA chain over k (ascending), i.e. the arithmetic of a plain fp32 dot product -- sgemm-class by construction, no split
-// operands.  It is 1/16 of the bf16 rate (155 TFLOP/s), which for K = 128 .. 512 -> 256 still sits at the HBM time of the
-// operands (bench frame: 11.5 GFLOP = 75 us against 225 MB = 28 us), so nothing cheaper is worth its rounding.
+// The convolution is a (pixels x K) . (K x 256) product at the width of an sgemm: SIX bf16 MFMA products of a three-piece split of
+// both operands with fp32 accumulation (lateral_body; 6 / 16 of the matrix-pipe time of v_mfma_f32_32x32x2_f32, which the first form
+// of this kernel used).
 //
-// Tiling: a workgroup of four waves takes 128 consecutive pixels of one view; wave w owns pixels 32 w .. 32 w + 31 and ALL 256
-// output channels (eight 32 x 32 accumulators = 128 registers; the CHANNELS are the rows of the MFMA, so that a lane ends up with
-// four consecutive channels of one pixel per register quad: 16-byte channels-last stores) -- or, on the small maps, 64 / 32 pixels with the channels split
-// over two / four waves (lateral_conv_kernel<PXW>).  A operands come straight from HBM: the NCHW input is
-// k-major, so lane (pixel p, k half) loads feat[k][p] -- 32 consecutive floats per half wave, no LDS, no transpose.  B operands
-// (the weight, reference layout (256, K)) are staged through LDS in chunks of 32 k, transposed on the way in ([k][co], so that a
-// lane group reads 32 consecutive output channels), double-buffered.
+// Tiling: a workgroup of four waves takes 32 PXW consecutive pixels of one view (PXW = 2 on the large map, 1 on the small ones:
+// blocks_per_workgroup); wave w owns pixel block w % PXW and 8 PXW / 4 of the eight 32-channel blocks.  The CHANNELS are the rows
+// of the MFMA, so that a lane ends up with four consecutive channels of one pixel per register quad: channels-last stores, through a
+// wave-private LDS tile.  The pixel operand comes straight from HBM two 16-k chunks ahead (the NCHW input is k-major: lane (pixel p,
+// k half) loads feat[k][p], 32 consecutive floats per half wave) and is split in registers; the weight comes pre-split in MFMA
+// fragment order (lateral_split_weight_kernel) and is streamed by every wave from L2 / L1: no LDS staging, no workgroup barrier.
+// vfa_lateral_convs_f32 runs the scales of a frame as ONE launch of each of the three kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
