@@ -379,6 +379,16 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
 int vfa_pipe_balance_f32(int n_views, int L, int W, int n_layers, int n_scales, int reserved_cus, int mode, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* The weight gradient of `collapse` (training):  g_w (256, K) (+)= g_lin^T . vox  with g_lin (rows, 256) the
+ * masked output gradient (vfa_relu_mask_backward_f32 / vfa_collapse_gemm_relu_backward_f32) and vox (rows, K) the voxel features of
+ * the same rows, K = n_layers * 256 in the column order of the weight passed to the forward.  Six bf16 MFMA products of a three-piece
+ * split of both operands, fp32 accumulation (sgemm class); per-workgroup partial sums added in a fixed order (the same bits on every
+ * run).  workspace: vfa_grad_weight_workspace_bytes(rows, K).  K a multiple of 256 (ABI v7).
+ *   replaces the autograd of nn.Linear's weight, vfa/model/vfa_op.py:59, :123 under vfa/trainer.py:41 */
+size_t vfa_grad_weight_workspace_bytes(long long rows, int K);
+int vfa_grad_weight_f32(const float *g_lin, const float *vox, float *g_w, long long rows, int K, int accumulate, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* ---- consumers of the path ---------------------------------------------------------------------------
  *
  * vfa_sort_vertices_f32: anticlockwise order of the valid vertices of n convex polygons per batch entry (rectangle x rectangle

@@ -286,3 +286,30 @@ def test_relu_mask_epilogue_equals_product_then_mask(n, cells, K):
     assert torch.equal(glin, want_glin)
     assert 0.2 < (glin != 0).float().mean().item() < 0.8
     torch.testing.assert_close(gb, want_gb, rtol=1e-4, atol=1e-4 * want_gb.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K", [(20000, 256), (3331, 1280), (16, 256), (7, 512), (100003, 256)])
+def test_weight_gradient_product_has_the_width_of_an_sgemm(rows, K):
+    """``vfa_grad_weight_f32``: g_w = g_lin^T . vox as six bf16 MFMA products of a three-piece split (reference: the autograd of
+    nn.Linear's weight, vfa_op.py:59, :123 under trainer.py:41).  Against float64: no worse than the library's fp32 product; ragged row
+    counts (a last step with fewer than 16 rows), accumulation, heavy-tailed operands, and the same bits on every run."""
+    from vfa_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows + K)
+    g_lin = torch.randn(rows, 256, generator=g)
+    g_lin[g_lin.abs() < 0.6] = 0.0                     # (a ReLU mask leaves many exact zeros)
+    vox = torch.randn(rows, K, generator=g) * torch.exp(2.0 * torch.randn(rows, 1, generator=g))  # (rows of very different size)
+    g_lin, vox = g_lin.to(dev), vox.to(dev)
+    want = g_lin.double().t() @ vox.double()
+    got = ops.grad_weight(g_lin, vox)
+    lib = g_lin.t() @ vox
+    err = ((got.double() - want).norm() / want.norm()).item()
+    err_lib = ((lib.double() - want).norm() / want.norm()).item()
+    print(f"[margin] rows {rows}, K {K}: normwise error {err:.2e} (library fp32 product {err_lib:.2e})")
+    assert err <= 6e-7 and err <= err_lib + 5e-8, (err, err_lib)  # (fp32 accumulation over up to 1e5 rows: 3e-7 at 2e4)
+    assert torch.equal(ops.grad_weight(g_lin, vox), got)
+    acc = torch.full((256, K), 0.5, device=dev)
+    ops.grad_weight(g_lin, vox, out=acc, accumulate=True)
+    torch.testing.assert_close(acc, got + 0.5, rtol=1e-6, atol=1e-6)
+    assert torch.equal(ops.grad_weight(g_lin[:0], vox[:0]), torch.zeros(256, K, device=dev))

@@ -26,7 +26,7 @@ def collapse_flags(terms=0, reserved_cus=0):
     return (int(terms) & 0xf) | ((int(reserved_cus) & 0xff) << 8)
 
 
-_c_int, _c_float, _c_size_t, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+_c_int, _c_float, _c_size_t, _vp, _c_longlong = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_longlong
 
 # name -> argtypes; must list every symbol include/vfa_hip.h declares (tests/test_abi.py checks it)
 SIGNATURES = {
@@ -60,6 +60,8 @@ SIGNATURES = {
     "vfa_integral_absmax_f32": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_lateral_conv_workspace_bytes": [_c_int, _c_int, _c_int],
     "vfa_lateral_conv_f32": [_vp, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
+    "vfa_grad_weight_workspace_bytes": [_c_longlong, _c_int],
+    "vfa_grad_weight_f32": [_vp, _vp, _vp, _c_longlong, _c_int, _c_int, _vp, _c_size_t, _vp],
     "vfa_lateral_convs_f32": [_c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp],
     "vfa_sort_vertices_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp],
     "vfa_bev_nms_f32": [_vp, _vp, _c_int, _c_int, _vp],

@@ -395,6 +395,32 @@ def relu_mask_backward(grad, lin, bias):
     return glin, gbias
 
 
+_grad_w_ws = {}
+
+
+def grad_weight(g_lin, vox, out=None, accumulate=False):
+    """out (256, K) (+)= g_lin^T . vox: the weight gradient of ``collapse`` (autograd of nn.Linear's weight, reference vfa_op.py:59, :123
+    under trainer.py:41).  g_lin (rows, 256) the masked output gradient, vox (rows, K) the voxel features of the same rows, K a
+    multiple of 256.  Six bf16 MFMA products of a three-piece split (sgemm class), fixed summation order (``vfa_grad_weight_f32``)."""
+    _lib.require_device(g_lin, vox, out)
+    g_lin, vox = _f32c(g_lin), _f32c(vox)
+    rows, K = vox.shape
+    assert tuple(g_lin.shape) == (rows, 256) and K % 256 == 0
+    dev = vox.device
+    if out is None:
+        out = torch.empty((256, K), dtype=torch.float32, device=dev)
+        accumulate = False
+    assert tuple(out.shape) == (256, K) and out.is_contiguous() and out.dtype == torch.float32
+    need = _lib.lib().vfa_grad_weight_workspace_bytes(rows, K)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _grad_w_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _grad_w_ws[key] = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+    _launch("vfa_grad_weight_f32", _lib.ptr(g_lin), _lib.ptr(vox), _lib.ptr(out), rows, K, 1 if accumulate else 0, _lib.ptr(ws),
+            ws.numel(), _lib.current_stream_handle(), tag=(rows, K))
+    return out
+
+
 def bias_relu_accumulate(lin, bias, out=None, accumulate=False):
     """out (M,N) (+)= sum_v relu(lin[v] + bias) (reference vfa_op.py:124, vfanet.py:82)."""
     _lib.require_device(lin, bias, out)

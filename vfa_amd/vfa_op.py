@@ -440,7 +440,7 @@ class _FusedFrameTrain(torch.autograd.Function):
                         g_b += g_b_part
                     g2 = g_lin.view(n * count, C)
                     if need_w:
-                        g_w_lm.addmm_(g2.t(), vox.view(n * count, nl * C))
+                        ops.grad_weight(g2, vox.view(n * count, nl * C), out=g_w_lm, accumulate=True)
                     if need_lat:
                         g_vox = torch.matmul(g2, w_lm).view(n, count, nl * C)
                         ops.project_gather_backward(g_vox, tuple(integral.shape), cal, grid_flat, z_layers, corner_off, conv_kind,
