@@ -388,6 +388,13 @@ int vfa_pipe_balance_f32(int n_views, int L, int W, int n_layers, int n_scales, 
 size_t vfa_grad_weight_workspace_bytes(long long rows, int K);
 int vfa_grad_weight_f32(const float *g_lin, const float *vox, float *g_w, long long rows, int K, int accumulate, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* ... and of its input:  g_vox (rows, K) = g_lin (rows, 256) . w (256, K), w = the weight in the column order of the forward.  The same
+ * six-product arithmetic; workspace: vfa_grad_input_workspace_bytes(K) (the weight as three bf16 planes in MFMA fragment order,
+ * rebuilt by every call).  K a multiple of 256, g_lin 16-byte aligned (ABI v7).
+ *   replaces the autograd of nn.Linear's input, vfa/model/vfa_op.py:123 under vfa/trainer.py:41 */
+size_t vfa_grad_input_workspace_bytes(int K);
+int vfa_grad_input_f32(const float *g_lin, const float *w, float *g_vox, long long rows, int K, void *workspace, size_t workspace_bytes,
+                       void *stream);
 
 /* ---- consumers of the path ---------------------------------------------------------------------------
  *

@@ -313,3 +313,30 @@ def test_weight_gradient_product_has_the_width_of_an_sgemm(rows, K):
     ops.grad_weight(g_lin, vox, out=acc, accumulate=True)
     torch.testing.assert_close(acc, got + 0.5, rtol=1e-6, atol=1e-6)
     assert torch.equal(ops.grad_weight(g_lin[:0], vox[:0]), torch.zeros(256, K, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K", [(20000, 256), (3331, 1280), (256, 256), (7, 512), (100003, 256)])
+def test_input_gradient_product_has_the_width_of_an_sgemm(rows, K):
+    """``vfa_grad_input_f32``: g_vox = g_lin . w as six bf16 MFMA products of a three-piece split (reference: the autograd of nn.Linear's
+    input, vfa_op.py:123 under trainer.py:41).  Against float64: the class of the library's fp32 product; ragged row counts (a last
+    block with fewer than 256 rows), several K tiles, and the same bits on every run."""
+    from vfa_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows + K + 1)
+    g_lin = torch.randn(rows, 256, generator=g) * torch.exp(2.0 * torch.randn(rows, 1, generator=g))
+    g_lin[g_lin.abs() < 0.6] = 0.0
+    w = torch.randn(256, K, generator=g) / 16.0
+    w[::9] *= 50.0                                     # (a heavy tail across the reduction index)
+    g_lin, w = g_lin.to(dev), w.to(dev)
+    want = g_lin.double() @ w.double()
+    got = ops.grad_input(g_lin, w)
+    lib = g_lin @ w
+    err = ((got.double() - want).norm() / want.norm()).item()
+    err_lib = ((lib.double() - want).norm() / want.norm()).item()
+    print(f"[margin] rows {rows}, K {K}: normwise error {err:.2e} (library fp32 product {err_lib:.2e})")
+    assert err <= 3e-7 and err <= err_lib + 1e-7, (err, err_lib)
+    assert torch.equal(ops.grad_input(g_lin, w), got)
+    # row by row: no row of the ragged last block is lost or written twice
+    worst = ((got.double() - want).abs().amax(1) / want.abs().amax(1).clamp_min(1e-30)).max().item()
+    assert worst <= 2e-6, worst

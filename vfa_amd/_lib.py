@@ -62,6 +62,8 @@ SIGNATURES = {
     "vfa_lateral_conv_f32": [_vp, _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_grad_weight_workspace_bytes": [_c_longlong, _c_int],
     "vfa_grad_weight_f32": [_vp, _vp, _vp, _c_longlong, _c_int, _c_int, _vp, _c_size_t, _vp],
+    "vfa_grad_input_workspace_bytes": [_c_int],
+    "vfa_grad_input_f32": [_vp, _vp, _vp, _c_longlong, _c_int, _vp, _c_size_t, _vp],
     "vfa_lateral_convs_f32": [_c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _vp],
     "vfa_sort_vertices_f32": [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp],
     "vfa_bev_nms_f32": [_vp, _vp, _c_int, _c_int, _vp],

@@ -12,6 +12,12 @@
 // one column (4-byte loads, a wave reads 2 x 128 contiguous bytes per instruction), splits them and writes the three 16-byte MFMA
 // fragments into LDS, 16 rows of both operands per step, double-buffered; the waves read their fragments back with ds_read_b128.
 // Every workgroup writes its 256 x 256 partial sum; a second kernel adds the partials in a fixed order: the same bits on every run.
+//
+// ... and the gradient of its INPUT,  g_vox (M, K) = g_lin (M, 256) . w (256, K)  (autograd of nn.Linear's input, the same lines): the
+// reduction index is the short one here.  The weight is split once per call into MFMA fragment order (grad_input_split_kernel); a
+// workgroup walks blocks of 256 rows -- wave w owns rows 32 w .. 32 w + 31 of the block and all 256 columns of its K tile --, its waves
+// load their own g_lin fragments straight from memory (eight consecutive floats per lane) and split them in registers, the weight
+// fragments of a 16-deep step (24 KB) go through LDS once per workgroup and step.  Same six products.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -194,6 +200,118 @@ __global__ __launch_bounds__(1024) void grad_weight_reduce_kernel(const float *p
     }
 }
 
+// ---- g_vox = g_lin . w --------------------------------------------------------------------------------------------------------
+// w (256, K) as three bf16 planes in MFMA b-fragment order:
+//   frag[(((kt * 16 + s) * 8 + cb) * 3 + plane) * 64 + lane] (16 B) = w[o = 16 s + 8 (lane >> 5) + j][kt * 256 + 32 cb + (lane & 31)], j = 0..7
+__global__ __launch_bounds__(256) void grad_input_split_kernel(const float *__restrict__ w, uint4 *__restrict__ frag, int K)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x; // (kt, s, cb, lane)
+    if (idx >= (K / kKTile) * 16 * 8 * 64) return;
+    const int lane = idx & 63, cb = (idx >> 6) & 7, st = (idx >> 9) & 15, kt = idx >> 13;
+    const float *src = w + (size_t)(16 * st + 8 * (lane >> 5)) * K + kt * kKTile + 32 * cb + (lane & 31);
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = src[(size_t)j * K];
+    bf16x8 p0, p1, p2;
+    split3(x, p0, p1, p2);
+    bf16x8 *o = reinterpret_cast<bf16x8 *>(frag) + ((size_t)((kt * 16 + st) * 8 + cb) * 3) * 64 + lane;
+    o[0] = p0; o[64] = p1; o[128] = p2;
+}
+
+struct GradXArgs {
+    const float *g_lin;   // (rows, 256)
+    const uint4 *wfrag;   // grad_input_split_kernel output
+    float *out;           // (rows, K)
+    long long rows;
+    int K;
+};
+
+__global__ __launch_bounds__(kThreads) void grad_input_kernel(GradXArgs a)
+{
+    __shared__ __align__(16) unsigned char s_b[2][kOperandBytes]; // weight fragments of a step: [cb][plane][lane] as in wfrag
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kt = blockIdx.y;
+    const int n = lane & 31, half = lane >> 5;
+    const long long blocks = (a.rows + 255) / 256;
+    const long long b0 = blocks * blockIdx.x / gridDim.x, b1 = blocks * (blockIdx.x + 1) / gridDim.x;
+    if (b0 >= b1) return;
+    // staging role: thread t copies the three 16-byte pieces t, t + 512, t + 1024 of the step's 1536 fragments
+    const uint4 *wsrc = a.wfrag + (size_t)kt * 16 * 8 * 3 * 64;
+    // (native vectors in named registers: an array of HIP's uint4 structs copied to LDS is compiled as a memcpy through scratch memory)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *wsrc4 = reinterpret_cast<const u32x4 *>(wsrc);
+    u32x4 wr0, wr1, wr2;
+    auto load_b = [&](int st) {
+        const u32x4 *p = wsrc4 + (size_t)st * (8 * 3 * 64) + tid;
+        wr0 = p[0]; wr1 = p[kThreads]; wr2 = p[2 * kThreads];
+    };
+    auto store_b = [&](int buf) {
+        u32x4 *d = reinterpret_cast<u32x4 *>(s_b[buf]) + tid;
+        d[0] = wr0; d[kThreads] = wr1; d[2 * kThreads] = wr2;
+    };
+    // this lane's row of the block and its eight consecutive reduction indices of a step
+    float xa[8];
+    auto load_a = [&](long long blk, int st) {
+        long long m = blk * 256 + 32 * wave + n;
+        m = m < a.rows ? m : a.rows - 1; // (rows beyond the end: computed and thrown away)
+        const float4 *p = reinterpret_cast<const float4 *>(a.g_lin + (size_t)m * kN + 16 * st + 8 * half);
+        const float4 u = p[0], v = p[1];
+        xa[0] = u.x; xa[1] = u.y; xa[2] = u.z; xa[3] = u.w; xa[4] = v.x; xa[5] = v.y; xa[6] = v.z; xa[7] = v.w;
+    };
+    load_b(0);
+    load_a(b0, 0);
+    store_b(0);
+    load_b(1);
+    __syncthreads();
+    for (long long blk = b0; blk < b1; ++blk) {
+        f32x16 acc[8];
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][i] = 0.0f;
+#pragma unroll 1
+        for (int st = 0; st < 16; ++st) {
+            const int buf = st & 1; // (16 steps per block: the buffer parity of step 0 is the same for every block)
+            bf16x8 a0, a1, a2;
+            split3(xa, a0, a1, a2);
+            // the row fragment of the next step (of this block or of the next one)
+            // (unconditional: behind the last step the last block's first fragment is read again and never used -- a load behind a branch
+            // puts its destination registers into scratch memory)
+            {
+                const long long nb = st + 1 < 16 ? blk : (blk + 1 < b1 ? blk + 1 : blk);
+                load_a(nb, (st + 1) & 15);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                const bf16x8 *fp = reinterpret_cast<const bf16x8 *>(s_b[buf]) + (cb * 3) * 64 + lane;
+                const bf16x8 w0 = fp[0], w1 = fp[64], w2 = fp[128];
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w2, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, w0, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc[cb], 0, 0, 0);
+            }
+            // the weight fragments of the next step (the same sixteen for every block): requested a step ago, stored now; the ones
+            // after them requested
+            store_b(buf ^ 1);
+            load_b((st + 2) & 15);
+            lds_barrier();
+        }
+        // out[m][kt * 256 + 32 cb + n]: register i of lane (n, half) is row (i & 3) + 8 (i >> 2) + 4 half of the wave's 32
+        const long long m0 = blk * 256 + 32 * wave;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long long m = m0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+            if (m < a.rows) {
+                float *o = a.out + (size_t)m * a.K + (size_t)kt * kKTile + n;
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb) o[cb * 32] = acc[cb][i];
+            }
+        }
+    }
+}
+
 inline int parts_of(long long rows, int K)
 {
     int n_cu = 256;
@@ -237,6 +355,41 @@ int vfa_grad_weight_f32(const float *g_lin, const float *vox, float *g_w, long l
     int e = (int)hipGetLastError();
     if (e) return e;
     hipLaunchKernelGGL(grad_weight_reduce_kernel, dim3(kN, (unsigned)ktiles), dim3(4 * kKTile), 0, s, a.partial, g_w, K, a.parts, accumulate);
+    return (int)hipGetLastError();
+}
+
+size_t vfa_grad_input_workspace_bytes(int K)
+{
+    if (K <= 0 || K % kKTile != 0) return 0;
+    return (size_t)kN * K * 3 * 2; // the weight as three bf16 planes
+}
+
+int vfa_grad_input_f32(const float *g_lin, const float *w, float *g_vox, long long rows, int K, void *workspace, size_t workspace_bytes,
+                       void *stream)
+{
+    if (rows < 0 || K <= 0) return VFA_ERR_BAD_ARGUMENT;
+    if (K % kKTile != 0) return VFA_ERR_UNSUPPORTED;
+    if (rows == 0) return 0;
+    if (!g_lin || !w || !g_vox || !workspace || workspace_bytes < vfa_grad_input_workspace_bytes(K)) return VFA_ERR_BAD_ARGUMENT;
+    if (((reinterpret_cast<uintptr_t>(g_lin)) & 15) != 0) return VFA_ERR_UNSUPPORTED; // (16-byte loads of the row fragments)
+    hipStream_t s = (hipStream_t)stream;
+    const int ktiles = K / kKTile;
+    uint4 *frag = reinterpret_cast<uint4 *>(workspace);
+    hipLaunchKernelGGL(grad_input_split_kernel, dim3((unsigned)(ktiles * 16 * 8 * 64 / 256)), dim3(256), 0, s, w, frag, K);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    int n_cu = 256;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n_cu = cus;
+    }
+    const long long blocks = (rows + 255) / 256;
+    long long wgs = n_cu / ktiles;
+    if (wgs < 1) wgs = 1;
+    if (wgs > blocks) wgs = blocks;
+    GradXArgs a;
+    a.g_lin = g_lin; a.wfrag = frag; a.out = g_vox; a.rows = rows; a.K = K;
+    hipLaunchKernelGGL(grad_input_kernel, dim3((unsigned)wgs, (unsigned)ktiles), dim3(kThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 

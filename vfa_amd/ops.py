@@ -421,6 +421,27 @@ def grad_weight(g_lin, vox, out=None, accumulate=False):
     return out
 
 
+def grad_input(g_lin, w, out=None):
+    """out (rows, K) = g_lin (rows, 256) . w (256, K): the gradient of ``collapse``'s input (autograd of nn.Linear's input, reference
+    vfa_op.py:123 under trainer.py:41), six bf16 MFMA products of a three-piece split (``vfa_grad_input_f32``)."""
+    _lib.require_device(g_lin, w, out)
+    g_lin, w = _f32c(g_lin), _f32c(w)
+    rows, K = g_lin.shape[0], w.shape[1]
+    assert g_lin.shape[1] == 256 and w.shape[0] == 256 and K % 256 == 0
+    dev = g_lin.device
+    if out is None:
+        out = torch.empty((rows, K), dtype=torch.float32, device=dev)
+    assert tuple(out.shape) == (rows, K) and out.is_contiguous() and out.dtype == torch.float32
+    need = _lib.lib().vfa_grad_input_workspace_bytes(K)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, "x")
+    ws = _grad_w_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _grad_w_ws[key] = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+    _launch("vfa_grad_input_f32", _lib.ptr(g_lin), _lib.ptr(w), _lib.ptr(out), rows, K, _lib.ptr(ws), ws.numel(),
+            _lib.current_stream_handle(), tag=(rows, K))
+    return out
+
+
 def bias_relu_accumulate(lin, bias, out=None, accumulate=False):
     """out (M,N) (+)= sum_v relu(lin[v] + bias) (reference vfa_op.py:124, vfanet.py:82)."""
     _lib.require_device(lin, bias, out)

@@ -442,7 +442,7 @@ class _FusedFrameTrain(torch.autograd.Function):
                     if need_w:
                         ops.grad_weight(g2, vox.view(n * count, nl * C), out=g_w_lm, accumulate=True)
                     if need_lat:
-                        g_vox = torch.matmul(g2, w_lm).view(n, count, nl * C)
+                        g_vox = ops.grad_input(g2, w_lm).view(n, count, nl * C)
                         ops.project_gather_backward(g_vox, tuple(integral.shape), cal, grid_flat, z_layers, corner_off, conv_kind,
                                                     (img_w, img_h), crange, cell_begin=begin, cell_count=count, out=g_int,
                                                     accumulate=True)
