@@ -41,7 +41,7 @@ def timed(fn, reps=10):
 
 
 with torch.no_grad():
-    integrals = [ops.integral_image(l) for l in lats]
+    integrals = ops.integral_images(lats)  # (with the feature statistics of the fp16 split: without them every fused call adds a pass)
     weights = [m.layer_major_weight().contiguous() for m in mods]
     biases = [m.collapse.bias for m in mods]
     ws = ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights)
@@ -70,7 +70,7 @@ with torch.no_grad():
     diag_off = lay["diag"]
     for mask, label in ((0, "full"), (128, "full + stamps"), (384, "stamps of wave 1"), (640, "stamps of wave 2"), (896, "stamps of wave 3"), (1152, "stamps of wave 4"), (1408, "stamps of wave 5"), (1664, "stamps of wave 6"), (1920, "stamps of wave 7"), (129, "no fills + stamps"), (130, "no pool + stamps"), (132, "no mfma + stamps"), (136, "one W + stamps"), (160, "no masked-item term + st"), (168, "no masked term, one W"), (144, "no records + stamps"), (152, "one W, no records + st"), (153, "one W, no rec, no fills"), (1, "no fills"), (2, "no pool"), (4, "no mfma"), (3, "no fills, no pool"),
                         (6, "no pool, no mfma"), (5, "no fills, no mfma"), (7, "skeleton only"), (64, "direct items only")):
-        us = timed(lambda: ops.pool_collapse(integrals, biases, ws, (L, W), out=out, debug=mask))
+        us = timed(lambda: ops.pool_collapse(integrals, biases, ws, (L, W), out=out, debug=mask, absmax=integrals.absmax))
         print(f"  pool_collapse [{label:>18}] {us:8.1f} us")
         if mask & 128:
             torch.cuda.synchronize()
