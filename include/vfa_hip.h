@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VFA_ABI_VERSION 7
+#define VFA_ABI_VERSION 8
 
 /* world-unit conversion of the grid, reference vfa_op.py:23-44 (chosen by args.data) */
 #define VFA_CONV_MULTIVIEWC 0 /* x / 1.0                                   */
@@ -362,7 +362,9 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
  *                          frames, then stop, and every later frame repeats bit for bit.  offsets[18] of
  *                          vfa_pipe_workspace_layout: the state (8 KiB: int bounds[513], launch size, cost signature; at byte
  *                          4096 a u64 cycle count per workgroup), for callers that keep one state per band of a banded frame.
- *                          offsets must hold 19 entries since ABI v5. */
+ *                          offsets must hold 19 entries since ABI v5, 22 since ABI v8: offsets[19 + k] = the sliver shifts of
+ *                          scale k, one unsigned per tile (binary places the fp16 operand split of the frame kernel gives up for
+ *                          the noisiest visible box of (tile, scale): 0 everywhere but next to boxes of ~1e-5 pixels). */
 size_t vfa_pipe_workspace_bytes(int n_views, int L, int W, int n_layers, int n_scales);
 int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_scales, size_t *offsets, int *tiles);
 int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off, int n_views,

@@ -340,7 +340,7 @@ def test_pipe_box_records_match_the_box_parameter_kernel(name, n_cam, crop, orig
     lay = ops.pipe_workspace_layout(n, L, W, nl, ns)
     tl_n, tw_n = lay["tiles_l"], lay["tiles_w"]
     tiles = tl_n * tw_n
-    seen_direct = 0
+    seen_direct = seen_shift = 0
     for s, (Hf, Wf) in enumerate(sizes):
         box, area, vis = ops.box_params(calibs, grid.reshape(-1, 3), zl, co, kind, img_wh, (Hf, Wf))
         box = box.cpu().numpy().reshape(n, nl, L, W, 4)
@@ -356,6 +356,16 @@ def test_pipe_box_records_match_the_box_parameter_kernel(name, n_cam, crop, orig
         rcp = (np.float32(1) / area).view(np.uint32)
         assert np.array_equal(g[..., 4][vis], rcp[vis]), f"scale {s}: 1 / area"
         assert (g[..., 4][~vis & (area == area)] == 0).all(), f"scale {s}: the factor of a masked box is 0"
+        assert np.array_equal(g[..., 10][vis], area.view(np.uint32)[vis]), f"scale {s}: area (the divisor of the exact quotient)"
+        # sliver shift of (tile, scale): the largest over views, layers and visible boxes of floor(log2(1/4 + 2^-18 Hf Wf / area)) + 1
+        bound = np.float32(0.25) + (np.float32(Hf) * np.float32(Wf) * np.float32(2.0 ** -18)) / area
+        sh = np.where(vis & (bound >= 1), np.floor(np.log2(np.maximum(bound, 1).astype(np.float64))).astype(np.int64) + 1, 0)
+        pad = np.zeros((n, nl, tl_n * 4, tw_n * 8), np.int64)
+        pad[:, :, :L, :W] = sh
+        want_shift = pad.reshape(n, nl, tl_n, 4, tw_n, 8).max(axis=(0, 1, 3, 5)).reshape(-1)
+        got_shift = host[lay["shifts"][s]:lay["shifts"][s] + tiles * 4].view(np.uint32).astype(np.int64)
+        assert np.array_equal(got_shift, want_shift), f"scale {s}: sliver shifts"
+        seen_shift += int((want_shift > 0).sum())
 
         def axis(coord, size):  # vfa_geom.h make_axis: X = fma(g + 1, size / 2, -0.5) (one rounding), i0 = floor(X), hi = X - i0
             x = (np.float32(coord) + np.float32(1)).astype(np.float64) * (size / 2.0) - 0.5
@@ -386,7 +396,7 @@ def test_pipe_box_records_match_the_box_parameter_kernel(name, n_cam, crop, orig
         y = np.where(srow < top[..., None], t0[..., None] + srow, b0[..., None] + (srow - top[..., None]))
         assert np.array_equal(y[sel], want_y[sel]) and np.array_equal((cols + x0[..., None])[sel], want_x[sel]), f"scale {s}: window taps"
         assert ((rows + cols)[sel] < h[..., 1][..., None][sel]).all(), f"scale {s}: a tap outside its window"
-    print(f"[records] {name}: {seen_direct} visible boxes in tiles pooled straight from L2")
+    print(f"[records] {name}: {seen_direct} visible boxes in tiles pooled straight from L2, {seen_shift} (tile, scale) pairs with a sliver shift")
 
 
 def test_pipe_balance_minimises_the_heaviest_share(monkeypatch):

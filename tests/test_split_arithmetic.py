@@ -98,7 +98,7 @@ def test_six_term_product_is_sgemm_class(K):
 # ---------------------------------------------------------------------------------------------------------------------------
 # the default arithmetic of the fused frame kernels: two fp16 pieces per operand with a power-of-two scale (vfa_split.h)
 # ---------------------------------------------------------------------------------------------------------------------------
-EXP_A, EXP_W, EXP_LIM = 14, 14, 40  # vfa_split.h: kExpA, kExpW, kExpLim
+EXP_A, EXP_W, EXP_LIM = 13, 14, 40  # vfa_split.h: kExpA, kExpW, kExpLim
 
 
 def split_exponent(absmax, target):
@@ -127,14 +127,14 @@ def split16(x, e):
 
 def test_fp16_split_is_exact_to_two_fp16_mantissas_over_the_range_of_the_scale():
     """x 2^e = hi + lo + r with |r| <= 2^-23 |x 2^e| wherever lo is a normal fp16 number, and |r| <= 2^-25 (half a subnormal step)
-    below that: with the maximum at 2^14 every element down to 2^-14 of it keeps 22 bits, whatever the magnitude of the map."""
+    below that: with the maximum at 2^13 (kExpA) every element down to 2^-13 of it keeps 22 bits, whatever the magnitude of the map."""
     rng = np.random.default_rng(0)
     for mag in (1.0, 1e4, 1e-6, 1e-7, 1e8):  # (|e| <= 40: maxima from 2^-26 to 2^54)
         x = (rng.standard_normal(100000) * 10.0 ** rng.uniform(-4, 0, 100000) * mag).astype(np.float32)
         e = split_exponent(np.abs(x).max(), EXP_A)
         hi, lo = split16(x, e)
         s = x.astype(np.float64) * 2.0 ** e
-        assert 2.0 ** 14 <= np.abs(s).max() < 2.0 ** 15
+        assert 2.0 ** EXP_A <= np.abs(s).max() < 2.0 ** (EXP_A + 1)
         r = s - hi.astype(np.float64) - lo.astype(np.float64)
         assert np.all(np.abs(r) <= np.maximum(2.0 ** -23 * np.abs(s), 2.0 ** -25)), mag
         big = np.abs(s) >= 1.0  # 2^-14 of the maximum and up

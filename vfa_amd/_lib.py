@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFA_AMD_LIB") or os.path.join(_HERE, "csrc", "libvfa_hip.so")  # (override: A/B runs of two builds)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 CONV_KIND = {"MultiviewC": 0, "MultiviewX": 1, "Wildtrack": 2}
 VOX_REFERENCE, VOX_LAYER_MAJOR = 0, 1

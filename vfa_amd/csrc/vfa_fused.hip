@@ -52,6 +52,7 @@ constexpr int kSteps = kC / 16;                                     // k-steps o
 constexpr int kVis = 1, kCont = 1 << 8; // bits 1-2 DXC, bits 3-4 DYC; kCont: same tap set as the previous box of the 4-box chunk
 // tile header flags
 constexpr int kTileLive = 1, kTileDirect = 2, kTileRows = 4; // kTileRows: a direct item whose pooled rows the pre-pass leaves in the workspace (header word 2 = its slot there)
+constexpr int kTileShiftAt = 8; // bits 8-15: the item's sliver shift (vfa_geom.h): binary places its voxel features are scaled down by in the fp16 split
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -127,11 +128,14 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
         constexpr int kBig = 1 << 20;
         int x0 = vis ? min(xs[0], xs[2]) : kBig, x1 = vis ? max(xs[1], xs[3]) : -kBig;
         int t0 = vis ? ys[0] : kBig, t1 = vis ? ys[1] : -kBig, b0 = vis ? ys[2] : kBig, b1 = vis ? ys[3] : -kBig;
+        // binary places the fp16 split of the item gives up for its noisiest visible box (vfa_geom.h: sliver_shift; 0 for honest boxes)
+        int shift = vis ? sliver_shift(area, Hf, Wf) : 0;
 #pragma unroll
         for (int m = 1; m < 32; m <<= 1) {
             x0 = min(x0, __shfl_xor(x0, m, 32)); x1 = max(x1, __shfl_xor(x1, m, 32));
             t0 = min(t0, __shfl_xor(t0, m, 32)); t1 = max(t1, __shfl_xor(t1, m, 32));
             b0 = min(b0, __shfl_xor(b0, m, 32)); b1 = max(b1, __shfl_xor(b1, m, 32));
+            shift = max(shift, __shfl_xor(shift, m, 32));
         }
         const unsigned long long vis_all = __ballot(vis), live_all = __ballot(live_box);
         const bool any_vis = ((vis_all >> (32 * half)) & 0xffffffffull) != 0ull;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
             if (b == 0) {
                 uint4 *hdr = reinterpret_cast<uint4 *>(a.hdrs[s] + ((size_t)view * a.n_tiles + tile) * kHdrBytes);
                 const int inv = cwid > 0 ? (65536 + cwid - 1) / cwid : 0; // floor(s / cwid) == (s * inv) >> 16 for s < 128
-                unsigned hflags = (any_live ? kTileLive : 0) | (direct ? kTileDirect : 0), word2 = (unsigned)cwid;
+                unsigned hflags = (any_live ? kTileLive : 0) | (direct ? kTileDirect : 0) | ((unsigned)shift << kTileShiftAt), word2 = (unsigned)cwid;
                 if (any_live) atomicOr(a.live[s] + tile, 1u << view);
                 if (any_live && direct) {
                     atomicOr(a.direct[s] + tile, 1u << view);
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
 
     // fp16 form: per scale, the factor 2^ea of the voxel features (from the largest |feature| the integral-image kernels saw) and
     // 2^(ea + ew) / 2^-(ea + ew) for the bias in the accumulator / the epilogue (powers of two: exact)
-    float f_a[kMaxScales] = {1.0f, 1.0f, 1.0f}, f_fwd[kMaxScales] = {1.0f, 1.0f, 1.0f}, f_inv[kMaxScales] = {1.0f, 1.0f, 1.0f};
+    float f_a[kMaxScales] = {1.0f, 1.0f, 1.0f}, f_a_inv[kMaxScales] = {1.0f, 1.0f, 1.0f}, f_fwd[kMaxScales] = {1.0f, 1.0f, 1.0f}, f_inv[kMaxScales] = {1.0f, 1.0f, 1.0f};
     if constexpr (F16) {
         __shared__ unsigned s_amax[kMaxScales];
         if (tid < kMaxScales) s_amax[tid] = 0u;
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         for (int s2 = 0; s2 < kMaxScales; ++s2) {
             if (s2 < a.n_scales) {
                 const int ea = split_exponent((unsigned)uniform_i((int)s_amax[s2]), kExpA), ew = uniform_i(a.wexp[s2]);
-                f_a[s2] = pow2f(ea); f_fwd[s2] = pow2f(ea + ew); f_inv[s2] = pow2f(-(ea + ew));
+                f_a[s2] = pow2f(ea); f_a_inv[s2] = pow2f(-ea); f_fwd[s2] = pow2f(ea + ew); f_inv[s2] = pow2f(-(ea + ew));
             }
         }
     }
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         const int cl = tl * kTileL + (row >> 3), cw = tw * kTileW + (row & 7);
         if (cl < a.L && cw < a.W) *reinterpret_cast<float4 *>(a.out + (size_t)(cl * a.W + cw) * kC + 4 * c4) = v;
     };
-    auto pool = [&](const Item &it, int it_flags, int it_word1, float s_a) {
+    auto pool = [&](const Item &it, int it_flags, int it_word1, float s_a, float s_a_inv) {
         if (!DIRECT && (it_flags & kTileRows)) {
             // a direct item of the main launch: its pooled rows arrived as its window (slot b = row of box b); only the
             // split remains
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             for (int q = 0; q < 4; ++q) {
                 float4 v = s_taps[(4 * wave + grp) * 64 + q * 16 + cq];
                 if (DIAG && (a.debug & kDbgDumpVox)) dump_vox(it.tile, 4 * wave + grp, q * 16 + cq, v);
-                if constexpr (F16) v = mul4(v, s_a);
+                if constexpr (F16) v = mul4(v, s_a); // (the pre-pass divided exactly: box_mean)
                 store_quad<F16>(s_planes, 4 * wave + grp, q * 16 + cq, v);
             }
             return;
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
                               __uint_as_float(rec.v[1].x), __uint_as_float(rec.v[1].y), __uint_as_float(rec.v[1].z), __uint_as_float(rec.v[1].w),
                               __uint_as_float(rec.v[2].x), __uint_as_float(rec.v[2].y), __uint_as_float(rec.v[2].z), __uint_as_float(rec.v[2].w),
                               __uint_as_float(rec.v[3].x), __uint_as_float(rec.v[3].y), __uint_as_float(rec.v[3].z), __uint_as_float(rec.v[3].w)};
-        const float rcp = __uint_as_float(rec.v[4].x), masked = __uint_as_float(rec.v[5].z);
+        const float rcp = __uint_as_float(rec.v[4].x), masked = __uint_as_float(rec.v[5].z), area = __uint_as_float(rec.v[5].w);
         const bool vis = (rec.v[4].y & (unsigned)kVis) != 0u;
         // tap positions in float4 units (LDS: slot inside the window; DIRECT: pixel inside the view's padded image): row part +
         // column part.  The coordinates of a masked box are meaningless: point them at slot / pixel 0 (the value is discarded).
@@ -778,19 +782,20 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         // a masked box reads slot / pixel 0 (finite) and multiplies by its masked value (0, or NaN for a NaN box) instead of
         // selecting afterwards; the A-plane address of quarter q is that of quarter 0 with one bit pair flipped
         // (((8 q + a) ^ r) << 4 = ((a ^ r) << 4) ^ (q << 7) for a < 8): both keep VALU work out of the quarter passes
-        // (fp16 form: times 2^ea -- a power of two, so v * (rcp 2^ea) = (v * rcp) 2^ea exactly)
-        const float scale = F16 ? (vis ? rcp : masked) * s_a : (vis ? rcp : masked);
+        // The quotient is the reference's correctly rounded division (vfa_op.py:118-119) times the item's power of two 2^(ea - shift)
+        // of the fp16 split (1 in the bf16 forms): box_quotient_scaled with rs = RN(1 / area) 2^k, as = area 2^-k (vfa_geom.h).
+        const float rs = (vis ? rcp : masked) * s_a, as = area * s_a_inv;
         const int plane0 = row * kRowBytes + (((((cq >> 1) ^ (row & 15)) << 4)) | ((cq & 1) << 3));
         auto finish = [&](int q, float4 lt, float4 rb, float4 rt, float4 lb) {
-            // (((lt + rb) - rt) - lb) * RN(1 / area)                                              (A.6)
+            // RN((((lt + rb) - rt) - lb) / area)                                                  (A.6)
             float4 v = make_float4(lt.x + rb.x, lt.y + rb.y, lt.z + rb.z, lt.w + rb.w);
             v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
             v = make_float4(v.x - lb.x, v.y - lb.y, v.z - lb.z, v.w - lb.w);
-            if (DIAG && (a.debug & kDbgDumpVox)) { // (the same product without the power-of-two factor of the fp16 split: the same bits / 2^ea)
-                const float sc0 = vis ? rcp : masked;
-                dump_vox(it.tile, row, q * 16 + cq, make_float4(v.x * sc0, v.y * sc0, v.z * sc0, v.w * sc0));
-            }
-            store_quad_at<F16>(s_planes, plane0 ^ (q << 7), make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale));
+            v = make_float4(box_quotient_scaled(v.x, as, rs), box_quotient_scaled(v.y, as, rs), box_quotient_scaled(v.z, as, rs),
+                            box_quotient_scaled(v.w, as, rs));
+            if (DIAG && (a.debug & kDbgDumpVox)) // (without the power-of-two factor of the fp16 split: the same bits / 2^k)
+                dump_vox(it.tile, row, q * 16 + cq, make_float4(v.x * s_a_inv, v.y * s_a_inv, v.z * s_a_inv, v.w * s_a_inv));
+            store_quad_at<F16>(s_planes, plane0 ^ (q << 7), v);
         };
         if constexpr (DIRECT) {
 #pragma unroll 1
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     Item nxt = seek(cur.tile, cur.scale, cur.rest, cur.rank + 1);
     if (nxt.valid) header_of(nxt, hbuf);
     int w_scale = -1;
-    float bc = 0.0f, sa_cur = 1.0f, inv_cur = 1.0f;
+    float bc = 0.0f, sa_cur = 1.0f, sa_inv_cur = 1.0f, inv_cur = 1.0f;
     f32x16 sum;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sum[i] = 0.0f;
@@ -965,12 +970,15 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         if (cur.scale != w_scale && !((dbg & kDbgOneW) && w_scale >= 0)) { // W and bias of this scale: land while the boxes are pooled
             load_weights(cur.scale);
             bc = bias_of(cur.scale);
-            if constexpr (F16) { bc *= pick(f_fwd, cur.scale); sa_cur = pick(f_a, cur.scale); inv_cur = pick(f_inv, cur.scale); }
+            if constexpr (F16) { bc *= pick(f_fwd, cur.scale); sa_cur = pick(f_a, cur.scale); sa_inv_cur = pick(f_a_inv, cur.scale); inv_cur = pick(f_inv, cur.scale); }
             w_scale = cur.scale;
         }
         // (the conversions of the fp16 split saturate instead of overflowing; the MFMAs below need the default mode: vfa_split.h)
+        // the item's own power of two: 2^ea of its scale, less the binary places its noisiest box asks for (header bits 8-15: sliver_shift)
+        const int shift = F16 ? (cur_flags >> kTileShiftAt) & 0xff : 0;
+        const float up = pow2f(shift), down = pow2f(-shift);
         if constexpr (F16) fp16_saturate_mode(true);
-        if (!(dbg & kDbgNoPool)) pool(cur, cur_flags, cur_word1, sa_cur);
+        if (!(dbg & kDbgNoPool)) pool(cur, cur_flags, cur_word1, sa_cur * down, sa_inv_cur * up);
         if constexpr (F16) fp16_saturate_mode(false);
         tick(3);
         // W, the bias and the tile stores of `flush` were issued a pooling pass ago.  Waiting for them HERE, explicitly, is
@@ -993,7 +1001,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         // chains buy nothing and their registers are better spent on running the A fragments ahead of the MFMAs
         f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = bc; // (the bias rides in the accumulator)
+        for (int i = 0; i < 16; ++i) acc[i] = bc * down; // (the bias rides in the accumulator, in the item's units)
         if (!(dbg & kDbgNoMfma)) {
             int key2 = key, fb = frag_base; // (opaque: keeps the 16 swizzled fragment offsets out of long-lived registers)
             asm volatile("" : "+v"(key2), "+v"(fb));
@@ -1040,7 +1048,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         rest_fills(); // windows of more than 64 slots
 #pragma unroll
         for (int i = 0; i < 16; ++i) { // vfa_op.py:124; vfanet.py:79, 82
-            if constexpr (F16) sum[i] = fmaf(relu_t(acc[i]), inv_cur, sum[i]); // (relu(acc) 2^-(ea+ew) is exact: the same bits as multiply, then add)
+            if constexpr (F16) sum[i] = fmaf(relu_t(acc[i]), inv_cur * up, sum[i]); // (relu(acc) 2^-(ea+ew-shift) is exact: the same bits as multiply, then add)
             else sum[i] = sum[i] + relu_t(acc[i]);
         }
         tick(6);

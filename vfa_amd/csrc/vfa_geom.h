@@ -130,5 +130,34 @@ __device__ __forceinline__ float box_mean(float lt, float rb, float rt, float lb
     return fmaf(fmaf(-area, q1, v), rcp, q1);
 }
 
+// The same quotient with a power of two folded in (the fused frame kernels: the fp16 operand split wants v / area * 2^k):
+// rs = RN(1 / area) 2^k and as = area 2^-k are exact scalings, every intermediate is 2^k times the one of `box_mean`, so the
+// result is RN(v / area) 2^k bit for bit (no intermediate leaves the normal range for |k| <= 80 on feature maps).
+// A masked box passes rs = its masked value (0, or NaN for a NaN box): q0 = 0, the residuals multiply by 0 -> 0 (or NaN).
+__device__ __forceinline__ float box_quotient_scaled(float v, float as, float rs)
+{
+    const float q0 = v * rs;
+    const float q1 = fmaf(fmaf(-as, q0, v), rs, q0);
+    return fmaf(fmaf(-as, q1, v), rs, q1);
+}
+
+// How far rounding noise can lift a voxel feature above the feature map's largest value (the fp16 operand split of the fused
+// kernels, vfa_split.h, needs a bound on |vox| before pooling).  vox = N / area with N = ((lt + rb) - rt) - lb (vfa_op.py:
+// 118-119), area = 4 x pixel area + 1e-6 (:104-105).  In exact arithmetic |N| <= absmax x pixel area, i.e. |N / area| <= absmax / 4.
+// In fp32, with u = 2^-24 and S = sum |feature| <= absmax Hf Wf:  an integral-image entry is off by <= 2 u S (two cumsums, each
+// element rounded once: vfa_op.py:172-173), a bilinear sample by <= 8 u S (its taps, its rounded weights, its four roundings),
+// the combination by <= 6 u S more:  |error of N| <= 38 u S < 2^-18 S.  So
+//     |vox| / absmax  <=  1/4 + 2^-18 Hf Wf / area              (an honest box: ~1/4; a sliver of area 1e-5 on a 90 x 160 map: 5 500)
+// and the reference KEEPS such slivers (visible = area > 1e-6, :106).  `sliver_shift` is the number of binary places the
+// frame kernels take out of a (tile, view, scale) item that holds such a box -- 0 unless the bound reaches 1, else
+// floor(log2(bound)) + 1 -- so that the scaled voxel features of the item stay below 2^(kExpA + 1) whatever the noise does.
+__device__ __forceinline__ int sliver_shift(float area, int Hf, int Wf)
+{
+    const float bound = 0.25f + ((float)Hf * (float)Wf * 0x1p-18f) / area;
+    if (!(bound >= 1.0f)) return 0; // (also a NaN area: such a box is not visible)
+    const int e = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 127 + 1;
+    return e > 48 ? 48 : e;
+}
+
 } // namespace vfa_dev
 #endif // VFA_GEOM_H

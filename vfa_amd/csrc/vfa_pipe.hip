@@ -101,6 +101,7 @@ struct RecordArgs {
     ScaleDims dims[kMaxScales];
     unsigned *live[kMaxScales];      // (n_tiles) bit v = view v has a live box in the tile, in any layer
     unsigned *globs;                 // (n_tiles) live (view, layer, scale) items whose tap window does not fit LDS
+    unsigned *shift[kMaxScales];     // (n_tiles) sliver shift of (tile, scale): the largest over its views, layers and visible boxes (vfa_geom.h)
     unsigned char *hdrs[kMaxScales];
     unsigned char *recs[kMaxScales];
 };
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
     const float *P = a.g.calibs + (size_t)view * 12;
     const float g0 = a.g.grid[cell * 3 + 0], g1 = a.g.grid[cell * 3 + 1], g2 = a.g.grid[cell * 3 + 2];
     bool live_any[kMaxScales] = {false, false, false};
+    int shift_max[kMaxScales] = {0, 0, 0};
     unsigned n_glob = 0;
 #pragma unroll 1
     for (int layer = 0; layer < a.nl; ++layer) {
@@ -152,12 +154,15 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
             constexpr int kBig = 1 << 20;
             int x0 = vis ? min(xs[0], xs[2]) : kBig, x1 = vis ? max(xs[1], xs[3]) : -kBig;
             int t0 = vis ? ys[0] : kBig, t1 = vis ? ys[1] : -kBig, b0 = vis ? ys[2] : kBig, b1 = vis ? ys[3] : -kBig;
+            int shift = vis ? sliver_shift(area, Hf, Wf) : 0; // (binary places the fp16 split gives up for a noise-dominated box: vfa_geom.h)
 #pragma unroll
             for (int m = 1; m < 32; m <<= 1) {
                 x0 = min(x0, __shfl_xor(x0, m, 32)); x1 = max(x1, __shfl_xor(x1, m, 32));
                 t0 = min(t0, __shfl_xor(t0, m, 32)); t1 = max(t1, __shfl_xor(t1, m, 32));
                 b0 = min(b0, __shfl_xor(b0, m, 32)); b1 = max(b1, __shfl_xor(b1, m, 32));
+                shift = max(shift, __shfl_xor(shift, m, 32));
             }
+            shift_max[s] = max(shift_max[s], shift);
             const unsigned long long vis_all = __ballot(vis), live_all = __ballot(live_box);
             const bool any_vis = ((vis_all >> (32 * half)) & 0xffffffffull) != 0ull;
             const bool any_live = ((live_all >> (32 * half)) & 0xffffffffull) != 0ull;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
                 const float rcp = 1.0f / area; // correctly rounded
                 st[0] = make_uint4(__float_as_uint(xl.hi), __float_as_uint(xr.hi), __float_as_uint(yt.hi), __float_as_uint(yb.hi));
                 st[1] = make_uint4(__float_as_uint(vis ? rcp : masked), vis ? (unsigned)kVis : 0u, rows[0] | (rows[1] << 16), rows[2] | (rows[3] << 16));
-                st[2] = make_uint4(cols[0] | (cols[1] << 16), cols[2] | (cols[3] << 16), 0u, 0u);
+                st[2] = make_uint4(cols[0] | (cols[1] << 16), cols[2] | (cols[3] << 16), __float_as_uint(area), 0u);
             }
             __syncthreads(); // (one wave: orders the LDS writes above against the reads below)
             if (pair_ok) {
@@ -216,6 +221,10 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
     if (pair_ok && b == 0)
         for (int s = 0; s < a.n_scales; ++s)
             if (live_any[s]) atomicOr(a.live[s] + tile, 1u << view);
+    // (the accumulators of a (tile, scale) run over all layers and, inside a group, over its views: one shift for all of them)
+    if (pair_ok && b == 0)
+        for (int s = 0; s < a.n_scales; ++s)
+            if (shift_max[s] > 0) atomicMax(a.shift[s] + tile, (unsigned)shift_max[s]);
     if (pair_ok && b == 0 && n_glob) atomicAdd(a.globs + tile, n_glob);
 }
 
@@ -351,6 +360,7 @@ struct PipeScale {
     const float *bias;              // (256) or NULL
     const uint4 *wfrag;             // pipe_split_weight_kernel output
     const unsigned *live;           // (n_tiles)
+    const unsigned *shift;          // (n_tiles) sliver shift of (tile, scale): pipe_records_kernel
     const unsigned char *hdrs, *recs;
     int Hf, Wf;
     const unsigned *amax;           // amax_n partial maxima of |feature| (fp32 bits): the scale of the fp16 split (vfa_split.h)
@@ -437,7 +447,8 @@ __device__ __forceinline__ float4 as_float4(f32x4 v) { return make_float4(v[0], 
 // taps in flight at 128 registers
 struct LaneBox {
     float wt[16];
-    float scl;
+    float scl, asc; // RN(1 / area) 2^k (or the masked value) and area 2^-k: box_quotient_scaled (vfa_geom.h); k = ea - shift (fp16 form), else 0
+    float back;     // 2^-k (diagnostic dump only)
     unsigned rowb[4], colb[4];
 };
 
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     __shared__ __align__(16) unsigned char s_rec1[2 * kTileBoxes * kRecBytes];
     __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
     __shared__ unsigned s_misc[16];
-    // per scale: integral, recs, wfrag, hdrs (lo, hi each), Hf, Wf | (ea + 64) << 16, nl * n_views, n_views; fp16 form: 2^(ea+ew), 2^-(ea+ew)
+    // per scale: integral, recs, wfrag, hdrs (lo, hi each), Hf, Wf | (ea + 128) << 16, nl * n_views, n_views; fp16 form: 2^(ea+ew), 2^-(ea+ew)
     __shared__ __align__(16) unsigned s_sc[kMaxScales][16];
     __shared__ unsigned s_amax[kMaxScales];
     // phase records (table wave): [phase & 3]{tile, views, w, -, then the 12 constants of the phase's scale (s_sc)}: whoever builds
@@ -597,7 +608,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         d[12] = d[13] = pow2_bits(0);
         if constexpr (F16) {
             const int ea = split_exponent(s_amax[s3], kExpA), ew = a.wexp[s3];
-            d[9] |= (unsigned)(ea + 64) << 16; // (Wf <= 65533: vfa_pipe_boxes_f32)
+            d[9] |= (unsigned)(ea + 128) << 16; // (Wf <= 65533: vfa_pipe_boxes_f32)
             d[12] = pow2_bits(ea + ew); d[13] = pow2_bits(-(ea + ew));
         }
     }
@@ -646,8 +657,9 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 
         // A phase record (LDS, written by wave 0): tile, the views of the group, w = scale | layer << 2 | nj << 15 | more << 20
         struct PhaseRec {
-            int tile; unsigned views, w;
+            int tile; unsigned views, w, sh;
             __device__ __forceinline__ bool valid() const { return tile >= 0; }
+            __device__ __forceinline__ int shift() const { return (int)sh; } // sliver shift of (tile, scale): fp16 form only, else 0
             __device__ __forceinline__ int scale() const { return (int)(w & 3u); }
             __device__ __forceinline__ int layer() const { return (int)((w >> 2) & 1023u); }
             __device__ __forceinline__ int nj() const { return (int)((w >> 15) & 7u); }
@@ -658,6 +670,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
             PhaseRec p;
             p.tile = uniform_i((int)v.x); p.views = (unsigned)uniform_i((int)v.y); p.w = (unsigned)uniform_i((int)v.z);
+            p.sh = F16 ? (unsigned)uniform_i((int)v.w) : 0u;
             return p;
         };
         // output rows of a tile: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 block, column r
@@ -728,6 +741,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const unsigned m0 = on ? (a.sc[0].live[t] & view_mask) : 0u;
             const unsigned m1 = (on && a.n_scales > 1) ? (a.sc[1].live[t] & view_mask) : 0u;
             const unsigned m2 = (on && a.n_scales > 2) ? (a.sc[2].live[t] & view_mask) : 0u;
+            const unsigned sh0 = (F16 && on) ? a.sc[0].shift[t] : 0u, sh1 = (F16 && on && a.n_scales > 1) ? a.sc[1].shift[t] : 0u,
+                           sh2 = (F16 && on && a.n_scales > 2) ? a.sc[2].shift[t] : 0u; // (fp16 split: the sliver shift of (tile, scale))
             const int gt = groups_of(m0) + groups_of(m1) + groups_of(m2);
             const int lo = t == t_begin ? k_begin : 0;
             const int hi = min(t == t_end ? k_end : gt, gt);
@@ -757,7 +772,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                         }
                         if (r >= lo && r < hi) {
                             const unsigned w = (unsigned)s2 | ((unsigned)nj << 15) | (r + 1 < hi ? 1u << 20 : 0u);
-                            *reinterpret_cast<uint4 *>(&s_groups[(base + r) & (kGroupRing - 1)][0]) = make_uint4((unsigned)t, views, w, 0u);
+                            *reinterpret_cast<uint4 *>(&s_groups[(base + r) & (kGroupRing - 1)][0]) =
+                                make_uint4((unsigned)t, views, w, s2 == 0 ? sh0 : (s2 == 1 ? sh1 : sh2));
                         }
                         ++r;
                     }
@@ -775,7 +791,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const bool end = uniform_i((int)g.x) < 0;
             {
                 const unsigned sc_w = s_sc[g.z & 3u][lane >= 4 && lane < 16 ? lane - 4 : 0];
-                const unsigned w0 = lane == 0 ? g.x : (lane == 1 ? g.y : (lane == 2 ? (g.z | ((unsigned)gen_layer << 2)) : 0u));
+                const unsigned w0 = lane == 0 ? g.x : (lane == 1 ? g.y : (lane == 2 ? (g.z | ((unsigned)gen_layer << 2)) : g.w));
                 if (lane < 16) s_phase[n & 3][lane] = lane < 4 ? w0 : sc_w;
             }
             if (!end && ++gen_layer == a.nl) { gen_layer = 0; ++gen_next; }
@@ -809,7 +825,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const int view = (int)((v.y >> (8 * jj)) & 0xffu);
             const unsigned flags = hd.x, n_slots = hd.y;
             const int Hf = (int)c2.x, Wf = (int)(c2.y & 0xffffu);
-            const unsigned ea64 = c2.y & 0xffff0000u; // (fp16 form: the exponent of the scale's voxel-feature factor, + 64, in the upper half)
+            // (fp16 form: the exponent of the phase's voxel-feature factor 2^(ea - shift), + 128, in the upper half)
+            const unsigned ea64 = (c2.y & 0xffff0000u) - (F16 ? v.w << 16 : 0u);
             const unsigned long long item = (unsigned long long)((unsigned)tile * c2.z + (unsigned)layer * c2.w + (unsigned)view);
             const unsigned long long img = ((unsigned long long)c0.y << 32 | c0.x) +
                                            (unsigned long long)view * (unsigned)((Hf + 2) * (Wf + 2)) * kSlotBytes + (unsigned)(q * kQSlot);
@@ -895,7 +912,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 // The bias rides in the accumulator: at the first step of a group both accumulators of the set restart from it.  A
                 // SELECT (on the first quarter of every layer), not an assignment under `grp_first`: the assignment made the
                 // allocator keep the old and the new accumulators in different registers and copy all 32 at the join.
-                const float b0 = ph.scale() == 0 ? bc[0] : (ph.scale() == 1 ? bc[1] : bc[2]);
+                const float b0 = (ph.scale() == 0 ? bc[0] : (ph.scale() == 1 ? bc[1] : bc[2])) * pow2f(-ph.shift()); // (in the group's units)
                 int first = grp_first ? 1 : 0;
                 asm volatile("" : "+v"(first)); // (opaque: keeps the compiler from turning the selects back into that assignment)
                 f32x16 bv;
@@ -1009,7 +1026,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         auto group_end = [&](const PhaseRec &ph) {
             float *slot = a.partial + (((size_t)lb * 3 + 2) * 8 + wave) * 16 * 64 + lane;
             const bool three = ph.nj() > 2, four = ph.nj() > 3, more = ph.more(), open = tile_open;
-            const float inv = inv_of(ph.scale());
+            const float inv = inv_of(ph.scale()) * pow2f(ph.shift()); // 2^-(ea + ew - shift): back to the map's units
             if constexpr (SMALL) { // tile = s + (r0 + r1): the association of the eight-step form for a group of one or two views
                 const bool two = ph.nj() > 1;
 #pragma unroll
@@ -1061,7 +1078,13 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const bool vis = (rv[1].y & (unsigned)kVis) != 0u;
             // a masked box reads slot / pixel 0 (finite) and multiplies by its masked value (0, or NaN for a NaN box)
             bx.scl = __uint_as_float(rv[1].x);
-            if constexpr (F16) bx.scl *= pow2f((int)(wp >> 16) - 64); // times 2^ea: a power of two, v * (rcp 2^ea) = (v * rcp) 2^ea exactly
+            bx.asc = __uint_as_float(rv[2].z);
+            bx.back = 1.0f;
+            if constexpr (F16) { // times 2^k, k = ea - shift: powers of two, the quotient comes out as RN(v / area) 2^k exactly
+                const int k2 = (int)(wp >> 16) - 128;
+                bx.scl *= pow2f(k2); bx.asc *= pow2f(-k2);
+                if constexpr (DIAG) bx.back = pow2f(-k2);
+            }
             wp &= 0xffffu;
             unsigned rw[4] = {rv[1].z & 0xffffu, rv[1].z >> 16, rv[1].w & 0xffffu, rv[1].w >> 16};
             unsigned cl[4] = {rv[2].x & 0xffffu, rv[2].x >> 16, rv[2].y & 0xffffu, rv[2].y >> 16};
@@ -1134,15 +1157,16 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     wait4(W0{}, d0, d1, d2, d3);
                     lb2 = sample4(as_float4(d0), as_float4(d1), as_float4(d2), as_float4(d3), bx.wt[12], bx.wt[13], bx.wt[14], bx.wt[15]);
                 }
-                // (((lt + rb) - rt) - lb) * RN(1 / area)                                              (A.6)
+                // RN((((lt + rb) - rt) - lb) / area)  (times the phase's power of two)                  (A.6)
                 float4 v = make_float4(lt.x + rb.x, lt.y + rb.y, lt.z + rb.z, lt.w + rb.w);
                 v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
                 v = make_float4(v.x - lb2.x, v.y - lb2.y, v.z - lb2.z, v.w - lb2.w);
-                const float xs[4] = {v.x * bx.scl, v.y * bx.scl, v.z * bx.scl, v.w * bx.scl};
+                const float xs[4] = {box_quotient_scaled(v.x, bx.asc, bx.scl), box_quotient_scaled(v.y, bx.asc, bx.scl),
+                                     box_quotient_scaled(v.z, bx.asc, bx.scl), box_quotient_scaled(v.w, bx.asc, bx.scl)};
                 if (DIAG && (a.debug & kDbgDumpVox)) { // (one view: sub-tile 0 of set 0; the power-of-two factor of the fp16 split taken out again: exact)
                     const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w, brow = phalf * 16 + pb;
                     const int cl = tl * kTileL + (brow >> 3), cw = tw * kTileW + (brow & 7);
-                    const float back = F16 ? pow2f(64 - (int)(s_sc[0][9] >> 16)) : 1.0f;
+                    const float back = bx.back;
                     if (x == 0 && cl < a.L && cw < a.W)
                         *reinterpret_cast<float4 *>(a.out + (size_t)(cl * a.W + cw) * kC + quarter_of(k) * 64 + (int)piece * 16 + pi * 4) =
                             make_float4(xs[0] * back, xs[1] * back, xs[2] * back, xs[3] * back);
@@ -1574,7 +1598,7 @@ __global__ __launch_bounds__(kMaxBlocks) void pipe_balance_kernel(int *bal, cons
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PipeLayout {
-    size_t live[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, costs, partial, diag, balance, wmax, wexp, amax, total;
+    size_t live[kMaxScales], shifts[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, costs, partial, diag, balance, wmax, wexp, amax, total;
     int tiles_l, tiles_w, n_tiles;
 };
 inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
@@ -1586,6 +1610,10 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
     size_t off = 0;
     for (int s = 0; s < kMaxScales; ++s) { // view masks and tickets first, contiguous: zeroed by ONE memset
         w.live[s] = off;
+        off = align_up(off + (s < n_scales ? (size_t)w.n_tiles * 4 : 0), 256);
+    }
+    for (int s = 0; s < kMaxScales; ++s) {
+        w.shifts[s] = off;
         off = align_up(off + (s < n_scales ? (size_t)w.n_tiles * 4 : 0), 256);
     }
     w.tickets = off;
@@ -1661,6 +1689,7 @@ int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_sca
     offsets[15] = lay.diag;
     offsets[16] = lay.total;
     offsets[18] = lay.balance;
+    for (int k = 0; k < kMaxScales; ++k) offsets[19 + k] = lay.shifts[k]; // (ABI v8: 22 entries)
     tiles[0] = lay.tiles_l;
     tiles[1] = lay.tiles_w;
     tiles[2] = kWinSlots;
@@ -1694,6 +1723,7 @@ int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_la
         // (tap positions of a direct item are byte offsets into one view's padded image, 32 bits)
         if ((unsigned long long)(a.dims[k].Hf + 2) * (a.dims[k].Wf + 2) * kSlotBytes >= (1ull << 32)) return VFA_ERR_UNSUPPORTED;
         a.live[k] = reinterpret_cast<unsigned *>(ws + lay.live[k]);
+        a.shift[k] = reinterpret_cast<unsigned *>(ws + lay.shifts[k]);
         a.hdrs[k] = ws + lay.hdrs[k];
         a.recs[k] = ws + lay.recs[k];
     }
@@ -1801,6 +1831,7 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
         a.sc[k].bias = biases ? biases[q] : nullptr;
         a.sc[k].wfrag = reinterpret_cast<const uint4 *>(ws + lay.wfrag[q]);
         a.sc[k].live = reinterpret_cast<const unsigned *>(ws + lay.live[q]);
+        a.sc[k].shift = reinterpret_cast<const unsigned *>(ws + lay.shifts[q]);
         a.sc[k].hdrs = ws + lay.hdrs[q];
         a.sc[k].recs = ws + lay.recs[q];
         a.sc[k].Hf = feat_hw[2 * q];

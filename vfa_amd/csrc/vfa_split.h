@@ -9,17 +9,26 @@
 // products) and the SAME work as the two-piece bf16 form (16 bits, 4e-6) it replaces as the default.
 //
 // fp16 has five exponent bits, so the pieces need a scale.  One power of two per operand and feature scale:
-//   A (voxel features):  2^ea with  absmax(feature map) 2^ea in [2^14, 2^15).  A box mean is (up to the rounding noise of the
-//                        integral image) at most absmax / 4 -- the box area of vfa_op.py:104 is four times the pixel area --, so
-//                        voxel features sit below 2^13 with a factor 8 of headroom up to fp16's 65504; the absolute error of a
-//                        piece is at most 2^-25 (half a subnormal step), i.e. 2^-38 of the largest voxel feature: rows down to
-//                        2^-14 of the largest keep the full 22 bits.  absmax comes from the integral-image kernels, which see
-//                        every feature value (vfa_integral.hip), or from a pass over the integral images when the caller has none
-//                        (integral_absmax_kernel).
+//   A (voxel features):  2^ea with  absmax(feature map) 2^ea in [2^13, 2^14).  In exact arithmetic a box mean is at most absmax / 4
+//                        (the box area of vfa_op.py:104 is four times the pixel area): an honest voxel feature sits below 2^12, a
+//                        factor 16 under fp16's 65504.  The fp32 rounding noise of the integral image does NOT obey that bound: the
+//                        reference keeps boxes down to area 1e-6 (vfa_op.py:106) and divides the noise by that area -- the shipped
+//                        Wildtrack grid holds visible boxes of 1e-5 pixels whose voxel features reach 2.8 absmax (round-4 verdict).
+//                        What is bounded is  |vox| / absmax <= 1/4 + 2^-18 Hf Wf / area  (vfa_geom.h: sliver_shift, with its derivation):
+//                        the geometry pass turns that bound into a SHIFT per (tile, view, scale) item (serial kernel; per (tile, scale) in
+//                        the pipelined kernel, whose accumulators run over views and layers) -- 0 for every honest box, floor(log2
+//                        bound) + 1 for a sliver -- and the frame kernels scale that item by 2^(ea - shift) instead: its voxel features
+//                        stay below 2^14 WHATEVER the noise does, its bias enters the accumulator times 2^(ea + ew - shift) and its
+//                        epilogue multiplies by 2^-(ea + ew - shift): powers of two, exact.  The absolute error of a piece is at most
+//                        2^-25 (half a subnormal step), i.e. 2^(shift - 37) of the largest honest voxel feature: with the largest
+//                        possible shift (area -> 1e-6 on a 270 x 480 map: 19) still 2^-18 of it, far inside the 1e-4 of the path; the
+//                        rows of an unshifted item keep the full 22 bits down to 2^-13 of the largest.  absmax comes from the
+//                        integral-image kernels, which see every feature value (vfa_integral.hip), or from a pass over the integral
+//                        images when the caller has none (integral_absmax_kernel).
 //   W (collapse.weight): 2^ew with  absmax(W) 2^ew in [2^14, 2^15).
 // The accumulator starts at bias 2^(ea+ew) and the epilogue multiplies relu(acc) by 2^-(ea+ew): powers of two, exact.
-// A value beyond fp16's range (a noise-dominated box of ~1e-6 pixels) must not turn a finite reference value into Inf - Inf:
-// the CONVERSIONS run under MODE.FP16_OVFL, where a result that overflows is +-65504 instead of infinity (true infinities and
+// A value beyond fp16's range (an infinite or absurd feature; no finite map reaches it past the shift above) must not turn into
+// Inf - Inf: the CONVERSIONS run under MODE.FP16_OVFL, where a result that overflows is +-65504 instead of infinity (true infinities and
 // NaNs stay what they are: measured, tools/micro/fp16_modes.hip).  The MFMAs must NOT: under that mode v_mfma_f32_32x32x16_f16
 // reads a NaN operand as a number and an infinite one as FLT_MAX (same tool) -- a NaN box (vfa_op.py:118-119: NaN * 0 stays NaN)
 // or a NaN feature would vanish from the map.  The mode is per wave: the pooling waves of vfa_pipe.hip set it for good, the
@@ -34,7 +43,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int kExpA = 14, kExpW = 14, kExpLim = 40;
+constexpr int kExpA = 13, kExpW = 14, kExpLim = 40;
 
 // power-of-two scale exponent that brings a maximum with the fp32 bit pattern `absmax_bits` (sign cleared) into
 // [2^target, 2^(target+1)); 0 for an all-zero or non-finite operand

@@ -750,12 +750,12 @@ BALANCE_STATE_BYTES = 8192  # (bounds + launch size + cost signature, and at byt
 def pipe_workspace_layout(n_views, L, W, n_layers, n_scales):
     """Offsets inside the ``pipe_records`` workspace, for tests and tools."""
     import ctypes
-    off = (ctypes.c_size_t * 19)()
+    off = (ctypes.c_size_t * 22)()
     tiles = (ctypes.c_int * 5)()
     _lib.call("vfa_pipe_workspace_layout", int(n_views), int(L), int(W), int(n_layers), int(n_scales), off, tiles)
     names = ("live", "hdrs", "recs", "wfrag")
     out = {nm: [int(off[4 * k + i]) for k in range(n_scales)] for i, nm in enumerate(names)}
     out.update(tickets=int(off[12]), globs=int(off[17]), chunks=int(off[13]), ranks=int(off[14]), diag=int(off[15]), total=int(off[16]),
                tiles_l=int(tiles[0]), tiles_w=int(tiles[1]), max_slots=int(tiles[2]), n_chunks=int(tiles[3]),
-               max_slots_3piece=int(tiles[4]), balance=int(off[18]))
+               max_slots_3piece=int(tiles[4]), balance=int(off[18]), shifts=[int(off[19 + k]) for k in range(n_scales)])
     return out
