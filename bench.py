@@ -295,7 +295,7 @@ ROOFLINE_ENTRY_POINTS = tuple(KERNEL_NAMES)
 
 def committed_traffic(workload, kernel_substr):
     """HBM bytes per dispatch from the committed PMC passes of this command (profiles/rNN_pmc_traffic.json), or None."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         # (the PMC passes of the bench default, and -- per workload -- of `--workload <name>`)
         fname = f"{tag}_pmc_traffic.json" if workload == PRIMARY else f"{tag}_{workload}_pmc_traffic.json"
         tpath = os.path.join(REPO, "profiles", fname)
@@ -382,14 +382,16 @@ def roofline_fused(g, workload, entry, live=None, terms=2):
     issued = products * per_launch * live_frac
     achieved = issued / avg_s / 1e12
     waves = "8 matrix waves + 4 pooling waves" if terms == 6 else "8 matrix waves + 8 pooling waves"
-    kname = (f"pipe_kernel<{terms}, false> (persistent; {waves} per CU: box pooling from LDS tap windows beside the {label}-split MFMA "
+    small = pipe and all(tag[0] <= 2 for tag in g["by_tag"])  # (frames of one or two views run the four-step phase: pipe_kernel<.., SMALL>)
+    kernel_id = (f"pipe_kernel<{terms}, false, {'true' if small else 'false'}>" if pipe else f"pool_collapse_kernel<{terms}, false, false>")
+    kname = (f"{kernel_id} (persistent; {waves} per CU: box pooling from LDS tap windows beside the {label}-split MFMA "
              "collapse of the previous 64 rows x 64 channels; accumulators of four views in registers across all z-layers; bias + "
              "ReLU + view / scale sum)") if pipe else \
             (f"pool_collapse_kernel<{terms}, false, false> (persistent, one launch per frame: box pooling of all views x scales from LDS "
              f"tap windows -> {label}-split MFMA collapse -> bias + ReLU + view / scale sum); the HIP events bracket the call that "
              "launches it (+ the empty launch for direct items without a row slot, ~5 us); its pre-pass pool_rows_kernel (the 4 % "
              "of items whose window exceeds LDS, ~28 us) is a separate, untimed call of the entry point")
-    traffic, src = committed_traffic(workload, f"pipe_kernel<{terms}, false>" if pipe else f"pool_collapse_kernel<{terms}, false, false>")
+    traffic, src = committed_traffic(workload, kernel_id)  # (the name as rocprofv3 prints it: all three template arguments)
     return {"bound": "mfma", "kernel": entry + ": " + kname, "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note(src),
             "avg_launch_us": avg_s * 1e6, "mfma_flops_per_launch": issued,
@@ -403,18 +405,39 @@ def roofline_fused(g, workload, entry, live=None, terms=2):
             "launches": g["launches"]}
 
 
+def integral_kernel_of(nv, C, sizes, channels_last=False):
+    """Which kernels `vfa_integral_images_f32` launches for this call (vfa_integral.hip: integral_images_launch): ONE pass where its
+    tiling fits -- NCHW input, >= 64 (view, 16-channel block) units, the column accumulators of every map in LDS --, two passes else."""
+    k_rows, k_ch, pitch = 32, 16, 32 * 16 + 16
+    onepass = (not channels_last and C % k_ch == 0 and C % 64 == 0 and nv * (C // k_ch) >= 64 and
+               all(h >= 8 and w >= 4 and k_rows * pitch * 4 + w * k_ch * 8 <= 160 * 1024 - 1024 for h, w in sizes))
+    return onepass
+
+
 def roofline_integral(g):
     """The integral-image entry point (HBM-bound): algorithmic bytes = every feature map read once + every
-    zero-bordered integral image written once, over the mean time of the call (HIP events on the launch stream)."""
+    zero-bordered integral image written once (the two-pass kernels move every byte twice: their own traffic is 2 x that, the
+    ALGORITHMIC bytes stay what one pass needs), over the mean time of the call (HIP events on the launch stream)."""
     alg = 0.0
+    one = two = 0
     for (nv, C, sizes, _affine), rec in g["by_tag"].items():
         alg += rec["launches"] * sum(nv * C * h * w * 4 + nv * C * (h + 2) * (w + 2) * 4 for h, w in sizes)
+        if integral_kernel_of(nv, C, sizes):
+            one += rec["launches"]
+        else:
+            two += rec["launches"]
     avg_s = g["ms"] / g["launches"] * 1e-3
     per = alg / g["launches"]
-    return {"bound": "hbm", "kernel": "vfa_integral_images_f32: integral_onepass_kernel (both cumsums of a (view, 16-channel block, column "
-            "part) in one workgroup; one launch for the three maps of the frame)", "achieved": per / avg_s / 1e9, "peak": HBM_PEAK_GBS,
+    names = []
+    if one:
+        names.append("integral_onepass_kernel (both cumsums of a (view, 16-channel block, column part) in one workgroup; one launch for the "
+                     "three maps of the frame)")
+    if two:
+        names.append("rows_batched_kernel + cols_batched_kernel (two passes: fewer than 4 cameras or a shape the one-pass tiling does not "
+                     "take; every byte moves twice)")
+    return {"bound": "hbm", "kernel": "vfa_integral_images_f32: " + " / ".join(names), "achieved": per / avg_s / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": per / avg_s / 1e9 / HBM_PEAK_GBS, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": per,
-            "launches": g["launches"], "traffic": None}
+            "launches": g["launches"], "launches_one_pass": one, "launches_two_pass": two, "traffic": None}
 
 
 def roofline_of(ks, ops, workload, live=None, terms=2):

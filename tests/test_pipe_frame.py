@@ -643,3 +643,52 @@ def test_fp16_split_saturates_instead_of_overflowing_and_keeps_nan():
         assert torch.equal(torch.isnan(out), torch.isnan(want))
         if not bad.all():
             _check("cells that do not see the NaN", out[~bad], want[~bad])
+
+
+@pytest.mark.parametrize("name", ["multiviewc_156x156x5", "multiviewc_200x200x1"])
+def test_captured_frames_keep_a_workspace_of_their_own(name):
+    """hipGraph capture of a frame (``vfa_amd.graph.GraphedAggregate``: the pipelined kernel on the five-layer grid, the serial
+    kernel on the single-layer one).  A captured frame replays into the geometry workspace it was captured with, so that workspace
+    must never be handed to anybody else: two graphs of the SAME geometry, replayed alternately with eager frames of that geometry in
+    between (on the capture streams' handles too: torch recycles them), every result bit for bit the eager one; the states a capture
+    pinned are not in the eager cache and no two owners share a workspace."""
+    import vfa_amd
+    from vfa_amd import vfa_op
+    from vfa_amd.graph import GraphedAggregate
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload(name, channels=256, seed=6, n_cam=3, device=dev)
+    grid = wl["grid"][:, 8:56, 4:44].contiguous()
+    torch.manual_seed(2)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
+    lats_a = [torch.cat([wl["features"][c][s] for c in range(3)]) for s in range(3)]
+    lats_b = [torch.relu(torch.randn_like(l)) for l in lats_a]
+    calibs = wl["calibs"]
+    vfa_op._pipe_states.clear()
+    pinned_before = len(vfa_op._pipe_pinned)
+    with torch.no_grad():
+        want_a = vfa_amd.aggregate_views(*mods, *lats_a, calibs, grid).clone()
+        want_b = vfa_amd.aggregate_views(*mods, *lats_b, calibs, grid).clone()
+    g1 = GraphedAggregate(*mods, *lats_a, calibs, grid)
+    g2 = GraphedAggregate(*mods, *lats_b, calibs, grid)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(40)]  # (more than torch's pool of 32 handles: some repeat the captures')
+    with torch.no_grad():
+        for rnd in range(3):
+            assert torch.equal(g1(*lats_a), want_a), rnd
+            with torch.cuda.stream(streams[(7 * rnd) % 40]):
+                eager = vfa_amd.aggregate_views(*mods, *lats_b, calibs, grid)
+            torch.cuda.synchronize()
+            assert torch.equal(eager, want_b), rnd
+            assert torch.equal(g2(*lats_b), want_b), rnd
+            for st in streams[rnd::3]:
+                with torch.cuda.stream(st):
+                    eager = vfa_amd.aggregate_views(*mods, *lats_a, calibs, grid)
+            torch.cuda.synchronize()
+            assert torch.equal(eager, want_a), rnd
+            assert torch.equal(g1(*lats_b), want_b) and torch.equal(g2(*lats_a), want_a), rnd
+    if mods[0].num_grid_layer > 1:  # (the pipelined path keeps persistent states; the serial path allocates per frame)
+        pinned = vfa_op._pipe_pinned[pinned_before:]
+        assert len(pinned) == 2 and all(st["pinned"] for st in pinned)
+        assert not any(st.get("pinned") for st in vfa_op._pipe_states.values())
+        owners = [st["ws"].data_ptr() for st in pinned] + [st["ws"].data_ptr() for st in vfa_op._pipe_states.values()]
+        assert len(set(owners)) == len(owners)

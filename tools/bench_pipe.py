@@ -88,6 +88,8 @@ with torch.no_grad():
         ws_old = ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=[m.layer_major_weight().contiguous() for m in mods])
         t_old = timed(lambda: ops.pool_collapse(integrals, biases, ws_old, (L, W), out=out), reps=20, warm=10)
         print(f"  serial fused kernel     {t_old:9.1f} us")
+    if terms not in (0, 2):  # (the diagnostic build exists for the default arithmetic only: the entry point refuses debug flags with other terms)
+        ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights, workspace=ws, terms=0)
     for mask, label in ((1, "no window DMA"), (2, "no pooling"), (4, "no MFMA"), (6, "no pooling, no MFMA"), (7, "skeleton only"), (64, "loop, tables, barrier only"), (32, "diagnostic build"), (8, "no setprio"), (16, "matrix waves prio 2")):
         us = timed(lambda: ops.pipe_collapse(integrals, biases, ws, (L, W), nl, out=out, debug=mask))
         print(f"  pipe_collapse [{label:>20}] {us:9.1f} us")

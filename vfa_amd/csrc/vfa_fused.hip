@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void split_weight_frag_kernel(SplitArgs sa)
     if (idx >= 8 * kSteps * 64) return;
     const int lane = idx & 63, s = (idx >> 6) & 15, wave = idx >> 10;
     const float *src = w + (size_t)(wave * 32 + (lane & 31)) * kC + 16 * s + 8 * (lane >> 5);
+    if (idx == 0 && blockIdx.y == 0) sa.wexp[kMaxScales] = sa.f16 ? 2 : 3; // the arithmetic these fragments are for: checked by the frame kernel
     uint4 uh, ul;
     if (sa.f16) {
         fp16_saturate_mode(true);
@@ -421,7 +422,7 @@ struct FusedArgs {
     const unsigned *row_counter;    // direct items of the frame
     int rows_cap;                   // row slots in the workspace
     int accumulate;
-    const int *wexp;                // (kMaxScales) scale exponent of the split collapse weight (split_weight_frag_kernel; fp16 form)
+    const int *wexp;                // (kMaxScales) scale exponent of the split collapse weight (split_weight_frag_kernel; fp16 form); [kMaxScales]: 2 = fp16 fragments, 3 = bf16
     int debug;                      // diagnostic build only: ablation mask (kDbg*), results are then meaningless
     unsigned long long *diag;       // diagnostic build only: per workgroup 8 cycle counters
 };
@@ -503,6 +504,14 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     // in front of the cameras.
     if (DIRECT && uniform_i((int)*a.row_counter) <= a.rows_cap) return; // every direct item of this frame got a row slot
     const int nblk = gridDim.x;
+    // The weight fragments in the workspace were split for ONE arithmetic (the geometry call's flags); a launch that asks for the other
+    // would read fp16 pieces as bf16 ones: fail loudly -- a map of NaNs -- instead of returning plausible garbage.
+    if (uniform_i(a.wexp[kMaxScales]) != (F16 ? 2 : 3)) {
+        if (!DIRECT)
+            for (size_t i = (size_t)blockIdx.x * kThreads + tid; i < (size_t)a.L * a.W * kC; i += (size_t)nblk * kThreads)
+                a.out[i] = __uint_as_float(0x7fc00000u);
+        return;
+    }
     const int lb = (int)xcd_contiguous(blockIdx.x, (nblk + 7) / 8);
     if (lb >= nblk) return;
     const int t_step = DIRECT ? nblk : 1;
@@ -1364,7 +1373,7 @@ __global__ __launch_bounds__(512) void pool_rows_kernel(RowsArgs a)
                               __uint_as_float(r[1].x), __uint_as_float(r[1].y), __uint_as_float(r[1].z), __uint_as_float(r[1].w),
                               __uint_as_float(r[2].x), __uint_as_float(r[2].y), __uint_as_float(r[2].z), __uint_as_float(r[2].w),
                               __uint_as_float(r[3].x), __uint_as_float(r[3].y), __uint_as_float(r[3].z), __uint_as_float(r[3].w)};
-        const float rcp = __uint_as_float(r[4].x), masked = __uint_as_float(r[5].z);
+        const float rcp = __uint_as_float(r[4].x), masked = __uint_as_float(r[5].z), area = __uint_as_float(r[5].w);
         const bool vis = (r[4].y & (unsigned)kVis) != 0u;
         // records of a direct item hold pixel coordinates (+ 1: the zero border); a masked box reads pixel 0 and discards it
         const unsigned rws[4] = {vis ? r[4].z & 0xffffu : 0u, vis ? r[4].z >> 16 : 0u, vis ? r[4].w & 0xffffu : 0u, vis ? r[4].w >> 16 : 0u};
@@ -1379,10 +1388,9 @@ __global__ __launch_bounds__(512) void pool_rows_kernel(RowsArgs a)
         const float4 rb = sample4(t[2][2], t[2][3], t[3][2], t[3][3], wt[4], wt[5], wt[6], wt[7]);
         const float4 rt = sample4(t[0][2], t[0][3], t[1][2], t[1][3], wt[8], wt[9], wt[10], wt[11]);
         const float4 lb2 = sample4(t[2][0], t[2][1], t[3][0], t[3][1], wt[12], wt[13], wt[14], wt[15]);
-        float4 v = make_float4(lt.x + rb.x, lt.y + rb.y, lt.z + rb.z, lt.w + rb.w); // (((lt + rb) - rt) - lb) * RN(1 / area)
-        v = make_float4(v.x - rt.x, v.y - rt.y, v.z - rt.z, v.w - rt.w);
-        v = make_float4(v.x - lb2.x, v.y - lb2.y, v.z - lb2.z, v.w - lb2.w);
-        float4 res = make_float4(v.x * rcp, v.y * rcp, v.z * rcp, v.w * rcp);
+        // RN((((lt + rb) - rt) - lb) / area): the reference's correctly rounded quotient (vfa_geom.h: box_mean)
+        float4 res = make_float4(box_mean(lt.x, rb.x, rt.x, lb2.x, area, rcp), box_mean(lt.y, rb.y, rt.y, lb2.y, area, rcp),
+                                 box_mean(lt.z, rb.z, rt.z, lb2.z, area, rcp), box_mean(lt.w, rb.w, rt.w, lb2.w, area, rcp));
         if (!vis) res = make_float4(masked, masked, masked, masked);
         reinterpret_cast<float4 *>(a.rows)[((size_t)slot * kTileBoxes + b) * (kC / 4) + q * 16 + cq] = res;
     }
@@ -1438,7 +1446,7 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     w.row_list = off;
     off = align_up(off + cap * sizeof(unsigned), 256);
     w.wmax = off; off = align_up(off + (size_t)kMaxScales * kWmaxParts * sizeof(unsigned), 256); // fp16 split: partial maxima of |W| per scale,
-    w.wexp = off; off = align_up(off + kMaxScales * sizeof(int), 256);                            // ... the weight exponents,
+    w.wexp = off; off = align_up(off + (kMaxScales + 1) * sizeof(int), 256);                            // ... the weight exponents,
     w.amax = off; off = align_up(off + (size_t)kMaxScales * kFallbackStats * sizeof(unsigned), 256); // ... and feature statistics made here for callers that pass none
     w.views_pad = (n_views + 7) / 8 * 8; // cost estimates of the items, per tile (tile_chunks_kernel)
     w.item_w = off;
@@ -1632,6 +1640,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
     const int debug = ((flags >> 16) & 0xfff) | ((flags & VFA_FLAG_DUMP_VOX) ? kDbgDumpVox : 0);
+    if (debug && terms != 0 && terms != 2) return VFA_ERR_BAD_ARGUMENT; // (the diagnostic build exists for the default arithmetic only)
     if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00 | VFA_FLAG_ROWS_ONLY | VFA_FLAG_SKIP_ROWS | VFA_FLAG_DUMP_VOX)) return VFA_ERR_BAD_ARGUMENT;
     if ((flags & VFA_FLAG_ROWS_ONLY) && (flags & VFA_FLAG_SKIP_ROWS)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || L < 0 || W < 0 || n_scales < 1 || n_scales > kMaxScales || !feat_hw || !integrals ||

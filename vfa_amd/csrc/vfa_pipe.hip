@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void pipe_split_weight_kernel(SplitArgs sa)
     if (idx >= 8 * kSteps * 64) return;
     const int lane = idx & 63, s = (idx >> 6) & 15, wave = idx >> 10;
     const float *src = w + (size_t)(wave * 32 + (lane & 31)) * kC * sa.nl + (size_t)(16 * s + 8 * (lane >> 5)) * sa.nl + layer;
+    if (idx == 0 && blockIdx.y == 0) sa.wexp[kMaxScales] = sa.f16 ? 2 : 3; // the arithmetic these fragments are for: checked by the frame kernel
     if (sa.f16) {
         fp16_saturate_mode(true);
         unsigned m = 0u;
@@ -377,7 +378,7 @@ struct PipeArgs {
     unsigned long long *diag;       // per workgroup 8 counters (VFA_FLAG_DEBUG)
     int debug;
     int *balance;                   // balance state of the workspace (kBalanceBytes: see kBalTag)
-    const int *wexp;                // (kMaxScales) scale exponent of the split collapse weight (fp16 form)
+    const int *wexp;                // (kMaxScales) scale exponent of the split collapse weight (fp16 form); [kMaxScales]: 2 = fp16 fragments, 3 = bf16
 };
 
 struct DevMasks {
@@ -532,6 +533,13 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     const int tid = threadIdx.x, wave = uniform_i(tid >> 6), lane = tid & 63;
 
     const int nblk = gridDim.x;
+    // The weight fragments in the workspace were split for ONE arithmetic (the geometry call's flags); a launch that asks for the other
+    // would read fp16 pieces as bf16 ones: fail loudly -- a map of NaNs -- instead of returning plausible garbage.
+    if (uniform_i(a.wexp[kMaxScales]) != (F16 ? 2 : 3)) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < (size_t)a.L * a.W * kC; i += (size_t)nblk * blockDim.x)
+            a.out[i] = __uint_as_float(0x7fc00000u);
+        return;
+    }
     const int lb = (int)xcd_contiguous(blockIdx.x, (nblk + 7) / 8);
     if (lb >= nblk) return;
     // the pieces of workgroup wg: the uniform split, or the bounds a balance call left for exactly this frame and launch size
@@ -1635,7 +1643,7 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
     w.diag = off;    off = align_up(off + (size_t)kMaxBlocks * 8 * sizeof(unsigned long long), 256);
     w.balance = off; off = align_up(off + kBalanceBytes, 256); // work-cut bounds per workgroup + the last launch's times (vfa_pipe_balance_f32)
     w.wmax = off;    off = align_up(off + (size_t)kMaxScales * kWmaxParts * sizeof(unsigned), 256); // fp16 split: partial maxima of |W| per scale,
-    w.wexp = off;    off = align_up(off + kMaxScales * sizeof(int), 256);                            // ... the weight exponents,
+    w.wexp = off;    off = align_up(off + (kMaxScales + 1) * sizeof(int), 256);                            // ... the weight exponents,
     w.amax = off;    off = align_up(off + (size_t)kMaxScales * kFallbackStats * sizeof(unsigned), 256); // ... feature statistics made here for callers that pass none
     w.total = off;
     return w;
@@ -1809,6 +1817,7 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
     const int debug = ((flags >> 16) & 0xfff) | ((flags & VFA_FLAG_DUMP_VOX) ? kDbgDumpVox : 0);
+    if (debug && terms != 0 && terms != 2) return VFA_ERR_BAD_ARGUMENT; // (the diagnostic build exists for the default arithmetic only)
     if (flags & ~(VFA_FLAG_TERMS_MASK | 0xfffff00 | VFA_FLAG_DUMP_VOX)) return VFA_ERR_BAD_ARGUMENT;
     if (!dims_ok(n_views, L, W, n_layers, n_scales) || !feat_hw || !integrals ||
         (terms != 0 && terms != 2 && terms != 3 && terms != 4 && terms != 6))

@@ -187,7 +187,7 @@ def lateral_conv(feat, weight, bias, gamma, beta, eps=1e-5):
 
 def lateral_convs(branches):
     """``lateral_conv`` for ALL the scales of a frame in three launches (``vfa_lateral_convs_f32``): branches = [(feat, weight, bias,
-    gamma, beta, eps), ...] (at most three; the largest map first) -> [(y, scale, shift), ...], bit for bit the per-scale calls
+    gamma, beta, eps), ...] (at most three; the C side orders them by descending K: the deepest map first) -> [(y, scale, shift), ...], bit for bit the per-scale calls
     (reference vfanet.py:72-74 for the three scales).  The small maps' workgroups fill the tail of the large map's launch."""
     if not branches:
         return []

@@ -329,12 +329,14 @@ def _pipe_state(dev, key, ws_bytes, n_bands):
     # one workspace per (geometry, stream): the geometry call of a frame on another stream must not overwrite records the
     # previous frame's kernel on THIS stream is still reading (`side.wait_stream(cur)` only orders against the current one)
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream) + key
+    capturing = torch.cuda.is_current_stream_capturing()
     st = _pipe_states.pop(key, None)
-    if st is None and torch.cuda.is_current_stream_capturing():
+    if st is None and capturing:
         # A capture runs on a stream of its own: it takes over the workspace a warm-up frame of the same geometry left on another
-        # stream -- with its balanced shares; a fresh one would have the one-off balance kernel (milliseconds) captured into the graph
+        # stream -- with its balanced shares; a fresh one would have the one-off balance kernel (milliseconds) captured into the graph.
+        # (The warm-up frame has finished: ``torch.cuda.graph`` synchronises the device before it begins the capture.)
         for k2 in list(_pipe_states):
-            if k2[0] == key[0] and k2[2:] == key[2:] and _pipe_states[k2]["frames"] > 0 and not _pipe_states[k2].get("pinned"):
+            if k2[0] == key[0] and k2[2:] == key[2:] and _pipe_states[k2]["frames"] > 0:
                 st = _pipe_states.pop(k2)
                 break
     if st is None:
@@ -343,10 +345,14 @@ def _pipe_state(dev, key, ws_bytes, n_bands):
         st = {"ws": ws, "frames": 0, "balance_off": lay["balance"],
               "bands": [torch.zeros(ops.BALANCE_STATE_BYTES, dtype=torch.uint8, device=dev) for _ in range(n_bands)] if n_bands > 1 else None}
         ws[lay["balance"]:lay["balance"] + ops.BALANCE_STATE_BYTES].zero_()  # (= vfa_pipe_balance_f32 mode 0)
-    if torch.cuda.is_current_stream_capturing() and not st.get("pinned"):
-        # a hipGraph that is being captured will replay into this workspace for as long as it lives: never dropped from here on
+    if capturing:
+        # A hipGraph that is being captured replays into this workspace for as long as it lives: the state belongs to that graph
+        # from here on.  It is kept alive in `_pipe_pinned` and NEVER goes back into `_pipe_states` -- torch hands stream handles out
+        # of a pool of 32, so an eager frame (or a second capture) on a stream with the same handle would otherwise pop it and
+        # write geometry, tickets and balance state into a workspace a live graph replays into.
         st["pinned"] = True
         _pipe_pinned.append(st)
+        return st
     _pipe_states[key] = st  # (most recent last)
     while len(_pipe_states) > PIPE_STATES_KEPT:
         _pipe_states.pop(next(iter(_pipe_states)))
