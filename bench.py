@@ -626,6 +626,39 @@ def main():
         extra["per_rank_proxy"] = dict(proxy, note="one GPU, rank 0's cameras of an N-rank camera-sharded frame, no collective: ms_per_frame "
                                        "and its ratio to (time of the full rig on one GPU) x (share of the cameras); a projection of the "
                                        "per-rank compute time, NOT a scaling measurement")
+    # ---- the drop-in AS THE REFERENCE CALLS IT (vfanet.py:64-82): per camera three `VFA.forward` calls, `f8 + f16 + f32`, `ortho +=`
+    # -- what train.py / predict.py get from the one-line import swap of INTEGRATION.md section 1, without `aggregate_views`
+    if a.fp32_steps > 0 and world == 1 and a.channels == 256 and len(leg.cams) > 0:
+        lats = leg.sets[0]
+
+        def reference_loop():
+            ortho = 0
+            for cam in range(len(leg.cams)):
+                f8 = leg.mods[0](lats[0][[cam], ...], leg.calibs[cam], leg.grid)
+                f16 = leg.mods[1](lats[1][[cam], ...], leg.calibs[cam], leg.grid)
+                f32 = leg.mods[2](lats[2][[cam], ...], leg.calibs[cam], leg.grid)
+                ortho = ortho + (f8 + f16 + f32)
+            return ortho
+
+        with torch.no_grad():
+            for _ in range(3):
+                got_loop = reference_loop()
+            want_loop = vfa_amd.aggregate_views(*leg.mods, *lats, leg.calibs, leg.grid, distributed=False)
+            leg.fence()
+            scale_l = float(want_loop.abs().max())
+            err_l = float((got_loop - want_loop).abs().max()) / scale_l
+            reps = max(3, a.fp32_steps // 2)
+            gc.collect()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                reference_loop()
+            leg.fence()
+            ms_loop = 1e3 * (time.perf_counter() - t0) / reps
+        extra["reference_loop"] = {"ms_per_frame": ms_loop, "value": leg.units_step / (ms_loop * 1e-3), "calls_per_frame": 3 * len(leg.cams),
+                                   "vs_batched_frame": ms_loop / (1e3 * dt / a.steps), "max_abs_diff_vs_batched_over_max": err_l,
+                                   "note": "the camera loop of the reference's VFANet.forward (vfanet.py:64-82) on this build's VFA modules: "
+                                           "7 cameras x 3 VFA.forward calls + the Python sums -- the drop-in without the batched "
+                                           "aggregate_views; same frame, same inputs; host clock around `reps` frames"}
     # ---- the producer in front of the path, NOT part of `value` (the path starts at lateral maps resident in HBM):
     # trunk outputs -> the three integral images through the hand-written lateral branch (fp32-MFMA 1x1 convolution, channels-last,
     # GroupNorm statistics in its epilogue; affine + ReLU inside the row scan) and through the library's operations
@@ -741,7 +774,7 @@ def main():
             "ms_per_step": 1e3 * dt / a.steps, "timing": timing, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 in / out, fp32 accumulation everywhere.  Pre-GEMM: the reference's exact fp32 rounding sequence (the fused "
-                          "kernels' pooled rows within 1 ulp of the reference's voxel features, 79-87 % identical: tests/test_fused_frame.py). "
+                          "kernels' pooled rows -- tap chains, box sum, correctly rounded quotient -- are the reference's voxel features bit for bit: tests/test_fused_frame.py). "
                           "The collapse product (reference: fp32 nn.Linear) = " + ARITHMETIC[primary_terms][3] + ".  Extra keys: "
                           "`bf16x2_16bit` = the narrower two-piece bf16 product (the default until round 3; NOT reference width), "
                           "`bf16x3_six_products` = three bf16 pieces, `collapse_fp32_ms_per_step` = the unfused step with the fp32 library GEMM",

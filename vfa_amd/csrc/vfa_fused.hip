@@ -1534,7 +1534,7 @@ int vfa_frame_boxes_f32(const float *calibs, const float *grid, const float *z_l
     a.row_list = reinterpret_cast<unsigned *>(ws + lay.row_list);
     a.item_w = reinterpret_cast<unsigned short *>(ws + lay.item_w);
     a.views_pad = lay.views_pad;
-    const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s);
+    const hipError_t e = zero_fill(ws, lay.masks_bytes, s); // (a kernel, not hipMemsetAsync: see vfa_geom.h)
     if (e != hipSuccess) return (int)e;
     const long long pairs = (long long)n_views * lay.n_tiles;
     hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(kWave), 0, s, a);
@@ -1652,7 +1652,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
     if (lay.n_tiles == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (n_views == 0) {
-        if (!accumulate) return (int)hipMemsetAsync(out, 0, (size_t)L * W * kC * sizeof(float), s);
+        if (!accumulate) return (int)zero_fill(out, (size_t)L * W * kC * sizeof(float), s);
         return 0;
     }
     if (!workspace || workspace_bytes < lay.rows) return VFA_ERR_BAD_ARGUMENT;

@@ -159,5 +159,24 @@ __device__ __forceinline__ int sliver_shift(float area, int Hf, int Wf)
     return e > 48 ? 48 : e;
 }
 
+// Zero `bytes` (a multiple of 16, 16-byte aligned) with a KERNEL on the stream.  The frame entry points clear their view masks,
+// tickets and counters with this instead of hipMemsetAsync: inside a captured hipGraph the runtime's memset node was seen to run
+// unordered against the kernel node behind it once the process had used a few more streams (ROCm 7.2: masks that
+// frame_records_kernel had already OR-ed were zeroed again -- tiles vanished from every later replay of the graph; found by
+// tests/test_pipe_frame.py::test_captured_frames_keep_a_workspace_of_their_own).  Kernel -> kernel edges of a graph hold.
+static __global__ __launch_bounds__(256) void zero_fill_kernel(uint4 *p, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+inline hipError_t zero_fill(void *p, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 15u) || ((size_t)p & 15u)) return hipMemsetAsync(p, 0, bytes, s); // (never the case for the workspaces: 256-byte regions)
+    const size_t n16 = bytes / 16;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(p), n16);
+    return hipGetLastError();
+}
+
 } // namespace vfa_dev
 #endif // VFA_GEOM_H

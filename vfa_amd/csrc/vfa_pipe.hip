@@ -1736,7 +1736,7 @@ int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_la
         a.recs[k] = ws + lay.recs[k];
     }
     a.globs = reinterpret_cast<unsigned *>(ws + lay.globs);
-    const hipError_t e = hipMemsetAsync(ws, 0, lay.masks_bytes, s); // view masks, tile tickets, counters
+    const hipError_t e = zero_fill(ws, lay.masks_bytes, s); // view masks, tile tickets, counters (a kernel, not hipMemsetAsync: see vfa_geom.h)
     if (e != hipSuccess) return (int)e;
     const long long pairs = (long long)n_views * lay.n_tiles;
     hipLaunchKernelGGL(pipe_records_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(kWave), 0, s, a);
@@ -1828,7 +1828,7 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
     if (lay.n_tiles == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (n_views == 0) {
-        if (!accumulate) return (int)hipMemsetAsync(out, 0, (size_t)L * W * kC * sizeof(float), s);
+        if (!accumulate) return (int)zero_fill(out, (size_t)L * W * kC * sizeof(float), s);
         return 0;
     }
     if (!workspace || workspace_bytes < lay.total || !out) return VFA_ERR_BAD_ARGUMENT;
