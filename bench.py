@@ -638,7 +638,9 @@ def main():
                 f16 = leg.mods[1](lats[1][[cam], ...], leg.calibs[cam], leg.grid)
                 f32 = leg.mods[2](lats[2][[cam], ...], leg.calibs[cam], leg.grid)
                 ortho = ortho + (f8 + f16 + f32)
-            return ortho
+            # (the reference hands `ortho` to `self.fuse`, a conv: the first torch function it meets computes a deferred result -- here
+            # that use is spelled out; with VFA_AMD_LAZY=0 every call above has already computed)
+            return vfa_amd.materialize(ortho)
 
         with torch.no_grad():
             for _ in range(3):
@@ -658,7 +660,23 @@ def main():
                                    "vs_batched_frame": ms_loop / (1e3 * dt / a.steps), "max_abs_diff_vs_batched_over_max": err_l,
                                    "note": "the camera loop of the reference's VFANet.forward (vfanet.py:64-82) on this build's VFA modules: "
                                            "7 cameras x 3 VFA.forward calls + the Python sums -- the drop-in without the batched "
-                                           "aggregate_views; same frame, same inputs; host clock around `reps` frames"}
+                                           "aggregate_views; same frame, same inputs; host clock around `reps` frames.  In inference VFA.forward "
+                                           "DEFERS (vfa_amd/lazy.py): the calls and sums only record, the first use of `ortho` runs one batched "
+                                           "frame; `eager_calls_ms_per_frame` is the same loop with VFA_AMD_LAZY=0 (21 launches of everything)"}
+        from vfa_amd import lazy as _lazy
+        if _lazy.LAZY:
+            _lazy.LAZY = False
+            try:
+                with torch.no_grad():
+                    reference_loop()
+                    leg.fence()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        reference_loop()
+                    leg.fence()
+                extra["reference_loop"]["eager_calls_ms_per_frame"] = 1e3 * (time.perf_counter() - t0) / 3
+            finally:
+                _lazy.LAZY = True
     # ---- the producer in front of the path, NOT part of `value` (the path starts at lateral maps resident in HBM):
     # trunk outputs -> the three integral images through the hand-written lateral branch (fp32-MFMA 1x1 convolution, channels-last,
     # GroupNorm statistics in its epilogue; affine + ReLU inside the row scan) and through the library's operations

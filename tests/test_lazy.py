@@ -1,0 +1,113 @@
+"""``vfa_amd.lazy.DeferredOrtho``: the deferred result of ``VFA.forward`` in inference (the reference's camera loop,
+vfa/model/vfanet.py:64-82, then costs ONE batched frame).  CPU: the algebra of the record with a stand-in for the computation.
+GPU (``-m gpu``): the reference-style loop over this build's modules against ``aggregate_views``, bit for bit."""
+import pytest
+import torch
+
+from vfa_amd import lazy, vfa_op
+
+
+@pytest.fixture
+def stub(monkeypatch):
+    """Replace the computation by something a CPU can do: sum over the terms of mean(feature) * calib[0, 0], broadcast to the shape."""
+    calls = []
+
+    def fake(terms, grid, crange):
+        calls.append(len(terms))
+        for _, feat, version, _ in terms:
+            if feat._version != version:
+                raise RuntimeError("modified in place")
+        total = sum(float(f.mean()) * float(c.reshape(-1)[0]) for _, f, _, c in terms)
+        return torch.full((1, 4, grid.shape[-3], grid.shape[-2]), total)
+
+    monkeypatch.setattr(vfa_op, "_materialize", fake)
+    return calls
+
+
+def _rec(grid, value, calib=1.0):
+    f = torch.full((1, 4, 3, 3), float(value))
+    return lazy.DeferredOrtho([(None, f, f._version, torch.tensor([[calib]]))], grid, (-1.0, 0.95), (1, 4, grid.shape[-3], grid.shape[-2]), f.device)
+
+
+def test_sums_stay_deferred_and_compute_once(stub):
+    grid = torch.zeros(1, 5, 6, 3)
+    ortho = 0
+    for cam in range(3):  # the shape of the reference's loop
+        f8, f16, f32 = _rec(grid, 1 + cam), _rec(grid, 10), _rec(grid, 100)
+        vfa_feats = f8 + f16 + f32
+        ortho += vfa_feats
+    assert isinstance(ortho, lazy.DeferredOrtho) and not stub
+    assert ortho.shape == (1, 4, 5, 6) and ortho.size(1) == 4 and ortho.dim() == 4 and ortho.dtype == torch.float32
+    assert not stub, "shape questions must not compute"
+    y = torch.nn.functional.relu(ortho)              # any torch function computes ...
+    assert stub == [9] and torch.equal(y, torch.full((1, 4, 5, 6), 336.0))
+    z = torch.nn.functional.conv2d(ortho, torch.ones(1, 4, 1, 1))   # ... once: the value is kept
+    assert stub == [9] and float(z[0, 0, 0, 0]) == 4 * 336.0
+    assert float(ortho.sum()) == 336.0 * 120 and float(ortho[0, 0, 0, 0]) == 336.0 and stub == [9]
+    assert torch.equal(lazy.materialize(ortho), ortho.materialize()) and lazy.materialize(y) is y
+
+
+def test_mixed_arithmetic_materialises(stub):
+    grid = torch.zeros(1, 2, 2, 3)
+    a, b = _rec(grid, 2.0), _rec(grid, 3.0)
+    t = torch.ones(1, 4, 2, 2)
+    assert torch.equal(a + t, torch.full((1, 4, 2, 2), 3.0)) and stub == [1]
+    assert torch.equal(t + b, torch.full((1, 4, 2, 2), 4.0)) and stub == [1, 1]
+    c = _rec(grid, 5.0)
+    assert torch.equal(c * 2, torch.full((1, 4, 2, 2), 10.0)) and torch.equal(1 - c, torch.full((1, 4, 2, 2), -4.0))
+    t2 = torch.zeros(1, 4, 2, 2)
+    t2 += _rec(grid, 7.0)                            # a real tensor on the left: computed at once
+    assert float(t2.mean()) == 7.0
+    other_grid = torch.zeros(1, 2, 2, 3)             # records of DIFFERENT grids do not merge
+    s = _rec(grid, 1.0) + _rec(other_grid, 1.0)
+    assert isinstance(s, torch.Tensor) and float(s.mean()) == 2.0
+
+
+def test_in_place_change_of_a_recorded_feature_is_an_error(stub):
+    grid = torch.zeros(1, 2, 2, 3)
+    f = torch.ones(1, 4, 3, 3)
+    r = lazy.DeferredOrtho([(None, f, f._version, torch.tensor([[1.0]]))], grid, (-1.0, 0.95), (1, 4, 2, 2), f.device)
+    f.mul_(2.0)
+    with pytest.raises(RuntimeError):
+        r.materialize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n_cam", [("multiviewc_200x200x1", 7), ("multiviewc_156x156x5", 3)])
+def test_reference_style_loop_equals_the_batched_frame(name, n_cam, monkeypatch):
+    """7 cameras x 3 ``VFA.forward`` calls + Python sums (vfanet.py:64-82) on this build's modules: deferred, then ONE launch of the
+    frame kernel -- bit for bit ``aggregate_views``; with the deferral off (21 launches) within the path's tolerance of it."""
+    import vfa_amd
+    from vfa_amd import ops
+    from vfa_amd.synthetic import make_workload
+    dev = torch.device("cuda:0")
+    wl = make_workload(name, channels=256, seed=5, n_cam=n_cam, device=dev)
+    grid = wl["grid"][:, 16:80, 8:104].contiguous()
+    torch.manual_seed(3)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
+    lats = [torch.cat([wl["features"][c][s] for c in range(n_cam)]) for s in range(3)]
+    calibs = wl["calibs"]
+
+    def loop():
+        ortho = 0
+        for cam in range(n_cam):
+            f8 = mods[0](lats[0][[cam], ...], calibs[cam], grid)
+            f16 = mods[1](lats[1][[cam], ...], calibs[cam], grid)
+            f32 = mods[2](lats[2][[cam], ...], calibs[cam], grid)
+            ortho += f8 + f16 + f32
+        return ortho
+
+    with torch.no_grad():
+        want = vfa_amd.aggregate_views(*mods, *lats, calibs, grid)
+        with ops.KernelTimer() as kt:
+            got = loop()
+            assert isinstance(got, lazy.DeferredOrtho) and not kt.summary(), "the calls and sums must only record"
+            fused = torch.nn.functional.relu(got)    # (the reference's next step is a conv on `ortho`)
+        frame_calls = [v["launches"] for k, v in kt.summary().items() if k in ("vfa_pool_collapse_relu_sum_f32", "vfa_pipe_collapse_relu_sum_f32")]
+        assert sum(frame_calls) <= 2, kt.summary()   # (one frame; the serial kernel's entry point is called in two stages)
+        assert torch.equal(fused, want)              # relu of a non-negative map: the map itself
+        monkeypatch.setattr(lazy, "LAZY", False)
+        eager = loop()
+        assert isinstance(eager, torch.Tensor)
+        scale = want.abs().max().item()
+        torch.testing.assert_close(eager, want, rtol=1e-4, atol=1e-5 * scale)

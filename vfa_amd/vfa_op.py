@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib, ops
+from . import _lib, lazy, ops
 from .utils import project  # noqa: F401  (re-exported like the reference module does)
 
 EPSILON = 1e-6
@@ -675,6 +675,14 @@ class VFA(nn.Module):
         if grid.dim() >= 3 and fused_train_ok([self], 1, (feature,)):
             ortho = fused_frame_train([self], [feature], calib.reshape(1, 3, 4), grid, crange)
         elif self.mfma_collapse_ok(feature) or (grid.dim() >= 3 and pipe_frame_ok([self], 1, (feature,))):
+            if lazy.LAZY and grid.dim() >= 3 and (pipe_frame_ok([self], 1, (feature,)) or fused_frame_ok([self], 1)):
+                # inference through a per-frame kernel: the result is DEFERRED (vfa_amd/lazy.py) -- the reference's loop over cameras
+                # and scales (vfanet.py:64-82) then costs one batched frame instead of 21 launches of a persistent kernel
+                _lib.require_device(feature, calib, grid)  # (no CPU path: fail at the call, not at the first use)
+                if feature.shape[1] != self.channel:
+                    raise ValueError(f"feature has {feature.shape[1]} channels, VFA was built for {self.channel}")
+                return lazy.DeferredOrtho([(self, feature, feature._version, calib)], grid, (float(crange[0]), float(crange[1])),
+                                         (1, self.collapse.out_features, length, width), feature.device)
             ortho = self.project_sum(feature, calib.reshape(1, 3, 4), grid, crange)
         else:
             lin = self.project_views(feature, calib.reshape(1, 3, 4), grid, crange)
@@ -698,6 +706,42 @@ class VFA(nn.Module):
                 ax.add_patch(patches.Rectangle((l * wf, t * hf), (r - l) * wf, (b - t) * hf, fill=False, linewidth=0.5))
         plt.show()
         return fig
+
+
+def _materialize(terms, grid, crange):
+    """The tensor behind a ``lazy.DeferredOrtho``: terms = [(module, feature (1,C,h,w), version, calib (3,4)), ...] in call order ->
+    (1, C_out, L, W) = sum over the terms of ``module.forward`` (reference vfa_op.py:61-125 per term, vfanet.py:79, 82 for the sums).
+    The terms are grouped by module; when the (at most three) modules saw the same cameras in the same order -- the reference's loop --
+    the whole sum is ONE batched frame (``pipe_frame`` / ``fused_frame``: what ``aggregate_views`` runs), otherwise one batched call
+    per module, accumulated."""
+    groups = {}
+    for mod, feat, version, calib in terms:
+        if feat._version != version:
+            raise RuntimeError("a feature map passed to VFA.forward was modified in place before its (deferred) result was used; "
+                               "clone it, or set VFA_AMD_LAZY=0")
+        groups.setdefault(id(mod), (mod, [], []))
+        groups[id(mod)][1].append(feat)
+        groups[id(mod)][2].append(calib)
+    mods = [g[0] for g in groups.values()]
+    feats = [g[1][0] if len(g[1]) == 1 else torch.cat(g[1]) for g in groups.values()]
+    calib_lists = [g[2] for g in groups.values()]
+    length, width = grid.shape[-3], grid.shape[-2]
+    dev = feats[0].device
+    c_out = mods[0].collapse.out_features
+    out = torch.empty((length * width, c_out), dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        n = len(calib_lists[0])
+        same_cameras = all(len(cl) == n and all(a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape) for a, b in zip(cl, calib_lists[0]))
+                           for cl in calib_lists[1:])
+        calibs0 = torch.stack([c.reshape(3, 4) for c in calib_lists[0]]).to(dtype=torch.float32)
+        if same_cameras and pipe_frame_ok(mods, n, feats):
+            pipe_frame(mods, feats, calibs0, grid, crange, out=out)
+        elif same_cameras and fused_frame_ok(mods, n):
+            fused_frame(mods, feats, calibs0, grid, crange, out=out)
+        else:
+            for i, (m, f, cl) in enumerate(zip(mods, feats, calib_lists)):
+                m.project_sum(f, torch.stack([c.reshape(3, 4) for c in cl]).to(dtype=torch.float32), grid, crange, out=out, accumulate=i > 0)
+    return out.view(1, length, width, c_out).permute(0, 3, 1, 2)
 
 
 def box_parameters(module, calibs, grid, feat_hw, crange=(-1, 0.95)):
