@@ -630,13 +630,17 @@ def main():
     # -- what train.py / predict.py get from the one-line import swap of INTEGRATION.md section 1, without `aggregate_views`
     if a.fp32_steps > 0 and world == 1 and a.channels == 256 and len(leg.cams) > 0:
         lats = leg.sets[0]
+        # (the reference forms lat8 / lat16 / lat32 per camera inside its loop -- relu(bn(lat(feat))), vfanet.py:72-74 --: the
+        # projector gets 21 SEPARATE tensors, resident in HBM when the path starts; they are made here, outside the timed loop)
+        per_cam = [[lats[s][cam:cam + 1].clone() for s in range(3)] for cam in range(len(leg.cams))]
 
         def reference_loop():
             ortho = 0
             for cam in range(len(leg.cams)):
-                f8 = leg.mods[0](lats[0][[cam], ...], leg.calibs[cam], leg.grid)
-                f16 = leg.mods[1](lats[1][[cam], ...], leg.calibs[cam], leg.grid)
-                f32 = leg.mods[2](lats[2][[cam], ...], leg.calibs[cam], leg.grid)
+                lat8, lat16, lat32 = per_cam[cam]
+                f8 = leg.mods[0](lat8, leg.calibs[cam], leg.grid)
+                f16 = leg.mods[1](lat16, leg.calibs[cam], leg.grid)
+                f32 = leg.mods[2](lat32, leg.calibs[cam], leg.grid)
                 ortho = ortho + (f8 + f16 + f32)
             # (the reference hands `ortho` to `self.fuse`, a conv: the first torch function it meets computes a deferred result -- here
             # that use is spelled out; with VFA_AMD_LAZY=0 every call above has already computed)

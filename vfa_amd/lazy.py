@@ -9,10 +9,10 @@ The reference calls the projector once per (camera, scale) and sums in Python (`
 With the one-line import swap of INTEGRATION.md that loop runs on this build's ``VFA`` modules.  Executed call by call it is
 HOST-bound: 21 calls x ~275 us of Python / launch overhead = 5.8 ms per MultiviewC frame, ten times the batched frame, and every call
 launches the persistent kernel for a twenty-first of its work.  So in inference (no gradient wanted) ``VFA.forward`` returns a
-``DeferredOrtho`` instead of a tensor: a record of (module, feature map, calibration) that knows its shape, adds to other records of the
-same grid (``f8 + f16 + f32``, ``ortho += ...``, ``0 + ...``) and turns into the real ``(1, C, L, W)`` tensor the first time anything
-else is asked of it -- any ``torch`` function (``self.fuse(ortho)`` is ``F.conv2d``), any tensor method or attribute, indexing,
-arithmetic with a real tensor.  By then the record holds the whole frame, and ONE batched launch (``fused_frame`` / ``pipe_frame``:
+``DeferredOrtho``: a ``torch.Tensor`` subclass without storage (a wrapper: shape, dtype and device are real) that holds a record of
+(module, feature map, calibration), adds to other records of the same grid (``f8 + f16 + f32``, ``ortho += ...``, ``0 + ...``) and is
+replaced by the real ``(1, C, L, W)`` tensor the first time anything else is asked of it -- any ``torch`` function (``self.fuse(ortho)``
+is ``F.conv2d``), any tensor method, indexing, arithmetic with a real tensor (all of them arrive at ``__torch_function__``).  By then the record holds the whole frame, and ONE batched launch (``fused_frame`` / ``pipe_frame``:
 the path ``aggregate_views`` takes) computes it: the loop costs the batched frame plus bookkeeping.
 
 Sums are re-associated exactly as ``aggregate_views`` re-associates them (inside the post-GEMM tolerance; pre-GEMM tensors are
@@ -30,59 +30,29 @@ def _is_zero(x):
     return isinstance(x, (int, float)) and not isinstance(x, bool) and x == 0
 
 
-class DeferredOrtho:
-    """Sum of not-yet-computed ``VFA.forward`` results on one grid.  Not a ``torch.Tensor`` subclass: it takes part in torch's
-    ``__torch_function__`` protocol (any torch function that receives it gets the materialised tensor) and forwards everything
-    else to that tensor."""
+def _real(x):
+    if isinstance(x, DeferredOrtho):
+        return x.materialize()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_real(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _real(v) for k, v in x.items()}
+    return x
 
-    __slots__ = ("_terms", "_grid", "_crange", "_value", "_shape", "_device")
 
-    def __init__(self, terms, grid, crange, shape, device):
-        self._terms, self._grid, self._crange, self._value, self._shape, self._device = terms, grid, crange, None, shape, device
+class DeferredOrtho(torch.Tensor):
+    """Sum of not-yet-computed ``VFA.forward`` results on one grid: a wrapper tensor (no storage) whose every use goes through
+    ``__torch_function__``."""
 
-    # ------------------------------------------------------------------ cheap facts that need no computation
-    @property
-    def shape(self):
-        return torch.Size(self._shape)
+    @staticmethod
+    def __new__(cls, terms, grid, crange, shape, device):
+        r = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=torch.float32, device=device, requires_grad=False)
+        r._terms, r._grid, r._crange, r._value = terms, grid, crange, None
+        return r
 
-    @property
-    def dtype(self):
-        return torch.float32
+    def __init__(self, *a, **k):
+        pass
 
-    @property
-    def device(self):
-        return self._device
-
-    @property
-    def requires_grad(self):
-        return False
-
-    @property
-    def is_cuda(self):
-        return True
-
-    def size(self, dim=None):
-        return torch.Size(self._shape) if dim is None else self._shape[dim]
-
-    def dim(self):
-        return len(self._shape)
-
-    # ------------------------------------------------------------------ sums of pending results stay pending
-    def _same_frame(self, other):
-        return (isinstance(other, DeferredOrtho) and other._value is None and self._value is None and other._grid is self._grid
-                and other._crange == self._crange and other._shape == self._shape)
-
-    def __add__(self, other):
-        if _is_zero(other):
-            return self
-        if self._same_frame(other):
-            return DeferredOrtho(self._terms + other._terms, self._grid, self._crange, self._shape, self._device)
-        return self.materialize() + (other.materialize() if isinstance(other, DeferredOrtho) else other)
-
-    __radd__ = __add__
-    __iadd__ = __add__
-
-    # ------------------------------------------------------------------ everything else wants the tensor
     def materialize(self):
         if self._value is None:
             from . import vfa_op
@@ -90,73 +60,47 @@ class DeferredOrtho:
             self._terms = None
         return self._value
 
+    def _merge(self, other):
+        """self + other as a record, or None when the sum must be computed."""
+        if _is_zero(other):
+            return self
+        if (isinstance(other, DeferredOrtho) and other._value is None and self._value is None and other._grid is self._grid
+                and other._crange == self._crange and other.shape == self.shape):
+            with torch._C.DisableTorchFunctionSubclass():
+                return DeferredOrtho(self._terms + other._terms, self._grid, self._crange, tuple(self.shape), self.device)
+        return None
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
-        def real(x):
-            if isinstance(x, DeferredOrtho):
-                return x.materialize()
-            if isinstance(x, (list, tuple)):
-                return type(x)(real(v) for v in x)
-            return x
-        return func(*real(args), **{k: real(v) for k, v in (kwargs or {}).items()})
+        kwargs = kwargs or {}
+        if func in _METADATA:  # shape, dtype, device, ...: the wrapper knows them
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        if func in _ADDS and len(args) == 2 and not kwargs:  # sums of records stay records
+            a, b = args
+            merged = a._merge(b) if isinstance(a, DeferredOrtho) else (b._merge(a) if isinstance(b, DeferredOrtho) else None)
+            if merged is not None:
+                return merged
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*_real(args), **_real(kwargs))
 
-    def __getattr__(self, name):  # (only reached for names not defined above)
-        return getattr(self.materialize(), name)
-
-    def __getitem__(self, idx):
-        return self.materialize()[idx]
-
-    def __len__(self):
-        return self._shape[0]
-
-    def __iter__(self):
-        return iter(self.materialize())
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # (wrapper subclasses must define it; every use is intercepted one level up, in __torch_function__ -- what still arrives here
+        # came in below the Python API: compute and run on the real tensors)
+        return func(*_real(args), **_real(kwargs or {}))
 
     def __repr__(self):
-        return repr(self.materialize()) if self._value is not None else f"DeferredOrtho({len(self._terms)} VFA.forward results, shape {tuple(self._shape)})"
+        if self._value is not None:
+            return repr(self._value)
+        return f"DeferredOrtho({len(self._terms)} VFA.forward results, shape {tuple(self.shape)})"
 
-    def __neg__(self):
-        return -self.materialize()
 
-    def __sub__(self, other):
-        return self.materialize() - materialize(other)
-
-    def __rsub__(self, other):
-        return materialize(other) - self.materialize()
-
-    def __mul__(self, other):
-        return self.materialize() * materialize(other)
-
-    __rmul__ = __mul__
-
-    def __truediv__(self, other):
-        return self.materialize() / materialize(other)
-
-    def __rtruediv__(self, other):
-        return materialize(other) / self.materialize()
-
-    def __matmul__(self, other):
-        return self.materialize() @ materialize(other)
-
-    def __eq__(self, other):
-        return self.materialize() == materialize(other)
-
-    def __ne__(self, other):
-        return self.materialize() != materialize(other)
-
-    def __lt__(self, other):
-        return self.materialize() < materialize(other)
-
-    def __gt__(self, other):
-        return self.materialize() > materialize(other)
-
-    def __le__(self, other):
-        return self.materialize() <= materialize(other)
-
-    def __ge__(self, other):
-        return self.materialize() >= materialize(other)
-
-    __hash__ = object.__hash__
+_T = torch.Tensor
+_METADATA = {_T.shape.__get__, _T.dtype.__get__, _T.device.__get__, _T.requires_grad.__get__, _T.ndim.__get__, _T.is_cuda.__get__,
+             _T.layout.__get__, _T.grad_fn.__get__, _T.is_leaf.__get__, _T.names.__get__, _T.size, _T.dim, _T.ndimension, _T.__len__,
+             _T.is_floating_point, _T.is_complex, _T.numel, _T.nelement}
+_ADDS = {_T.add, _T.__add__, _T.__radd__, _T.__iadd__, _T.add_, torch.add}
 
 
 def materialize(x):

@@ -672,22 +672,31 @@ class VFA(nn.Module):
         length, width = grid.shape[-3], grid.shape[-2]
         if visualize:
             self.visualize_cube(feature, calib, grid, crange)
+        if lazy.LAZY and not torch.is_grad_enabled() and grid.dim() >= 3 and feature.is_cuda and calib.is_cuda and grid.is_cuda \
+                and feature.shape[1] == self.channel and self._defer_ok():
+            # Inference through a per-frame kernel: the result is DEFERRED (vfa_amd/lazy.py) -- the reference's loop over cameras and
+            # scales (vfanet.py:64-82) then costs one batched frame instead of 21 launches of a persistent kernel.  (The check is the
+            # cheap one on purpose: this branch is taken 21 times per frame on the host.)
+            return lazy.DeferredOrtho([(self, feature, feature._version, calib)], grid, (float(crange[0]), float(crange[1])),
+                                      (1, self.collapse.out_features, length, width), feature.device)
         if grid.dim() >= 3 and fused_train_ok([self], 1, (feature,)):
             ortho = fused_frame_train([self], [feature], calib.reshape(1, 3, 4), grid, crange)
         elif self.mfma_collapse_ok(feature) or (grid.dim() >= 3 and pipe_frame_ok([self], 1, (feature,))):
-            if lazy.LAZY and grid.dim() >= 3 and (pipe_frame_ok([self], 1, (feature,)) or fused_frame_ok([self], 1)):
-                # inference through a per-frame kernel: the result is DEFERRED (vfa_amd/lazy.py) -- the reference's loop over cameras
-                # and scales (vfanet.py:64-82) then costs one batched frame instead of 21 launches of a persistent kernel
-                _lib.require_device(feature, calib, grid)  # (no CPU path: fail at the call, not at the first use)
-                if feature.shape[1] != self.channel:
-                    raise ValueError(f"feature has {feature.shape[1]} channels, VFA was built for {self.channel}")
-                return lazy.DeferredOrtho([(self, feature, feature._version, calib)], grid, (float(crange[0]), float(crange[1])),
-                                         (1, self.collapse.out_features, length, width), feature.device)
             ortho = self.project_sum(feature, calib.reshape(1, 3, 4), grid, crange)
         else:
             lin = self.project_views(feature, calib.reshape(1, 3, 4), grid, crange)
             ortho = _BiasReluSum.apply(lin, self.collapse.bias)
         return ortho.view(1, length, width, self.collapse.out_features).permute(0, 3, 1, 2)
+
+    def _defer_ok(self):
+        """A per-frame inference kernel covers this module on its own (what ``_materialize`` can always fall back to), memoised on the
+        switches that decide it."""
+        key = (PIPE, PIPE_SINGLE_LAYER, FUSED_POOL, COLLAPSE_KERNEL, self.num_grid_layer, self.channel, self.collapse.out_features)
+        cached = getattr(self, "_defer_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, bool(pipe_frame_ok([self], 1) or fused_frame_ok([self], 1)))
+            self._defer_cache = cached
+        return cached[1]
 
     def extra_repr(self):
         return f"channel={self.channel}, layers={self.num_grid_layer}, data={getattr(self.args, 'data', None)}"
