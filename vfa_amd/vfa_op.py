@@ -108,7 +108,7 @@ class _CollapseGemm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vox2d, weight, reserved_cus=0):
         ctx.save_for_backward(vox2d, weight)
-        return ops.collapse_gemm(vox2d, weight, terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
+        return ops.collapse_gemm(vox2d, weight, terms=_unfused_terms(), reserved_cus=reserved_cus)
 
     @staticmethod
     def backward(ctx, grad):
@@ -382,8 +382,11 @@ class _FusedFrameTrain(torch.autograd.Function):
     voxel features are pooled again from the kept integral images (bit-identical to what the forward pooled), ``lin = vox . W^T``
     is formed again with the MFMA tile GEMM (the ReLU mask), then the usual gradients: d lin = d out * (lin + b > 0),
     d W += d lin^T . vox, d b, d vox = d lin . W, scattered back through the box pooling
-    (``vfa_project_gather_backward_f32``) and the two cumsums.  Gradients are those of the unfused path up to the summation
-    order of the recomputed product (a pre-activation within ~1e-6 of zero may take the other side of the ReLU)."""
+    (``vfa_project_gather_backward_f32``) and the two cumsums.  The forward's product is the fp16 x 2 split (~2e-7 of max|lin|),
+    the recomputed one the bf16 x 2 form of the tile GEMM (``vfa_collapse_gemm_relu_backward_f32``, ~4e-6: it has no fp16 form): a
+    pre-activation within ~4e-6 max|lin| of zero may take the other side of the ReLU in the backward.  Measured against the
+    reference's own fp32 ``backward()`` (tests/test_reference_gradients.py): d weight / d bias within 6e-7, d feature within the
+    reference's own fp32-vs-float64 noise -- the window is two orders of magnitude inside what fp32 itself leaves open."""
 
     @staticmethod
     def forward(ctx, calibs, grid, crange, meta, reserved_cus, *tensors):
@@ -434,12 +437,12 @@ class _FusedFrameTrain(torch.autograd.Function):
                     count = min(chunk, n_cells - begin)
                     vox = ops.project_gather(integral, cal, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h), crange,
                                              cell_begin=begin, cell_count=count)
-                    # (the product of the forward -- the same bf16-split MFMA arithmetic decides the ReLU mask -- with the mask as its
-                    # epilogue: d lin and d b come out, the pre-activations are never written)
+                    # (the product again, as the two-piece bf16 MFMA tile GEMM -- the unfused product kernels have the bf16 forms only:
+                    # `_unfused_terms` -- with the ReLU mask as its epilogue: d lin and d b come out, the pre-activations are never written)
                     if count >= 32:
-                        g_lin, g_b_part = ops.collapse_gemm_relu_backward(vox, w_lm, b, grad_out[begin:begin + count], terms=COLLAPSE_TERMS)
+                        g_lin, g_b_part = ops.collapse_gemm_relu_backward(vox, w_lm, b, grad_out[begin:begin + count], terms=_unfused_terms())
                     else:  # (fewer than 32 cells in the chunk: product, then the mask kernel)
-                        lin = ops.collapse_gemm(vox.view(n * count, nl * C), w_lm, terms=COLLAPSE_TERMS).view(n, count, C)
+                        lin = ops.collapse_gemm(vox.view(n * count, nl * C), w_lm, terms=_unfused_terms()).view(n, count, C)
                         g_lin, g_b_part = ops.relu_mask_backward(grad_out[begin:begin + count], lin, b)
                         del lin
                     if need_b:
@@ -500,7 +503,7 @@ def window_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accu
         for k, (m, integral) in enumerate(zip(mods, integrals)):
             ops.pool_windows(integral, ws, (length, width), len(mods), k, out=vox)
             ops.collapse_relu_sum(vox, m.layer_major_weight(), m.collapse.bias, out=out, accumulate=accumulate or k > 0,
-                                  terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
+                                  terms=_unfused_terms(), reserved_cus=reserved_cus)
     return out
 
 
@@ -661,7 +664,7 @@ class VFA(nn.Module):
                 vox = ops.project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h),
                                          (float(crange[0]), float(crange[1])), cell_begin=begin, cell_count=count)
                 ops.collapse_relu_sum(vox, weight, self.collapse.bias, out=out[begin:begin + count],
-                                      accumulate=accumulate, terms=COLLAPSE_TERMS, reserved_cus=reserved_cus)
+                                      accumulate=accumulate, terms=_unfused_terms(), reserved_cus=reserved_cus)
         return out
 
     # ------------------------------------------------------------------ reference interface
