@@ -824,6 +824,10 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) tb[i][j] = rw[i] + cl[j];
+            // (Tried in round 5, slower: a ROLLING form -- four taps at a time into two register quads, the reads of sample k + 1 in front of
+            // the FMA chain of sample k, the next quarter's first sample in front of this quarter's quotient / split / stores -- 480 us
+            // against 445 per launch in an A/B on one device: 256 registers, eight of them spilled inside the loop, and the scheduling
+            // barriers it needs keep the compiler from interleaving reads and arithmetic on its own.)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 lt, rb, rt, lb;

@@ -103,7 +103,9 @@ class _BoxPool(torch.autograd.Function):
 
 class _CollapseGemm(torch.autograd.Function):
     """lin (M,N) = vox (M,K) @ weight (N,K)^T.  Forward: the hand-written bf16-split MFMA tile GEMM
-    (``vfa_collapse_gemm_f32``); backward: the two fp32 library products."""
+    (``vfa_collapse_gemm_f32``); backward: the hand-written gradient products of vfa_grad.hip (six bf16 MFMA products of a three-piece
+    split, sgemm class: ``vfa_grad_input_f32``, ``vfa_grad_weight_f32``) where their shapes fit (N = 256, K a multiple of 256), the
+    fp32 library products otherwise."""
 
     @staticmethod
     def forward(ctx, vox2d, weight, reserved_cus=0):
@@ -114,8 +116,12 @@ class _CollapseGemm(torch.autograd.Function):
     def backward(ctx, grad):
         vox2d, weight = ctx.saved_tensors
         grad = grad.contiguous()
-        g_vox = torch.matmul(grad, weight) if ctx.needs_input_grad[0] else None
-        g_w = torch.matmul(grad.t(), vox2d) if ctx.needs_input_grad[1] else None
+        hand = grad.shape[1] == 256 and weight.shape[0] == 256 and weight.shape[1] % 256 == 0 and grad.shape[0] > 0
+        g_vox = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_vox = ops.grad_input(grad, weight) if hand else torch.matmul(grad, weight)
+        if ctx.needs_input_grad[1]:
+            g_w = ops.grad_weight(grad, vox2d) if hand else torch.matmul(grad.t(), vox2d)
         return g_vox, g_w, None
 
 
