@@ -668,7 +668,7 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
     // The source offsets of a wave's fills (slots wave, wave + 4, ...: at most 32) are computed ONCE per item, lane j that of
     // fill j, with a handful of vector instructions; the MFMA loop then reads them back with v_readlane: 5 instructions per
     // fill where the closed form took ~20 dependent scalar ones, in a wave that issues in order, in front of its next MFMA.
-    constexpr int kFillWaves = 4; // waves 0-3 bring the window in (see begin_fills)
+    constexpr int kFillWaves = 4; // waves 0-3 bring the window in (see begin_fills; 2 or 8 waves measured 2.5 % slower in round 5)
     int f_slot = 0, f_n = 0;
     unsigned f_off = 0; // lane j: byte offset of this wave's j-th slot inside the view's padded integral image (< 4 GiB)
     const char *f_img = nullptr;
@@ -980,6 +980,10 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         if (nxt.valid) header_get(nh, hbuf); // (the header of the next item landed with that wait)
         tick(2);
         flush();
+        // (Tried in round 5, no gain: W of the NEXT scale requested at the end of the last item of this one -- behind the fills, waited
+        // for with a counted vmcnt(32) at the head of the loop -- 446-448 us against 443 per launch in an A/B on one device.  Also
+        // without effect: the younger wave of every SIMD delayed by 128 - 512 cycles at the head of pooling (434-438 against 435);
+        // the window fills issued by 2 or 8 waves instead of 4: 453 / 455 against 442.)
         if (cur.scale != w_scale && !((dbg & kDbgOneW) && w_scale >= 0)) { // W and bias of this scale: land while the boxes are pooled
             load_weights(cur.scale);
             bc = bias_of(cur.scale);
