@@ -666,3 +666,37 @@ def test_repeated_launches_on_one_workspace_find_clear_hand_off_tickets():
             run(reserved_cus=248, out=acc, accumulate=True)
             torch.testing.assert_close(acc, first[0] + first[248], rtol=1e-6, atol=0)
         torch.cuda.synchronize()
+
+
+def test_product_form_of_workspace_and_launch_must_agree():
+    """The geometry call splits ``collapse.weight`` for ONE arithmetic (fp16 pieces, or bf16 pieces) and leaves a tag beside the weight
+    exponents; a collapse call that asks for the other form would read fp16 fragments as bf16 numbers.  It must fail LOUDLY: the frame
+    kernels check the tag and write a map of NaNs; diagnostic flags with a non-default form are refused outright.  Serial and pipelined
+    kernel."""
+    import vfa_amd
+    from vfa_amd import _lib, ops
+    from vfa_amd.synthetic import make_workload
+    dev = _dev()
+    wl = make_workload("multiviewc_200x200x1", channels=256, seed=3, n_cam=2, device=dev)
+    grid = wl["grid"][:, 40:72, 40:104].contiguous()
+    L, W = grid.shape[1:3]
+    mods = _mods(wl, dev)
+    lats = [torch.cat([wl["features"][c][s] for c in range(2)]) for s in range(3)]
+    zl, co = mods[0]._kernel_geometry(dev)
+    kind, img_wh, sizes = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1], [tuple(l.shape[-2:]) for l in lats]
+    biases = [m.collapse.bias for m in mods]
+    with torch.no_grad():
+        integrals = ops.integral_images(lats)
+        ws3 = ops.frame_records(wl["calibs"], grid, zl, co, kind, img_wh, sizes, weights=[m.layer_major_weight().contiguous() for m in mods], terms=3)
+        ok = ops.pool_collapse(integrals, biases, ws3, (L, W), terms=3)
+        bad = ops.pool_collapse(integrals, biases, ws3, (L, W), terms=2)          # fp16 kernel on bf16 fragments
+        assert torch.isfinite(ok).all() and torch.isnan(bad).all()
+        with pytest.raises(_lib.VFAHipError):
+            ops.pool_collapse(integrals, biases, ws3, (L, W), terms=3, debug=128)  # the diagnostic build is the default form's
+        wp2 = ops.pipe_records(wl["calibs"], grid, zl, co, kind, img_wh, sizes, weights=[m.collapse.weight for m in mods], terms=2)
+        okp = ops.pipe_collapse(integrals, biases, wp2, (L, W), 1, terms=2)
+        badp = ops.pipe_collapse(integrals, biases, wp2, (L, W), 1, terms=3)       # bf16 kernel on fp16 fragments
+        assert torch.isfinite(okp).all() and torch.isnan(badp).all()
+        with pytest.raises(_lib.VFAHipError):
+            ops.pipe_collapse(integrals, biases, wp2, (L, W), 1, terms=6, debug=128)
+    torch.cuda.synchronize()
