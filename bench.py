@@ -62,6 +62,7 @@ def parse():
     p.add_argument("--rotate", type=int, default=4, help="input sets of the rotating-input leg (0 disables)")
     p.add_argument("--fp32-steps", type=int, default=20, help="timed steps of the fp32-arithmetic collapse leg (0 disables)")
     p.add_argument("--proxy-steps", type=int, default=20, help="timed steps of the per-rank proxy legs (0 disables)")
+    p.add_argument("--loop-steps", type=int, default=10, help="timed frames of the reference_loop leg: the reference's 21-call camera loop (0 disables)")
     p.add_argument("--tune-gemm", type=int, default=0,
                    help="1: TunableOp selects the library GEMM in warm-up (only used with VFA_AMD_COLLAPSE=library)")
     return p.parse_args()
@@ -628,7 +629,7 @@ def main():
                                        "per-rank compute time, NOT a scaling measurement")
     # ---- the drop-in AS THE REFERENCE CALLS IT (vfanet.py:64-82): per camera three `VFA.forward` calls, `f8 + f16 + f32`, `ortho +=`
     # -- what train.py / predict.py get from the one-line import swap of INTEGRATION.md section 1, without `aggregate_views`
-    if a.fp32_steps > 0 and world == 1 and a.channels == 256 and len(leg.cams) > 0:
+    if a.loop_steps > 0 and world == 1 and a.channels == 256 and len(leg.cams) > 0:
         lats = leg.sets[0]
         # (the reference forms lat8 / lat16 / lat32 per camera inside its loop -- relu(bn(lat(feat))), vfanet.py:72-74 --: the
         # projector gets 21 SEPARATE tensors, resident in HBM when the path starts; they are made here, outside the timed loop)
@@ -653,7 +654,7 @@ def main():
             leg.fence()
             scale_l = float(want_loop.abs().max())
             err_l = float((got_loop - want_loop).abs().max()) / scale_l
-            reps = max(3, a.fp32_steps // 2)
+            reps = max(3, a.loop_steps)
             gc.collect()
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -681,6 +682,48 @@ def main():
                 extra["reference_loop"]["eager_calls_ms_per_frame"] = 1e3 * (time.perf_counter() - t0) / 3
             finally:
                 _lazy.LAZY = True
+    # ---- a STATIC rig: the geometry (box records, windows, work cuts, split weights) formed once, frames = integral images + the frame
+    # kernel (vfa_amd.FrameGeometry: an explicit contract of the caller).  NOT `value`: the reference projects every frame, and so does
+    # the primary leg.  For rank 0's cameras of an N-rank frame too (the fixed per-frame costs a rank cannot shrink).
+    if a.loop_steps > 0 and world == 1 and a.channels == 256 and len(leg.cams) > 0:
+        static = {}
+        for nranks in (1, 8):
+            cams = leg.cams if nranks == 1 else vfa_amd.camera_shard(leg.n_frame, 0, nranks)
+            if not cams:
+                continue
+            idx = torch.tensor(cams, dtype=torch.long, device=dev)
+            feats = [f[idx].contiguous() for f in leg.sets[0]]
+            cal = leg.calibs[idx].contiguous()
+            try:
+                geom = vfa_amd.FrameGeometry(leg.mods, cal, leg.grid, [tuple(f.shape[-2:]) for f in feats])
+            except ValueError:
+                break  # (a frame processed in bands: one geometry per band, not timed here)
+            with torch.no_grad():
+                want_s = vfa_amd.aggregate_views(*leg.mods, *feats, cal, leg.grid, distributed=False)
+                same = bool(torch.equal(geom.frame(feats), want_s))
+                for _ in range(5):
+                    geom.frame(feats)
+                leg.fence()
+                reps = max(10, 4 * a.loop_steps)
+                gc.collect()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    geom.frame(feats)
+                leg.fence()
+                ms_s = 1e3 * (time.perf_counter() - t0) / reps
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    vfa_amd.aggregate_views(*leg.mods, *feats, cal, leg.grid, distributed=False)
+                leg.fence()
+                ms_d = 1e3 * (time.perf_counter() - t0) / reps
+            static[str(nranks)] = {"cameras": len(cams), "ms_per_frame": ms_s, "ms_per_frame_geometry_every_frame": ms_d,
+                                   "bit_identical": same}
+            del geom
+        if static:
+            extra["static_rig"] = dict(static, note="vfa_amd.FrameGeometry: the rig's geometry computed ONCE (the caller's contract: cameras, grid and "
+                                       "weights stand still), then per frame the integral images + the persistent kernel; keys = ranks of a "
+                                       "camera-sharded frame (1: the whole rig; 8: rank 0's camera); beside it the same frames through "
+                                       "aggregate_views, which recomputes the geometry every frame like the reference and like `value`")
     # ---- the producer in front of the path, NOT part of `value` (the path starts at lateral maps resident in HBM):
     # trunk outputs -> the three integral images through the hand-written lateral branch (fp32-MFMA 1x1 convolution, channels-last,
     # GroupNorm statistics in its epilogue; affine + ReLU inside the row scan) and through the library's operations

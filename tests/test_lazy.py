@@ -116,3 +116,28 @@ def test_reference_style_loop_equals_the_batched_frame(name, n_cam, monkeypatch)
         assert isinstance(eager, torch.Tensor) and not isinstance(eager, lazy.DeferredOrtho)
         scale = want.abs().max().item()
         torch.testing.assert_close(eager, want, rtol=1e-4, atol=1e-5 * scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n_cam", [("multiviewc_200x200x1", 4), ("multiviewc_156x156x5", 3), ("multiviewc_200x200x1", 1)])
+def test_frame_geometry_of_a_static_rig_is_the_per_frame_path_bit_for_bit(name, n_cam):
+    """``vfa_amd.FrameGeometry``: the geometry of a static rig formed once, frames = integral images + the frame kernel.  Several
+    frames of different feature maps against ``aggregate_views`` (which recomputes the geometry every frame, like the reference:
+    vfa_op.py:64-106): the same bits; a changed weight is noticed."""
+    import vfa_amd
+    from vfa_amd.synthetic import make_workload
+    dev = torch.device("cuda:0")
+    wl = make_workload(name, channels=256, seed=8, n_cam=n_cam, device=dev)
+    grid = wl["grid"][:, 24:88, 16:112].contiguous()
+    torch.manual_seed(5)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
+    lats = [torch.cat([wl["features"][c][s] for c in range(n_cam)]) for s in range(3)]
+    geom = vfa_amd.FrameGeometry(mods, wl["calibs"], grid, [tuple(l.shape[-2:]) for l in lats])
+    with torch.no_grad():
+        for k in range(3):
+            frame = [torch.relu(l + 0.3 * k * torch.randn_like(l)) for l in lats]
+            want = vfa_amd.aggregate_views(*mods, *frame, wl["calibs"], grid)
+            assert torch.equal(geom.frame(frame), want), k
+        mods[1].collapse.weight.mul_(1.5)
+        with pytest.raises(RuntimeError):
+            geom.frame(lats)

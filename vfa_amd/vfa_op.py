@@ -771,3 +771,72 @@ def box_parameters(module, calibs, grid, feat_hw, crange=(-1, 0.95)):
     box, area, visible = ops.box_params(calibs, grid.reshape(-1, 3), z_layers, corner_off, conv_kind, (img_w, img_h),
                                         feat_hw, crange)
     return dict(box=box, area=area, visible=visible.bool())
+
+
+class FrameGeometry:
+    """The geometry of a STATIC camera rig, computed once instead of once per frame.
+
+    The reference projects every cube of the grid through every camera in every ``VFA.forward`` (vfa_op.py:64-106): cameras may move.
+    In a deployment they do not -- calibrations, grid and ``collapse`` weights stand still for a whole stream -- and everything the
+    frame kernels read besides the feature maps (box records, tap windows, work cuts, the split weights) can be formed ONCE:
+
+    >>> geom = vfa_amd.FrameGeometry([vfa8, vfa16, vfa32], calibs, grid, [(90, 160), (45, 80), (23, 40)])
+    >>> ortho = geom.frame([lat8, lat16, lat32])            # per frame: integral images + ONE persistent kernel
+
+    ``frame`` returns the (1, C, L, W) view ``aggregate_views`` returns, bit for bit.  This is an explicit contract of the CALLER
+    (nothing here can notice a camera that moved; a changed ``collapse.weight`` / ``bias`` IS noticed -- version counters -- and
+    raises): the default paths (``aggregate_views``, ``VFA.forward``, ``bench.py``'s ``value``) recompute the geometry every frame
+    like the reference.  One frame at a time per object (its workspace holds the hand-off slots of the launch in flight).
+    Inference only."""
+
+    def __init__(self, mods, calibs, grid, feat_hws, crange=(-1, 0.95), reserved_cus=0):
+        mods = list(mods)
+        _lib.require_device(calibs, grid)
+        n = calibs.shape[0]
+        self.pipe = pipe_frame_ok(mods, n)
+        if not self.pipe and not fused_frame_ok(mods, n):
+            raise ValueError("FrameGeometry needs a module set the per-frame inference kernels cover (C = 256, one layer count, <= 32 cameras)")
+        m0 = mods[0]
+        grid3 = grid.reshape(grid.shape[-3], grid.shape[-2], 3)
+        self.length, self.width = grid3.shape[0], grid3.shape[1]
+        self.mods, self.n, self.nl, self.crange, self.reserved_cus = mods, n, m0.num_grid_layer, crange, int(reserved_cus)
+        self.feat_hws = [tuple(int(v) for v in hw) for hw in feat_hws]
+        dev = calibs.device
+        z_layers, corner_off = m0._kernel_geometry(dev)
+        conv_kind = _conv_kind(m0.args)
+        img_h, img_w = (float(v) for v in m0.args.image_size)
+        with torch.no_grad():
+            if self.pipe:
+                self.terms = COLLAPSE_TERMS
+                if ops.pipe_workspace_bytes(n, self.length, self.width, self.nl, len(mods)) > PIPE_WS_LIMIT:
+                    raise ValueError("FrameGeometry: this frame is processed in bands of grid rows (workspace above VFA_AMD_PIPE_WS_BYTES); "
+                                     "build one FrameGeometry per band of the grid")
+                self.ws = ops.pipe_records(calibs, grid3, z_layers, corner_off, conv_kind, (img_w, img_h), self.feat_hws,
+                                           weights=[m.collapse.weight for m in mods], crange=crange, terms=self.terms)
+                if PIPE_BALANCE:
+                    ops.pipe_balance(self.ws, n, (self.length, self.width), self.nl, len(mods), reserved_cus=self.reserved_cus)
+            else:
+                self.terms = _fused_terms()
+                self.ws = ops.frame_records(calibs, grid3, z_layers, corner_off, conv_kind, (img_w, img_h), self.feat_hws,
+                                            weights=[m.layer_major_weight() for m in mods], crange=crange, terms=self.terms)
+        self._versions = [(m.collapse.weight._version, m.collapse.weight.data_ptr()) for m in mods]
+
+    def frame(self, features=None, integrals=None, out=None, accumulate=False):
+        """features: one (n, 256, Hf, Wf) lateral batch per scale (or ``integrals``: their integral images) -> (1, C, L, W)."""
+        if [(m.collapse.weight._version, m.collapse.weight.data_ptr()) for m in self.mods] != self._versions:
+            raise RuntimeError("FrameGeometry: a collapse.weight changed since the geometry (which holds its split fragments) was built")
+        with torch.no_grad():
+            if integrals is None:
+                _lib.require_device(*features)
+                if [tuple(f.shape[-2:]) for f in features] != self.feat_hws or any(f.shape[0] != self.n for f in features):
+                    raise ValueError("FrameGeometry.frame: feature maps of other shapes than the geometry was built for")
+                integrals = ops.integral_images(features)
+            biases = [m.collapse.bias for m in self.mods]
+            lw = (self.length, self.width)
+            if self.pipe:
+                res = ops.pipe_collapse(integrals, biases, self.ws, lw, self.nl, out=out, accumulate=accumulate, terms=self.terms,
+                                        reserved_cus=self.reserved_cus)
+            else:
+                res = ops.pool_collapse(integrals, biases, self.ws, lw, out=out, accumulate=accumulate, terms=self.terms,
+                                        reserved_cus=self.reserved_cus)
+        return res.view(1, self.length, self.width, res.shape[-1]).permute(0, 3, 1, 2)
