@@ -793,7 +793,8 @@ class FrameGeometry:
         mods = list(mods)
         _lib.require_device(calibs, grid)
         n = calibs.shape[0]
-        self.pipe = pipe_frame_ok(mods, n)
+        with torch.no_grad():  # (inference only: the parameters' requires_grad is not what decides here)
+            self.pipe = pipe_frame_ok(mods, n)
         if not self.pipe and not fused_frame_ok(mods, n):
             raise ValueError("FrameGeometry needs a module set the per-frame inference kernels cover (C = 256, one layer count, <= 32 cameras)")
         m0 = mods[0]
