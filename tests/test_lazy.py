@@ -132,6 +132,9 @@ def test_frame_geometry_of_a_static_rig_is_the_per_frame_path_bit_for_bit(name, 
     torch.manual_seed(5)
     mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
     lats = [torch.cat([wl["features"][c][s] for c in range(n_cam)]) for s in range(3)]
+    # (a state the eager path kept from an EARLIER geometry of the same shapes would run the uniform work split -- its balanced bounds
+    # carry another frame's signature -- and sum the tiles cut between workgroups in another association: start both from scratch)
+    vfa_op._pipe_states.clear()
     geom = vfa_amd.FrameGeometry(mods, wl["calibs"], grid, [tuple(l.shape[-2:]) for l in lats])
     with torch.no_grad():
         for k in range(3):
