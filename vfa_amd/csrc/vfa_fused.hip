@@ -982,7 +982,8 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
         flush();
         // (Tried in round 5, no gain: W of the NEXT scale requested at the end of the last item of this one -- behind the fills, waited
         // for with a counted vmcnt(32) at the head of the loop -- 446-448 us against 443 per launch in an A/B on one device.  Also
-        // without effect: the younger wave of every SIMD delayed by 128 - 512 cycles at the head of pooling (434-438 against 435);
+        // without effect: the younger wave of every SIMD delayed by 128 - 512 cycles at the head of pooling (434-438 against 435), or
+        // raised to priority 1 / 3 for the pooling pass (438.0 / 437.4-438.4 against 437.8);
         // the window fills issued by 2 or 8 waves instead of 4: 453 / 455 against 442.)
         if (cur.scale != w_scale && !((dbg & kDbgOneW) && w_scale >= 0)) { // W and bias of this scale: land while the boxes are pooled
             load_weights(cur.scale);
