@@ -340,3 +340,77 @@ def test_input_gradient_product_has_the_width_of_an_sgemm(rows, K):
     # row by row: no row of the ragged last block is lost or written twice
     worst = ((got.double() - want).abs().amax(1) / want.abs().amax(1).clamp_min(1e-30)).max().item()
     assert worst <= 2e-6, worst
+
+
+@pytest.mark.parametrize("name,n_cam,crop", [("multiviewc_200x200x1", 7, None), ("multiviewc_156x156x5", 2, (96, 156)), ("wildtrack_120x360x8", 2, (64, 360))])
+def test_recomputed_relu_mask_is_the_forwards_bit_for_bit(name, n_cam, crop):
+    """The training backward recomputes ``lin = vox . W^T + b`` to get the ReLU mask (the fused forward keeps no pre-activations).
+    With the default arithmetic it repeats the FORWARD's product -- fp16 pieces under the frame's scales, the per-item sliver shifts,
+    the accumulator started at bias 2^(ea+ew-shift), the three MFMA products in the frame kernels' order
+    (``vfa_collapse_gemm_relu_backward_f16_f32`` + ``vfa_sliver_shifts_u8``) -- so the mask must be the forward's on EVERY element.  The
+    forward's mask is observable on a frame of one view and one scale (out = relu(lin) 2^-k: positive exactly where lin is): every
+    (camera, scale) of the frame, serial kernel (single-layer grid) and pipelined kernel (5 and 8 layers; Wildtrack has shifted items).
+    The bf16 recompute of round 4 is counted beside it (reference: vfa_op.py:123-124 under trainer.py:41)."""
+    import vfa_amd
+    from vfa_amd import _lib, ops, vfa_op
+    from vfa_amd.synthetic import make_workload
+    dev = torch.device("cuda:0")
+    wl = make_workload(name, channels=256, seed=4, n_cam=n_cam if name != "wildtrack_120x360x8" else 7, device=dev)
+    cams = range(n_cam) if name != "wildtrack_120x360x8" else (4, 5)  # (cameras 4-5 of the Wildtrack rig see the sliver boxes)
+    grid = wl["grid"] if crop is None else wl["grid"][:, :crop[0], :crop[1]].contiguous()
+    L, W = grid.shape[1:3]
+    torch.manual_seed(3)
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
+    with torch.no_grad():
+        for m in mods:
+            m.collapse.weight.mul_(3.0)
+            m.collapse.bias.uniform_(-0.3, 0.1)
+    nl = mods[0].num_grid_layer
+    zl, co = mods[0]._kernel_geometry(dev)
+    kind, img_wh = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
+    grid_flat = grid.reshape(-1, 3).contiguous()
+    ones = torch.ones(L * W, 256, device=dev)
+    total = flipped_bf16 = shifted_rows = 0
+    with torch.no_grad():
+        for s, m in enumerate(mods):
+            w_lm = m.collapse.weight.view(256, 256, nl).permute(0, 2, 1).reshape(256, nl * 256).contiguous()
+            for cam in cams:
+                lat = wl["features"][cam][s]
+                cal = wl["calibs"][cam:cam + 1]
+                integrals = ops.integral_images([lat])
+                piped = vfa_op.pipe_frame_ok([m], 1)
+                frame = vfa_op.pipe_frame if piped else vfa_op.fused_frame
+                out = frame([m], None, cal, grid, integrals=integrals)            # (L*W, 256) = relu(lin) of this view and scale
+                mask_fwd = out > 0
+                vox = ops.project_gather(integrals[0], cal.reshape(1, 12).contiguous(), grid_flat, zl, co, kind, img_wh)
+                shifts = ops.sliver_shifts(cal, grid, zl, co, kind, img_wh, lat.shape[-2:], not piped)
+                g, _ = ops.collapse_gemm_relu_backward(vox, w_lm, m.collapse.bias, ones, absmax=integrals.absmax[0], shift=shifts)
+                g3, _ = ops.collapse_gemm_relu_backward(vox, w_lm, m.collapse.bias, ones, terms=3)
+                assert torch.equal(g[0] > 0, mask_fwd), (name, s, cam, int(((g[0] > 0) != mask_fwd).sum()))
+                total += mask_fwd.numel()
+                flipped_bf16 += int(((g3[0] > 0) != mask_fwd).sum())
+                shifted_rows += int((shifts > 0).sum())
+                assert 0.02 < mask_fwd.float().mean().item() < 0.98
+    print(f"[mask] {name}: {total} pre-activations, recomputed fp16 mask identical to the forward's; the bf16 recompute of round 4 "
+          f"differs on {flipped_bf16}; rows with a sliver shift: {shifted_rows}")
+
+
+def test_training_step_through_the_fused_node_uses_the_fp16_recompute():
+    """``aggregate_views`` with gradients wanted on a single-layer frame: the backward calls the fp16 form of the tile GEMM (the
+    forward's product) and the shift kernel; gradients still those of tests/test_reference_gradients.py (checked there)."""
+    import vfa_amd
+    from vfa_amd import ops
+    from vfa_amd.synthetic import make_workload
+    dev = torch.device("cuda:0")
+    wl = make_workload("multiviewc_200x200x1", channels=256, seed=2, n_cam=2, device=dev)
+    grid = wl["grid"][:, 60:124, 40:136].contiguous()
+    mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
+    lats = [torch.cat([wl["features"][c][s] for c in range(2)]).requires_grad_(True) for s in range(3)]
+    with ops.KernelTimer() as kt:
+        out = vfa_amd.aggregate_views(*mods, *lats, wl["calibs"], grid)
+        out.sum().backward()
+    torch.cuda.synchronize()
+    ran = set(kt.summary())
+    assert {"vfa_collapse_gemm_relu_backward_f16_f32", "vfa_sliver_shifts_u8", "vfa_grad_weight_f32"} <= ran, sorted(ran)
+    assert "vfa_collapse_gemm_relu_backward_f32" not in ran
+    assert all(torch.isfinite(l.grad).all() for l in lats)

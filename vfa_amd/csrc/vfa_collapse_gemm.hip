@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "vfa_hip.h"
+#include "vfa_split.h"
 
 
 namespace {
@@ -42,6 +43,13 @@ constexpr int kLoads = kTileRows * kChunk / 4 / kThreads; // float4 per thread a
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+using vfa_dev::f16x8;
+using vfa_dev::kExpA;
+using vfa_dev::kExpW;
+using vfa_dev::pow2f;
+using vfa_dev::split_exponent;
+using vfa_dev::split_f16x4;
+using vfa_dev::wave_max_u32;
 
 __device__ __forceinline__ void split_bf16(float x, __bf16 &hi, __bf16 &lo)
 {
@@ -71,6 +79,55 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float *__restri
     ws[base + 64] = lo.u;
 }
 
+// fp16 form (VFA_FLAG_TERMS 2: the arithmetic of the fused frame kernels, vfa_split.h): max |W| in kWmaxParts partial maxima, then the
+// fragments of W 2^ew split into two fp16 pieces, ew = the exponent that brings max|W| into [2^14, 2^15) -- what
+// split_weight_frag_kernel / pipe_split_weight_kernel of the frame kernels compute, so that the recomputed product of the training
+// backward sees the forward's operands bit for bit.  `tail` (behind the fragments): kWmaxParts partial maxima, then ew.
+constexpr int kWmaxParts = 32;
+__global__ __launch_bounds__(256) void gemm_weight_absmax_kernel(const float *__restrict__ weight, unsigned *tail, size_t count)
+{
+    __shared__ unsigned part[4];
+    unsigned m = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)kWmaxParts * 256) m = max(m, __float_as_uint(weight[i]) & 0x7fffffffu);
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) tail[blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+__global__ __launch_bounds__(256) void split_weight_f16_kernel(const float *__restrict__ weight, uint4 *__restrict__ ws, int K, unsigned *tail)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)(K / kChunk) * 8 * kStepsPerChunk * 64;
+    if (i >= total) return;
+    vfa_dev::fp16_saturate_mode(true);
+    unsigned m = 0u;
+    for (int k = 0; k < kWmaxParts; ++k) m = max(m, tail[k]);
+    const int ew = split_exponent(m, kExpW);
+    if (i == 0) reinterpret_cast<int *>(tail)[kWmaxParts] = ew;
+    const float sc = pow2f(ew);
+    const int lane = (int)(i & 63);
+    const int s = (int)((i >> 6) % kStepsPerChunk);
+    const int w = (int)((i >> 6) / kStepsPerChunk % 8);
+    const int c = (int)((i >> 6) / kStepsPerChunk / 8);
+    const int r = lane & 31, h = lane >> 5;
+    const float *src = weight + (size_t)(32 * w + r) * K + (size_t)kChunk * c + 16 * s + 8 * h;
+    uint2 h0, l0, h1, l1;
+    split_f16x4(src[0] * sc, src[1] * sc, src[2] * sc, src[3] * sc, h0, l0);
+    split_f16x4(src[4] * sc, src[5] * sc, src[6] * sc, src[7] * sc, h1, l1);
+    const size_t base = ((((size_t)c * 8 + w) * kStepsPerChunk + s) * 2) * 64 + lane;
+    ws[base] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    ws[base + 64] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
+// fp16 form: what the kernel needs beside the operands -- the feature statistics of the scale (the frame kernels' 2^ea), the weight
+// exponent (tail of the workspace) and the sliver shift of every row's item (vfa_sliver_shifts_u8; NULL: none)
+struct F16Args {
+    const unsigned *amax; int amax_n;
+    const int *wexp;             // -> ew
+    const unsigned char *shift;  // (shift_views, shift_cells) or NULL
+    long long shift_cells; int shift_views;
+};
+
 // MASK: the epilogue of the training backward (vfa_collapse_gemm_relu_backward_f32).  The product is the recomputed pre-activation;
 // instead of storing it the kernel stores  d lin = (lin + bias > 0) ? d out[cell] : 0  (row m = view * cells + cell: the gradient
 // of the view sum reaches every view alike) and adds the column sums of d lin to d bias -- `lin` never exists in memory.
@@ -83,8 +140,9 @@ struct MaskArgs {
 
 template <int TERMS, bool MASK>
 __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__restrict__ vox, const uint4 *__restrict__ ws,
-                                                               float *__restrict__ lin, long long M, int K, MaskArgs ma)
+                                                               float *__restrict__ lin, long long M, int K, MaskArgs ma, F16Args fa)
 {
+    constexpr bool F16 = TERMS == 2; // two fp16 pieces per operand under a power-of-two scale (vfa_split.h) instead of two bf16 pieces
     extern __shared__ __align__(16) unsigned char planes[]; // [buffer][hi / lo][128 rows][256 B]
     int *live = reinterpret_cast<int *>(planes + 2 * 2 * kPlane); // [item % 3][row block]: the chunk has a non-zero element there
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -92,12 +150,33 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
     const int n_chunks = K / kChunk;
     long long tile = blockIdx.x;
     if (tile >= n_tiles) return;
+    // fp16 form: 2^ea of the voxel features (largest |feature| the integral-image kernels saw: the frame kernels' own reduction) and ew
+    int ea = 0, ew = 0;
+    if constexpr (F16) {
+        __shared__ unsigned s_amax;
+        if (tid == 0) s_amax = 0u;
+        __syncthreads();
+        unsigned mx = 0u;
+        for (int i = tid; i < fa.amax_n; i += kThreads) mx = max(mx, fa.amax[i]);
+        mx = wave_max_u32(mx);
+        if (lane == 0) atomicMax(&s_amax, mx);
+        __syncthreads();
+        ea = split_exponent((unsigned)__builtin_amdgcn_readfirstlane((int)s_amax), kExpA);
+        ew = __builtin_amdgcn_readfirstlane(*fa.wexp);
+    }
+    // sliver shift of row m (its item's: vfa_geom.h): per (view, cell), or per cell for every view
+    auto shift_of = [&](long long m) -> int {
+        if (!F16 || !fa.shift) return 0;
+        const long long cell = m % fa.shift_cells;
+        return (int)fa.shift[fa.shift_views == 1 ? cell : m];
+    };
 
     // this thread's share of a chunk: float4 number tid + 512 i of the 128 x 32 float4 (row = idx / 32).
     // Every load of the main loop is UNCONDITIONAL (addresses are clamped instead): with straight-line loads the in-order
     // vmcnt counter lets the compiler wait for exactly the W fragments it needs and leave the younger HBM loads in
     // flight; with predicated loads it fell back to vmcnt(0) between them and before the first MFMA (1.5x slower).
     float4 pre[kLoads];
+    float row_scale[kLoads]; // fp16 form: 2^(ea - shift) of the row of pre[i]
     auto fetch = [&](long long t, int c) {
         const long long row0 = t * kTileRows;
 #pragma unroll
@@ -106,9 +185,11 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
             long long m = row0 + row;
             m = m < M ? m : M - 1; // rows past the end read a valid row; their outputs are never stored
             pre[i] = *reinterpret_cast<const float4 *>(vox + (size_t)m * K + (size_t)c * kChunk + 4 * c4);
+            if constexpr (F16) row_scale[i] = pow2f(ea - shift_of(m));
         }
     };
     auto stage = [&](int buf, int slot) {
+        if constexpr (F16) vfa_dev::fp16_saturate_mode(true); // (conversions saturate; the MFMAs need the default mode: vfa_split.h)
         unsigned nz = 0; // bit rb: this thread saw a non-zero (or NaN) element in row block rb
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
@@ -116,10 +197,17 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
             const float x[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
             union { __bf16 b[4]; uint2 u; } hi, lo;
             bool any = false;
+            if constexpr (F16) {
+                const float sc = row_scale[i]; // 2^(ea - shift) of this row (set by `fetch`)
+                split_f16x4(x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc, hi.u, lo.u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) any |= !(x[j] == 0.0f);
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 split_bf16(x[j], hi.b[j], lo.b[j]);
                 any |= !(x[j] == 0.0f);
+            }
             }
             nz |= any ? 1u << (row >> 5) : 0u;
             const int off = row * kRowBytes + ((((c4 >> 1) ^ (row & 15)) << 4) | ((c4 & 1) << 3));
@@ -130,6 +218,7 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
 #pragma unroll
         for (int rb = 0; rb < kRowBlocks; ++rb)
             if (__ballot((nz >> rb) & 1u) != 0ull && lane == 0) live[slot * kRowBlocks + rb] = 1; // every writer stores 1
+        if constexpr (F16) vfa_dev::fp16_saturate_mode(false);
     };
     // W fragments of half a chunk (4 k-steps x 2 planes = 32 VGPRs); two halves are alive at a time
     struct WHalf { bf16x8 hi[kStepsPerChunk / 2], lo[kStepsPerChunk / 2]; };
@@ -157,10 +246,18 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
                 const unsigned char *pr = pa + rb * 32 * kRowBytes + off;
                 const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(pr);
                 const bf16x8 a_lo = *reinterpret_cast<const bf16x8 *>(pr + kPlane);
+                if constexpr (F16) { // (the order of the frame kernels: hi.lo, hi.hi, lo.hi)
+                    const f16x8 ah = __builtin_bit_cast(f16x8, a_hi), al = __builtin_bit_cast(f16x8, a_lo);
+                    const f16x8 wh = __builtin_bit_cast(f16x8, wq.hi[s]), wl = __builtin_bit_cast(f16x8, wq.lo[s]);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc[rb], 0, 0, 0);
+                } else {
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, wq.lo[s], acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, wq.hi[s], acc[rb], 0, 0, 0);
                 acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, wq.hi[s], acc[rb], 0, 0, 0);
                 if (TERMS >= 4) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, wq.lo[s], acc[rb], 0, 0, 0);
+                }
             }
         }
     };
@@ -181,7 +278,14 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
 #pragma unroll
         for (int rb = 0; rb < kRowBlocks; ++rb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[rb][i] = 0.0f;
+            for (int i = 0; i < 16; ++i) {
+                acc[rb][i] = 0.0f;
+                if constexpr (F16 && MASK) { // the bias rides in the accumulator, in the row's units: exactly how the frame kernels start it
+                    long long m = tile * kTileRows + rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    m = m < M ? m : M - 1;
+                    acc[rb][i] = (bias_c * pow2f(ea + ew)) * pow2f(-shift_of(m));
+                }
+            }
         for (int c = 0; c < n_chunks; ++c) {
             const bool last_chunk = c + 1 == n_chunks;
             const long long nt = last_chunk ? tile + gridDim.x : tile;
@@ -217,11 +321,13 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
                         long long cell = cell0 + row;
                         cell = cell >= ma.cells ? cell - ma.cells : cell;
                         const float g = ma.grad[(size_t)cell * kN + wave * 32 + r];
-                        const float o = (acc[rb][i] + bias_c > 0.0f) ? g : 0.0f;
+                        const float pre_act = F16 ? acc[rb][i] : acc[rb][i] + bias_c; // (fp16 form: the bias is in the accumulator)
+                        const float o = (pre_act > 0.0f) ? g : 0.0f;
                         orow[(size_t)row * kN] = o;
                         gb += o;
                     } else {
-                        orow[(size_t)row * kN] = acc[rb][i];
+                        // (fp16 form: back from the row's units 2^(ea + ew - shift): exact)
+                        orow[(size_t)row * kN] = F16 ? acc[rb][i] * pow2f(shift_of(row0 + row) - (ea + ew)) : acc[rb][i];
                     }
                 }
             }
@@ -240,11 +346,12 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
 extern "C" size_t vfa_collapse_gemm_workspace_bytes(int K, int N)
 {
     if (K <= 0 || N <= 0) return 0;
-    return (size_t)K * (size_t)N * 4;
+    return (size_t)K * (size_t)N * 4 + 256; // (+ the tail of the fp16 form: partial maxima of |W| and its exponent)
 }
 
+// f16: the fp16 form (statistics + shifts given): only through vfa_collapse_gemm_relu_backward_f16_f32
 static int collapse_gemm_launch(const float *vox, const float *weight, float *out, void *workspace, size_t workspace_bytes, size_t M,
-                                int K, int N, int flags, const MaskArgs *mask, void *stream)
+                                int K, int N, int flags, const MaskArgs *mask, void *stream, const F16Args *f16 = nullptr)
 {
     const int terms = flags & VFA_FLAG_TERMS_MASK, reserved_cus = (flags >> 8) & 0xff;
     if (flags & ~(VFA_FLAG_TERMS_MASK | 0xff00)) return VFA_ERR_BAD_ARGUMENT;
@@ -255,8 +362,9 @@ static int collapse_gemm_launch(const float *vox, const float *weight, float *ou
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false; // idempotent: a race only repeats the call
     if (!attr_set) {
-        const void *fns[4] = {(const void *)collapse_gemm_kernel<3, false>, (const void *)collapse_gemm_kernel<4, false>,
-                              (const void *)collapse_gemm_kernel<3, true>, (const void *)collapse_gemm_kernel<4, true>};
+        const void *fns[5] = {(const void *)collapse_gemm_kernel<3, false>, (const void *)collapse_gemm_kernel<4, false>,
+                              (const void *)collapse_gemm_kernel<3, true>, (const void *)collapse_gemm_kernel<4, true>,
+                              (const void *)collapse_gemm_kernel<2, true>};
         for (const void *fn : fns) {
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
             if (e != hipSuccess) return (int)e;
@@ -271,7 +379,16 @@ static int collapse_gemm_launch(const float *vox, const float *weight, float *ou
             n_cu = cus;
     }
     const size_t frags = (size_t)(K / kChunk) * 8 * kStepsPerChunk * 64;
-    hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, s, weight, (uint4 *)workspace, K);
+    F16Args fa = {};
+    if (f16) {
+        unsigned *tail = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(workspace) + (size_t)K * N * 4);
+        hipLaunchKernelGGL(gemm_weight_absmax_kernel, dim3(kWmaxParts), dim3(256), 0, s, weight, tail, (size_t)K * N);
+        hipLaunchKernelGGL(split_weight_f16_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, s, weight, (uint4 *)workspace, K, tail);
+        fa = *f16;
+        fa.wexp = reinterpret_cast<const int *>(tail) + kWmaxParts;
+    } else {
+        hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, s, weight, (uint4 *)workspace, K);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const long long n_tiles = ((long long)M + kTileRows - 1) / kTileRows;
@@ -285,20 +402,24 @@ static int collapse_gemm_launch(const float *vox, const float *weight, float *ou
     if (wgs > n_cu) wgs = n_cu;
     const unsigned blocks = (unsigned)wgs;
     const MaskArgs none = {nullptr, nullptr, nullptr, 1};
-    if (mask) {
+    if (f16) {
+        if (!mask) return VFA_ERR_BAD_ARGUMENT;
+        hipLaunchKernelGGL((collapse_gemm_kernel<2, true>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, out,
+                           (long long)M, K, *mask, fa);
+    } else if (mask) {
         if (terms == 4)
             hipLaunchKernelGGL((collapse_gemm_kernel<4, true>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, out,
-                               (long long)M, K, *mask);
+                               (long long)M, K, *mask, fa);
         else
             hipLaunchKernelGGL((collapse_gemm_kernel<3, true>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, out,
-                               (long long)M, K, *mask);
+                               (long long)M, K, *mask, fa);
     } else {
         if (terms == 4)
             hipLaunchKernelGGL((collapse_gemm_kernel<4, false>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, out,
-                               (long long)M, K, none);
+                               (long long)M, K, none, fa);
         else
             hipLaunchKernelGGL((collapse_gemm_kernel<3, false>), dim3(blocks), dim3(kThreads), kLdsBytes, s, vox, (const uint4 *)workspace, out,
-                               (long long)M, K, none);
+                               (long long)M, K, none, fa);
     }
     return (int)hipGetLastError();
 }
@@ -318,4 +439,24 @@ extern "C" int vfa_collapse_gemm_relu_backward_f32(const float *vox, const float
     if (cells < 32 || cells >= (1ull << 31)) return VFA_ERR_UNSUPPORTED; // (a 32-row block wraps over the cells at most once)
     const MaskArgs ma = {bias, grad_out, grad_bias, (long long)cells};
     return collapse_gemm_launch(vox, weight, grad_lin, workspace, workspace_bytes, (size_t)n_views * cells, K, N, flags, &ma, stream);
+}
+
+// The same with the product of the FUSED FRAME KERNELS (two fp16 pieces per operand under the frame's power-of-two scales, vfa_split.h):
+// feat_absmax / absmax_count = the feature statistics of this scale's integral images (what the forward reduced to 2^ea), shift =
+// vfa_sliver_shifts_u8 of the frame ((shift_views, cells) bytes, shift_views = n_views or 1; NULL: no shifts).  Operands, scales,
+// accumulator start and the order of the MFMA products are the forward's, so the recomputed pre-activation -- and with it the ReLU
+// mask of the backward -- is the forward's bit for bit.
+extern "C" int vfa_collapse_gemm_relu_backward_f16_f32(const float *vox, const float *weight, const float *bias, const float *grad_out,
+                                                       float *grad_lin, float *grad_bias, void *workspace, size_t workspace_bytes,
+                                                       int n_views, size_t cells, int K, int N, const unsigned *feat_absmax,
+                                                       int absmax_count, const unsigned char *shift, int shift_views, int flags, void *stream)
+{
+    if (n_views < 0 || !grad_out || !grad_lin || !feat_absmax || absmax_count <= 0) return VFA_ERR_BAD_ARGUMENT;
+    if (shift && shift_views != 1 && shift_views != n_views) return VFA_ERR_BAD_ARGUMENT;
+    if (flags & VFA_FLAG_TERMS_MASK & ~2) return VFA_ERR_BAD_ARGUMENT; // (terms 0 / 2: this entry point IS the fp16 form)
+    if (n_views == 0 || cells == 0) return 0;
+    if (cells < 32 || cells >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
+    const MaskArgs ma = {bias, grad_out, grad_bias, (long long)cells};
+    const F16Args fa = {feat_absmax, absmax_count, nullptr, shift, (long long)cells, shift_views};
+    return collapse_gemm_launch(vox, weight, grad_lin, workspace, workspace_bytes, (size_t)n_views * cells, K, N, flags & ~VFA_FLAG_TERMS_MASK, &ma, stream, &fa);
 }

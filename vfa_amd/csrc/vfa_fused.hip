@@ -219,6 +219,57 @@ __global__ __launch_bounds__(kWave) void frame_records_kernel(RecordArgs a)
     }
 }
 
+// The sliver shifts of a frame as the BACKWARD of training needs them (vfa_collapse_gemm_relu_backward_f16_f32): per row of the
+// recomputed product the binary places its item was scaled down by in the forward.  Same projection, same area, same sliver_shift as
+// frame_records_kernel / pipe_records_kernel.  per_item: the serial kernel's unit (view, tile, scale) -> out[view][cell]; else the
+// pipelined kernel's (tile, scale) over all views and layers -> tile_max[tile] (atomicMax), expanded by sliver_expand_kernel.
+struct ShiftArgs {
+    BoxGeom g;
+    int n_views, L, W, tiles_w, n_tiles, nl, Hf, Wf, per_item;
+    unsigned char *out;   // per_item: (n_views, L * W)
+    unsigned *tile_max;   // else: (n_tiles), zeroed
+};
+__global__ __launch_bounds__(kWave) void sliver_shift_kernel(ShiftArgs a)
+{
+    const int lane = threadIdx.x, half = lane >> 5, b = lane & 31;
+    const long long pair = (long long)blockIdx.x * 2 + half;
+    const bool pair_ok = pair < (long long)a.n_views * a.n_tiles;
+    const int view = pair_ok ? (int)(pair / a.n_tiles) : 0, tile = pair_ok ? (int)(pair % a.n_tiles) : 0;
+    const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
+    const int cl = tl * kTileL + (b >> 3), cw = tw * kTileW + (b & 7);
+    const bool valid = pair_ok && cl < a.L && cw < a.W;
+    const int cell = valid ? cl * a.W + cw : 0;
+    const float *P = a.g.calibs + (size_t)view * 12;
+    int shift = 0;
+    for (int layer = 0; layer < a.nl; ++layer) {
+        const float gx = a.g.grid[cell * 3 + 0] + 0.0f, gy = a.g.grid[cell * 3 + 1] + 0.0f, gz = a.g.grid[cell * 3 + 2] + a.g.z_layers[layer];
+        float l = 0.0f, t = 0.0f, r = 0.0f, bt = 0.0f;
+#pragma unroll 1
+        for (int k = 0; k < 8; ++k) {
+            float nu, nv;
+            project_corner(a.g, P, gx, gy, gz, k, nu, nv);
+            if (k == 0) { l = r = nu; t = bt = nv; }
+            else { l = min_t(l, nu); r = max_t(r, nu); t = min_t(t, nv); bt = max_t(bt, nv); }
+        }
+        const float area = box_area(l, t, r, bt, a.Hf, a.Wf);
+        if (valid && box_visible(area, a.Hf, a.Wf)) shift = max(shift, sliver_shift(area, a.Hf, a.Wf));
+    }
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) shift = max(shift, __shfl_xor(shift, m, 32));
+    if (a.per_item) {
+        if (valid) a.out[(size_t)view * a.L * a.W + cell] = (unsigned char)shift;
+    } else if (pair_ok && b == 0 && shift > 0) {
+        atomicMax(a.tile_max + tile, (unsigned)shift);
+    }
+}
+__global__ __launch_bounds__(256) void sliver_expand_kernel(const unsigned *tile_max, unsigned char *out, int L, int W, int tiles_w)
+{
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= L * W) return;
+    const int cl = cell / W, cw = cell - cl * W;
+    out[cell] = (unsigned char)tile_max[(cl / kTileL) * tiles_w + cw / kTileW];
+}
+
 // collapse.weight (N = 256, K = 256) fp32 -> bf16 hi / lo planes in MFMA B-fragment order:
 //   out[((wave * 16 + s) * 2 + plane) * 64 + lane] (16 B) = W[n = 32 wave + (lane & 31)][k = 16 s + 8 (lane >> 5) + j], j = 0..7
 // F16 (VFA_FLAG_TERMS 2, the default): the two-piece fp16 split of vfa_split.h, scaled by 2^ew with max|W| 2^ew in [2^14, 2^15)
@@ -1762,6 +1813,36 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
         hipLaunchKernelGGL((pool_collapse_kernel<3, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
     else
         hipLaunchKernelGGL((pool_collapse_kernel<2, false, true>), dim3(nblk), dim3(kThreads), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+size_t vfa_sliver_shifts_scratch_bytes(int L, int W)
+{
+    if (L <= 0 || W <= 0) return 0;
+    return ((size_t)((L + kTileL - 1) / kTileL) * ((W + kTileW - 1) / kTileW) * sizeof(unsigned) + 15) / 16 * 16;
+}
+
+int vfa_sliver_shifts_u8(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off, int n_views,
+                         int L, int W, int conv_kind, float img_w, float img_h, float cmin, float cmax, int Hf, int Wf, int per_item,
+                         unsigned char *shift, void *scratch, size_t scratch_bytes, void *stream)
+{
+    if (n_views < 0 || L < 0 || W < 0 || n_layers < 1 || Hf <= 0 || Wf <= 0 || conv_kind < 0 || conv_kind > 2 || !shift) return VFA_ERR_BAD_ARGUMENT;
+    if (per_item && n_layers != 1) return VFA_ERR_BAD_ARGUMENT; // (the serial kernel's items: single-layer grids)
+    if (n_views == 0 || L == 0 || W == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ShiftArgs a;
+    a.g = BoxGeom{calibs, grid, z_layers, corner_off, conv_kind, img_w, img_h, cmin, cmax};
+    a.n_views = n_views; a.L = L; a.W = W; a.tiles_w = (W + kTileW - 1) / kTileW; a.n_tiles = ((L + kTileL - 1) / kTileL) * a.tiles_w;
+    a.nl = n_layers; a.Hf = Hf; a.Wf = Wf; a.per_item = per_item ? 1 : 0;
+    a.out = shift; a.tile_max = reinterpret_cast<unsigned *>(scratch);
+    if (!per_item) {
+        if (!scratch || scratch_bytes < vfa_sliver_shifts_scratch_bytes(L, W)) return VFA_ERR_BAD_ARGUMENT;
+        const hipError_t e = zero_fill(scratch, vfa_sliver_shifts_scratch_bytes(L, W), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long long pairs = (long long)n_views * a.n_tiles;
+    hipLaunchKernelGGL(sliver_shift_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(kWave), 0, s, a);
+    if (!per_item) hipLaunchKernelGGL(sliver_expand_kernel, dim3((unsigned)((L * W + 255) / 256)), dim3(256), 0, s, a.tile_max, shift, L, W, a.tiles_w);
     return (int)hipGetLastError();
 }
 

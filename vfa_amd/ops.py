@@ -507,10 +507,13 @@ def collapse_gemm(vox2d, weight, out=None, terms=0, reserved_cus=0):
     return out
 
 
-def collapse_gemm_relu_backward(vox, weight, bias, grad_out, terms=0, reserved_cus=0):
+def collapse_gemm_relu_backward(vox, weight, bias, grad_out, terms=0, reserved_cus=0, absmax=None, shift=None):
     """Training backward behind the fused forward: vox (n, cells, K), weight (256, K) (columns in the order of vox), bias (256) or
     None, grad_out (cells, 256) -> (grad_lin (n, cells, 256) = (vox . W^T + b > 0) ? grad_out : 0, grad_bias (256)) with the ReLU mask
-    as the epilogue of the recomputed product (``vfa_collapse_gemm_relu_backward_f32``): the pre-activations never reach memory."""
+    as the epilogue of the recomputed product (``vfa_collapse_gemm_relu_backward_f32``): the pre-activations never reach memory.
+    ``absmax`` (the feature statistics of this scale's integral images, int32) selects the product of the FUSED FRAME KERNELS
+    (``vfa_collapse_gemm_relu_backward_f16_f32``: fp16 pieces under the frame's scales); with ``shift`` = this chunk's rows of
+    ``sliver_shifts`` ((n or 1, cells) uint8) the mask is then the forward's bit for bit."""
     _lib.require_device(vox, weight, bias, grad_out)
     vox, weight, grad_out = _f32c(vox), _f32c(weight), _f32c(grad_out)
     n, cells, K = vox.shape
@@ -524,10 +527,41 @@ def collapse_gemm_relu_backward(vox, weight, bias, grad_out, terms=0, reserved_c
     ws = _gemm_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _gemm_ws[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    if absmax is not None:
+        _lib.require_device(absmax, shift)
+        assert absmax.dtype == torch.int32 and absmax.is_contiguous()
+        sv = 0
+        if shift is not None:
+            assert shift.dtype == torch.uint8 and shift.is_contiguous() and shift.shape[-1] == cells and shift.numel() in (cells, n * cells)
+            sv = shift.numel() // cells
+        _launch("vfa_collapse_gemm_relu_backward_f16_f32", _lib.ptr(vox), _lib.ptr(weight), _lib.ptr(bias) if bias is not None else None,
+                _lib.ptr(grad_out), _lib.ptr(glin), _lib.ptr(gbias), _lib.ptr(ws), ws.numel(), n, cells, K, 256, _lib.ptr(absmax),
+                absmax.numel(), _lib.ptr(shift) if shift is not None else None, sv, _lib.collapse_flags(0, reserved_cus),
+                _lib.current_stream_handle(), tag=(n, cells, K, "f16"))
+        return glin, gbias
     _launch("vfa_collapse_gemm_relu_backward_f32", _lib.ptr(vox), _lib.ptr(weight), _lib.ptr(bias) if bias is not None else None,
             _lib.ptr(grad_out), _lib.ptr(glin), _lib.ptr(gbias), _lib.ptr(ws), ws.numel(), n, cells, K, 256,
             _lib.collapse_flags(terms, reserved_cus), _lib.current_stream_handle(), tag=(n, cells, K))
     return glin, gbias
+
+
+def sliver_shifts(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_hw, per_item, crange=(-1, 0.95)):
+    """The sliver shifts of a frame per output row of the collapse product (``vfa_sliver_shifts_u8``): uint8 (n_views, L*W) for the
+    serial frame kernel's items (``per_item`` True: single-layer grids, one scale) or (1, L*W) for the pipelined kernel's (tile, scale)
+    over all views and layers -- what ``collapse_gemm_relu_backward(..., absmax=..., shift=...)`` needs to repeat the forward's scaling."""
+    _lib.require_device(calibs, grid, z_layers, corner_off)
+    grid = _f32c(grid.reshape(grid.shape[-3], grid.shape[-2], 3))
+    L, W = grid.shape[:2]
+    calibs = _f32c(calibs.reshape(-1, 12))
+    n = calibs.shape[0]
+    z_layers, corner_off = _f32c(z_layers.reshape(-1)), _f32c(corner_off.reshape(8, 3))
+    out = torch.empty((n if per_item else 1, L * W), dtype=torch.uint8, device=calibs.device)
+    need = _lib.lib().vfa_sliver_shifts_scratch_bytes(L, W)
+    scratch = torch.empty(max(need, 16), dtype=torch.uint8, device=calibs.device)
+    _launch("vfa_sliver_shifts_u8", _lib.ptr(calibs), _lib.ptr(grid), _lib.ptr(z_layers), z_layers.numel(), _lib.ptr(corner_off), n, L, W,
+            int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]), int(feat_hw[0]), int(feat_hw[1]),
+            1 if per_item else 0, _lib.ptr(out), _lib.ptr(scratch), scratch.numel(), _lib.current_stream_handle(), tag=(n, L, W))
+    return out
 
 
 def frame_records(calibs, grid, z_layers, corner_off, conv_kind, image_wh, feat_hws, weights=None, crange=(-1, 0.95),

@@ -388,11 +388,13 @@ class _FusedFrameTrain(torch.autograd.Function):
     voxel features are pooled again from the kept integral images (bit-identical to what the forward pooled), ``lin = vox . W^T``
     is formed again with the MFMA tile GEMM (the ReLU mask), then the usual gradients: d lin = d out * (lin + b > 0),
     d W += d lin^T . vox, d b, d vox = d lin . W, scattered back through the box pooling
-    (``vfa_project_gather_backward_f32``) and the two cumsums.  The forward's product is the fp16 x 2 split (~2e-7 of max|lin|),
-    the recomputed one the bf16 x 2 form of the tile GEMM (``vfa_collapse_gemm_relu_backward_f32``, ~4e-6: it has no fp16 form): a
-    pre-activation within ~4e-6 max|lin| of zero may take the other side of the ReLU in the backward.  Measured against the
-    reference's own fp32 ``backward()`` (tests/test_reference_gradients.py): d weight / d bias within 6e-7, d feature within the
-    reference's own fp32-vs-float64 noise -- the window is two orders of magnitude inside what fp32 itself leaves open."""
+    (``vfa_project_gather_backward_f32``) and the two cumsums.  With the default arithmetic the recomputed product IS the forward's:
+    ``vfa_collapse_gemm_relu_backward_f16_f32`` splits both operands into the same fp16 pieces under the same scales (the saved feature
+    statistics give 2^ea, ``vfa_sliver_shifts_u8`` the per-item shifts), starts the accumulator at the same bias 2^(ea+ew-shift) and issues
+    the three MFMA products in the same order: the ReLU mask of the backward equals the forward's bit for bit
+    (tests/test_hip_backward.py).  The bf16 forms (``VFA_AMD_COLLAPSE_TERMS`` 3 / 4 / 6) recompute with the two-piece bf16 tile GEMM.
+    Measured against the reference's own fp32 ``backward()`` (tests/test_reference_gradients.py): d weight / d bias within 6e-7, d feature
+    within the reference's own fp32-vs-float64 noise."""
 
     @staticmethod
     def forward(ctx, calibs, grid, crange, meta, reserved_cus, *tensors):
@@ -402,20 +404,25 @@ class _FusedFrameTrain(torch.autograd.Function):
         n = calibs.shape[0]
         with torch.no_grad():
             integrals = ops.integral_images([l.detach() for l in lats])  # kept: the backward pools from them again
-            frame = pipe_frame if pipe_frame_ok(mods, n) else fused_frame
+            piped = pipe_frame_ok(mods, n)
+            frame = pipe_frame if piped else fused_frame
             out = frame(mods, None, calibs, grid, crange, reserved_cus=reserved_cus, integrals=integrals)
-        ctx.save_for_backward(calibs, grid, *integrals, *weights, *biases)
-        ctx.meta = (mods, tuple(float(c) for c in crange))
+        # (the feature statistics too: with them the backward repeats the forward's fp16 product -- scales, shifts, order -- and its ReLU
+        # mask is the forward's bit for bit)
+        f16 = (COLLAPSE_TERMS if piped else _fused_terms()) in (0, 2)
+        ctx.save_for_backward(calibs, grid, *integrals, *weights, *biases, *(integrals.absmax if f16 else ()))
+        ctx.meta = (mods, tuple(float(c) for c in crange), piped, f16)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        mods, crange = ctx.meta
+        mods, crange, piped, f16 = ctx.meta
         ns = len(mods)
         calibs, grid = ctx.saved_tensors[:2]
         integrals = ctx.saved_tensors[2:2 + ns]
         weights = ctx.saved_tensors[2 + ns:2 + 2 * ns]
         biases = ctx.saved_tensors[2 + 2 * ns:2 + 3 * ns]
+        stats = ctx.saved_tensors[2 + 3 * ns:2 + 4 * ns] if f16 else (None,) * ns
         m0 = mods[0]
         conv_kind = _conv_kind(m0.args)
         img_h, img_w = (float(v) for v in m0.args.image_size)
@@ -428,7 +435,7 @@ class _FusedFrameTrain(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         g_lats, g_ws, g_bs = [], [], []
         with torch.no_grad():
-            for k, (m, integral, w, b) in enumerate(zip(mods, integrals, weights, biases)):
+            for k, (m, integral, w, b, stat) in enumerate(zip(mods, integrals, weights, biases, stats)):
                 need_lat, need_w, need_b = ctx.needs_input_grad[5 + k], ctx.needs_input_grad[5 + ns + k], ctx.needs_input_grad[5 + 2 * ns + k]
                 if not (need_lat or need_w or need_b):
                     g_lats.append(None), g_ws.append(None), g_bs.append(None)
@@ -439,13 +446,22 @@ class _FusedFrameTrain(torch.autograd.Function):
                 g_b = torch.zeros_like(b) if need_b else None
                 per_cell = n * nl * C * 4 * 2  # vox and d vox
                 chunk = max(1, min(n_cells, VOX_BYTES_LIMIT // max(per_cell, 1)))
+                # the sliver shifts the forward's geometry pass gave this scale's items (serial kernel: per (view, tile); pipelined: per
+                # tile over views and layers): the recomputed product scales its rows the same way
+                shifts = None
+                if stat is not None and grid.dim() >= 3:
+                    shifts = ops.sliver_shifts(cal, grid, z_layers, corner_off, conv_kind, (img_w, img_h),
+                                               (integral.shape[1] - 2, integral.shape[2] - 2), not piped, crange)
                 for begin in range(0, n_cells, chunk):
                     count = min(chunk, n_cells - begin)
                     vox = ops.project_gather(integral, cal, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h), crange,
                                              cell_begin=begin, cell_count=count)
                     # (the product again, as the two-piece bf16 MFMA tile GEMM -- the unfused product kernels have the bf16 forms only:
                     # `_unfused_terms` -- with the ReLU mask as its epilogue: d lin and d b come out, the pre-activations are never written)
-                    if count >= 32:
+                    if count >= 32 and shifts is not None:  # the forward's own product: fp16 pieces, its scales, its shifts
+                        g_lin, g_b_part = ops.collapse_gemm_relu_backward(vox, w_lm, b, grad_out[begin:begin + count], absmax=stat,
+                                                                          shift=shifts[:, begin:begin + count].contiguous())
+                    elif count >= 32:
                         g_lin, g_b_part = ops.collapse_gemm_relu_backward(vox, w_lm, b, grad_out[begin:begin + count], terms=_unfused_terms())
                     else:  # (fewer than 32 cells in the chunk: product, then the mask kernel)
                         lin = ops.collapse_gemm(vox.view(n * count, nl * C), w_lm, terms=_unfused_terms()).view(n, count, C)
