@@ -266,13 +266,14 @@ int vfa_collapse_gemm_relu_backward_f32(const float *vox, const float *weight, c
                                         size_t cells, int K, int N, int flags, void *stream);
 /* The same with the product of the FUSED FRAME KERNELS -- two fp16 pieces per operand under the frame's power-of-two scales (ABI v8) --
  * so that the recomputed pre-activation, and with it the ReLU mask of the backward, is the forward's bit for bit: feat_absmax /
- * absmax_count = the feature statistics of this scale (vfa_integral_images_f32: what the frame kernel reduced to its 2^ea), shift =
- * the frame's sliver shifts from vfa_sliver_shifts_u8 ((shift_views, cells) bytes, shift_views = n_views or 1; NULL: none).  Operands,
+ * absmax_count = the feature statistics of this scale (vfa_integral_images_f32: what the frame kernel reduced to its 2^ea), row_shift
+ * = the sliver shift of every row of the product (n_views * cells bytes: vfa_sliver_shifts_u8, its per-cell form repeated per view;
+ * NULL: none), tile_any = one byte per 128 rows, non-zero where a row of that block has a shift (NULL: every row is looked up).  Operands,
  * scales, accumulator start (bias 2^(ea+ew-shift)) and the order of the three MFMA products are the forward's.  flags: reserved CUs. */
 int vfa_collapse_gemm_relu_backward_f16_f32(const float *vox, const float *weight, const float *bias, const float *grad_out,
                                             float *grad_lin, float *grad_bias, void *workspace, size_t workspace_bytes, int n_views,
                                             size_t cells, int K, int N, const unsigned *feat_absmax, int absmax_count,
-                                            const unsigned char *shift, int shift_views, int flags, void *stream);
+                                            const unsigned char *row_shift, const unsigned char *tile_any, int flags, void *stream);
 /* The sliver shifts of a frame, per output row of that product (vfa_geom.h: sliver_shift): the binary places the
  * fp16 operand split of the frame kernels gave up for the noisiest visible box of the row's item.  per_item = 1: the serial kernel's
  * items (view, 8 x 4-cell tile) of ONE scale (feature map Hf x Wf), single-layer grids -> shift (n_views, L * W); per_item = 0: the

@@ -54,7 +54,7 @@ SIGNATURES = {
     "vfa_collapse_gemm_f32": [_vp, _vp, _vp, _vp, _c_size_t, _c_size_t, _c_int, _c_int, _c_int, _vp],
     "vfa_collapse_gemm_relu_backward_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_size_t, _c_int, _c_int, _c_int, _vp],
     "vfa_collapse_gemm_relu_backward_f16_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_size_t, _c_int, _c_size_t, _c_int, _c_int, _vp, _c_int, _vp,
-                                                _c_int, _c_int, _vp],
+                                                _vp, _c_int, _vp],
     "vfa_sliver_shifts_scratch_bytes": [_c_int, _c_int],
     "vfa_sliver_shifts_u8": [_vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _c_int,
                              _c_int, _vp, _vp, _c_size_t, _vp],

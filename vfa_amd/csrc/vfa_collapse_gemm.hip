@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void split_weight_f16_kernel(const float *__re
 // exponent (tail of the workspace) and the sliver shift of every row's item (vfa_sliver_shifts_u8; NULL: none)
 struct F16Args {
     const unsigned *amax; int amax_n;
-    const int *wexp;             // -> ew
-    const unsigned char *shift;  // (shift_views, shift_cells) or NULL
-    long long shift_cells; int shift_views;
+    const int *wexp;                // -> ew
+    const unsigned char *shift;     // (M) per row, or NULL
+    const unsigned char *tile_any;  // (ceil(M / 128)) 1 = a row of the tile has a shift (NULL: look at every row)
 };
 
 // MASK: the epilogue of the training backward (vfa_collapse_gemm_relu_backward_f32).  The product is the recomputed pre-activation;
@@ -164,13 +164,11 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
         ea = split_exponent((unsigned)__builtin_amdgcn_readfirstlane((int)s_amax), kExpA);
         ew = __builtin_amdgcn_readfirstlane(*fa.wexp);
     }
-    // sliver shift of row m (its item's: vfa_geom.h): per (view, cell), or per cell for every view
-    auto shift_of = [&](long long m) -> int {
-        if (!F16 || !fa.shift) return 0;
-        const long long cell = m % fa.shift_cells;
-        return (int)fa.shift[fa.shift_views == 1 ? cell : m];
+    // sliver shift of row m (its item's: vfa_geom.h).  Tiles without a shifted row -- nearly all -- are told by one byte per tile.
+    auto tile_shifted = [&](long long t) -> bool {
+        if (!F16 || !fa.shift) return false;
+        return !fa.tile_any || __builtin_amdgcn_readfirstlane((int)fa.tile_any[t]) != 0;
     };
-
     // this thread's share of a chunk: float4 number tid + 512 i of the 128 x 32 float4 (row = idx / 32).
     // Every load of the main loop is UNCONDITIONAL (addresses are clamped instead): with straight-line loads the in-order
     // vmcnt counter lets the compiler wait for exactly the W fragments it needs and leave the younger HBM loads in
@@ -179,13 +177,14 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
     float row_scale[kLoads]; // fp16 form: 2^(ea - shift) of the row of pre[i]
     auto fetch = [&](long long t, int c) {
         const long long row0 = t * kTileRows;
+        const bool shifted = tile_shifted(t);
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int idx = tid + kThreads * i, row = idx >> 5, c4 = idx & 31;
             long long m = row0 + row;
             m = m < M ? m : M - 1; // rows past the end read a valid row; their outputs are never stored
             pre[i] = *reinterpret_cast<const float4 *>(vox + (size_t)m * K + (size_t)c * kChunk + 4 * c4);
-            if constexpr (F16) row_scale[i] = pow2f(ea - shift_of(m));
+            if constexpr (F16) row_scale[i] = pow2f(ea - (shifted ? (int)fa.shift[m] : 0));
         }
     };
     auto stage = [&](int buf, int slot) {
@@ -275,15 +274,17 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
     float bias_c = 0.0f, gb = 0.0f; // MASK: this lane's column (32 wave + r): its bias, its running column sum of d lin
     if constexpr (MASK) bias_c = ma.bias ? ma.bias[wave * 32 + r] : 0.0f;
     for (; tile < n_tiles; tile += gridDim.x) {
+        const bool shifted_tile = tile_shifted(tile);
 #pragma unroll
         for (int rb = 0; rb < kRowBlocks; ++rb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 acc[rb][i] = 0.0f;
                 if constexpr (F16 && MASK) { // the bias rides in the accumulator, in the row's units: exactly how the frame kernels start it
-                    long long m = tile * kTileRows + rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const int row = rb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    long long m = tile * kTileRows + row;
                     m = m < M ? m : M - 1;
-                    acc[rb][i] = (bias_c * pow2f(ea + ew)) * pow2f(-shift_of(m));
+                    acc[rb][i] = (bias_c * pow2f(ea + ew)) * pow2f(shifted_tile ? -(int)fa.shift[m] : 0);
                 }
             }
         for (int c = 0; c < n_chunks; ++c) {
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
                         gb += o;
                     } else {
                         // (fp16 form: back from the row's units 2^(ea + ew - shift): exact)
-                        orow[(size_t)row * kN] = F16 ? acc[rb][i] * pow2f(shift_of(row0 + row) - (ea + ew)) : acc[rb][i];
+                        orow[(size_t)row * kN] = F16 ? acc[rb][i] * pow2f((shifted_tile ? (int)fa.shift[row0 + row] : 0) - (ea + ew)) : acc[rb][i];
                     }
                 }
             }
@@ -442,21 +443,22 @@ extern "C" int vfa_collapse_gemm_relu_backward_f32(const float *vox, const float
 }
 
 // The same with the product of the FUSED FRAME KERNELS (two fp16 pieces per operand under the frame's power-of-two scales, vfa_split.h):
-// feat_absmax / absmax_count = the feature statistics of this scale's integral images (what the forward reduced to 2^ea), shift =
-// vfa_sliver_shifts_u8 of the frame ((shift_views, cells) bytes, shift_views = n_views or 1; NULL: no shifts).  Operands, scales,
+// feat_absmax / absmax_count = the feature statistics of this scale's integral images (what the forward reduced to 2^ea), row_shift =
+// the sliver shift of every row (n_views * cells bytes, from vfa_sliver_shifts_u8; NULL: none), tile_any = one byte per 128 rows: a
+// row of that tile has a shift (NULL: every row is looked up).  Operands, scales,
 // accumulator start and the order of the MFMA products are the forward's, so the recomputed pre-activation -- and with it the ReLU
 // mask of the backward -- is the forward's bit for bit.
 extern "C" int vfa_collapse_gemm_relu_backward_f16_f32(const float *vox, const float *weight, const float *bias, const float *grad_out,
                                                        float *grad_lin, float *grad_bias, void *workspace, size_t workspace_bytes,
                                                        int n_views, size_t cells, int K, int N, const unsigned *feat_absmax,
-                                                       int absmax_count, const unsigned char *shift, int shift_views, int flags, void *stream)
+                                                       int absmax_count, const unsigned char *row_shift, const unsigned char *tile_any,
+                                                       int flags, void *stream)
 {
-    if (n_views < 0 || !grad_out || !grad_lin || !feat_absmax || absmax_count <= 0) return VFA_ERR_BAD_ARGUMENT;
-    if (shift && shift_views != 1 && shift_views != n_views) return VFA_ERR_BAD_ARGUMENT;
+    if (n_views < 0 || !grad_out || !grad_lin || !feat_absmax || absmax_count <= 0 || (tile_any && !row_shift)) return VFA_ERR_BAD_ARGUMENT;
     if (flags & VFA_FLAG_TERMS_MASK & ~2) return VFA_ERR_BAD_ARGUMENT; // (terms 0 / 2: this entry point IS the fp16 form)
     if (n_views == 0 || cells == 0) return 0;
     if (cells < 32 || cells >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
     const MaskArgs ma = {bias, grad_out, grad_bias, (long long)cells};
-    const F16Args fa = {feat_absmax, absmax_count, nullptr, shift, (long long)cells, shift_views};
+    const F16Args fa = {feat_absmax, absmax_count, nullptr, row_shift, tile_any};
     return collapse_gemm_launch(vox, weight, grad_lin, workspace, workspace_bytes, (size_t)n_views * cells, K, N, flags & ~VFA_FLAG_TERMS_MASK, &ma, stream, &fa);
 }

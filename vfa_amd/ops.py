@@ -530,14 +530,16 @@ def collapse_gemm_relu_backward(vox, weight, bias, grad_out, terms=0, reserved_c
     if absmax is not None:
         _lib.require_device(absmax, shift)
         assert absmax.dtype == torch.int32 and absmax.is_contiguous()
-        sv = 0
+        rows = tiles = None
         if shift is not None:
-            assert shift.dtype == torch.uint8 and shift.is_contiguous() and shift.shape[-1] == cells and shift.numel() in (cells, n * cells)
-            sv = shift.numel() // cells
+            assert shift.dtype == torch.uint8 and shift.shape[-1] == cells and shift.numel() in (cells, n * cells)
+            rows = shift.reshape(-1, cells).expand(n, cells).contiguous().view(-1)  # one byte per row of the product (view, cell)
+            pad = (-rows.numel()) % 128
+            tiles = (torch.nn.functional.pad(rows, (0, pad)) if pad else rows).view(-1, 128).amax(dim=1).contiguous()
         _launch("vfa_collapse_gemm_relu_backward_f16_f32", _lib.ptr(vox), _lib.ptr(weight), _lib.ptr(bias) if bias is not None else None,
                 _lib.ptr(grad_out), _lib.ptr(glin), _lib.ptr(gbias), _lib.ptr(ws), ws.numel(), n, cells, K, 256, _lib.ptr(absmax),
-                absmax.numel(), _lib.ptr(shift) if shift is not None else None, sv, _lib.collapse_flags(0, reserved_cus),
-                _lib.current_stream_handle(), tag=(n, cells, K, "f16"))
+                absmax.numel(), _lib.ptr(rows) if rows is not None else None, _lib.ptr(tiles) if tiles is not None else None,
+                _lib.collapse_flags(0, reserved_cus), _lib.current_stream_handle(), tag=(n, cells, K, "f16"))
         return glin, gbias
     _launch("vfa_collapse_gemm_relu_backward_f32", _lib.ptr(vox), _lib.ptr(weight), _lib.ptr(bias) if bias is not None else None,
             _lib.ptr(grad_out), _lib.ptr(glin), _lib.ptr(gbias), _lib.ptr(ws), ws.numel(), n, cells, K, 256,
