@@ -718,6 +718,28 @@ def main():
                 ms_d = 1e3 * (time.perf_counter() - t0) / reps
             static[str(nranks)] = {"cameras": len(cams), "ms_per_frame": ms_s, "ms_per_frame_geometry_every_frame": ms_d,
                                    "bit_identical": same}
+            # ... and the same frame captured into a hipGraph (static shapes, static buffers: what a deployed rank replays per frame)
+            try:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side), torch.no_grad():
+                    for _ in range(2):
+                        geom.frame(feats)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph), torch.no_grad():
+                    g_out = geom.frame(feats)
+                graph.replay()
+                leg.fence()
+                same_g = bool(torch.equal(g_out, want_s))
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    graph.replay()
+                leg.fence()
+                static[str(nranks)].update(ms_per_frame_graphed=1e3 * (time.perf_counter() - t0) / reps, graphed_bit_identical=same_g)
+                del graph, g_out
+            except Exception as exc:  # (a capture failure must not take the bench line down)
+                static[str(nranks)]["graph_error"] = repr(exc)[:200]
             del geom
         if static:
             extra["static_rig"] = dict(static, note="vfa_amd.FrameGeometry: the rig's geometry computed ONCE (the caller's contract: cameras, grid and "
