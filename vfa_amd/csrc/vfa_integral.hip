@@ -240,8 +240,12 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// (launch bounds: FOUR waves per SIMD = two of these 512-thread workgroups per CU.  The LDS footprint was sized for two (79.9 KB on the
+// bench frame), but at 136 registers only one fitted: round 5's second session capped the kernel at 128 -- 3 spilled registers -- and
+// the three maps of the bench frame take 87 instead of 97 us: a unit is a chain of dependent fp64 scans, the second workgroup fills its
+// stalls.)
 template <bool AFFINE>
-__global__ __launch_bounds__(kOpThreads) void integral_onepass_kernel(OnePassArgs a)
+__global__ __launch_bounds__(kOpThreads, 4) void integral_onepass_kernel(OnePassArgs a)
 {
     extern __shared__ __align__(16) unsigned char op_lds[];
     float *tile = reinterpret_cast<float *>(op_lds);                                  // [32 rows][kOpRowPitch]
