@@ -273,41 +273,40 @@ __global__ __launch_bounds__(256) void sliver_expand_kernel(const unsigned *tile
 // collapse.weight (N = 256, K = 256) fp32 -> bf16 hi / lo planes in MFMA B-fragment order:
 //   out[((wave * 16 + s) * 2 + plane) * 64 + lane] (16 B) = W[n = 32 wave + (lane & 31)][k = 16 s + 8 (lane >> 5) + j], j = 0..7
 // F16 (VFA_FLAG_TERMS 2, the default): the two-piece fp16 split of vfa_split.h, scaled by 2^ew with max|W| 2^ew in [2^14, 2^15)
-// -- the maximum comes from weight_absmax_kernel (kWmaxParts partial maxima per scale), the exponent is left in wexp[scale] for
-// the frame kernel.
-constexpr int kWmaxParts = 32;
+// -- every splitting block finds the maximum for itself --, the exponent is left in wexp[scale] for the frame kernel.
+constexpr int kWmaxParts = 32; // (a reserved region of the workspace: the partial maxima of rounds 3-4)
 struct SplitArgs { const float *w[kMaxScales]; uint4 *out[kMaxScales]; unsigned *wmax; int *wexp; int f16; };
-__global__ __launch_bounds__(256) void weight_absmax_kernel(SplitArgs sa, int count)
+// The split runs in the spare blocks of the work-cuts launch (round 5): tile_chunks_kernel is ONE workgroup walking dependent memory
+// round trips for ~30 us; as two launches of their own behind it (rounds 3-4: partial maxima, then the split: 20 us of launches for
+// 0.8 MB of weights) the weights were the tail of the geometry stream, and with the integral images at 87 us the geometry had become
+// the longer of the two chains in front of the frame kernel.
+// Block b = 1 + scale * kSplitBlocks + j (1024 threads): the maximum of |W[scale]| over all 65 536 weights (every block for itself:
+// 64 loads per thread out of L2), then fragments [1024 j, 1024 j + 1024) of the scale.
+constexpr int kSplitBlocks = 8 * kSteps * 64 / 1024;
+__device__ __forceinline__ void split_block(const SplitArgs &sa, int b, unsigned long long *part)
 {
-    __shared__ unsigned part[4];
-    const float *__restrict__ w = sa.w[blockIdx.y];
-    unsigned m = 0u;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += kWmaxParts * 256) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
-    m = wave_max_u32(m);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) sa.wmax[blockIdx.y * kWmaxParts + blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
-}
-__device__ __forceinline__ int weight_exponent(const unsigned *wmax, int scale)
-{
-    unsigned m = 0u;
-    for (int i = 0; i < kWmaxParts; ++i) m = max(m, wmax[scale * kWmaxParts + i]);
-    return split_exponent(m, kExpW);
-}
-__global__ __launch_bounds__(256) void split_weight_frag_kernel(SplitArgs sa)
-{
-    const float *__restrict__ w = sa.w[blockIdx.y];
-    uint4 *__restrict__ out = sa.out[blockIdx.y];
-    const int idx = blockIdx.x * 256 + threadIdx.x; // (wave, s, lane)
-    if (idx >= 8 * kSteps * 64) return;
-    const int lane = idx & 63, s = (idx >> 6) & 15, wave = idx >> 10;
-    const float *src = w + (size_t)(wave * 32 + (lane & 31)) * kC + 16 * s + 8 * (lane >> 5);
-    if (idx == 0 && blockIdx.y == 0) sa.wexp[kMaxScales] = sa.f16 ? 2 : 3; // the arithmetic these fragments are for: checked by the frame kernel
+    const int scale = b / kSplitBlocks, j = b - scale * kSplitBlocks, tid = threadIdx.x;
+    const float *__restrict__ w = sa.w[scale];
+    uint4 *__restrict__ out = sa.out[scale];
+    int ew = 0;
+    if (sa.f16) {
+        unsigned m = 0u;
+        for (int i = tid; i < kC * kC; i += 1024) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+        m = wave_max_u32(m);
+        if ((tid & 63) == 0) part[tid >> 6] = m;
+        __syncthreads();
+        unsigned mm = 0u;
+        for (int i = 0; i < 16; ++i) mm = max(mm, (unsigned)part[i]);
+        ew = split_exponent(mm, kExpW);
+    }
+    const int idx = j * 1024 + tid; // (wave, s, lane)
+    const int lane = idx & 63, st = (idx >> 6) & 15, wave = idx >> 10;
+    const float *src = w + (size_t)(wave * 32 + (lane & 31)) * kC + 16 * st + 8 * (lane >> 5);
+    if (idx == 0 && scale == 0) sa.wexp[kMaxScales] = sa.f16 ? 2 : 3; // the arithmetic these fragments are for: checked by the frame kernel
     uint4 uh, ul;
     if (sa.f16) {
         fp16_saturate_mode(true);
-        const int ew = weight_exponent(sa.wmax, blockIdx.y);
-        if (idx == 0) sa.wexp[blockIdx.y] = ew;
+        if (idx == 0) sa.wexp[scale] = ew;
         const float sc = pow2f(ew);
         uint2 h0, l0, h1, l1;
         split_f16x4(src[0] * sc, src[1] * sc, src[2] * sc, src[3] * sc, h0, l0);
@@ -317,15 +316,15 @@ __global__ __launch_bounds__(256) void split_weight_frag_kernel(SplitArgs sa)
     } else {
         union { __bf16 b[8]; uint4 u; } hi, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = src[j];
-            hi.b[j] = (__bf16)x;
-            lo.b[j] = (__bf16)(x - (float)hi.b[j]);
+        for (int k = 0; k < 8; ++k) {
+            const float x = src[k];
+            hi.b[k] = (__bf16)x;
+            lo.b[k] = (__bf16)(x - (float)hi.b[k]);
         }
         uh = hi.u; ul = lo.u;
     }
-    out[((size_t)(wave * kSteps + s) * 2 + 0) * 64 + lane] = uh;
-    out[((size_t)(wave * kSteps + s) * 2 + 1) * 64 + lane] = ul;
+    out[((size_t)(wave * kSteps + st) * 2 + 0) * 64 + lane] = uh;
+    out[((size_t)(wave * kSteps + st) * 2 + 1) * 64 + lane] = ul;
 }
 
 // Work balance of the persistent kernel: the item sequence (tile, scale, view) is cut into kChunks pieces of equal estimated COST;
@@ -344,6 +343,8 @@ struct ChunkArgs {
     const unsigned short *item_w; // (n_tiles, kMaxScales, views_pad): written by frame_records_kernel
     int n_scales, n_tiles, n_views, views_pad;
     int *chunk_start, *chunk_rank;
+    SplitArgs split; // n_split_blocks > 0: the blocks behind block 0 split the collapse weights (nothing of the frame in them)
+    int n_split_blocks;
 };
 template <int G> struct TileItemsT { unsigned m[kMaxScales]; uint4 q[kMaxScales][G]; }; // item masks and their cost estimates (8 views per uint4)
 // G = 1: up to 8 views, the first two tiles of a thread cached in registers; G = 4: up to 32 views, tiles re-read for the second walk
@@ -353,6 +354,10 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(ChunkArgs a)
     using TileItems = TileItemsT<G>;
     constexpr bool kCache = G == 1;
     __shared__ unsigned long long part[1024];
+    if (blockIdx.x > 0) { // (the weight split rides in this launch: split_block)
+        split_block(a.split, (int)blockIdx.x - 1, part);
+        return;
+    }
     const int tid = threadIdx.x, n_tiles = a.n_tiles;
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
     const int per = (n_tiles + 1023) / 1024, t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
@@ -1623,12 +1628,10 @@ int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *con
     ca.item_w = reinterpret_cast<const unsigned short *>(ws + lay.item_w);
     ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
     ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);
-    if (n_views <= 8) hipLaunchKernelGGL(tile_chunks_kernel<1>, dim3(1), dim3(1024), 0, s, ca);
-    else hipLaunchKernelGGL(tile_chunks_kernel<4>, dim3(1), dim3(1024), 0, s, ca);
-    int st = (int)hipGetLastError();
-    if (st) return st;
-    if (weights) {
-        SplitArgs sa;
+    ca.split = SplitArgs{};
+    ca.n_split_blocks = 0;
+    if (weights) { // the split of the collapse weights: the spare blocks of the same launch
+        SplitArgs &sa = ca.split;
         for (int k = 0; k < kMaxScales; ++k) {
             sa.w[k] = weights[k < n_scales ? k : 0];
             sa.out[k] = reinterpret_cast<uint4 *>(ws + lay.wfrag[k < n_scales ? k : 0]);
@@ -1637,15 +1640,11 @@ int vfa_frame_cuts_f32(int n_views, int L, int W, int n_scales, const float *con
         sa.wmax = reinterpret_cast<unsigned *>(ws + lay.wmax);
         sa.wexp = reinterpret_cast<int *>(ws + lay.wexp);
         sa.f16 = (terms == 0 || terms == 2) ? 1 : 0;
-        if (sa.f16) {
-            hipLaunchKernelGGL(weight_absmax_kernel, dim3(kWmaxParts, n_scales), dim3(256), 0, s, sa, kC * kC);
-            st = (int)hipGetLastError();
-            if (st) return st;
-        }
-        hipLaunchKernelGGL(split_weight_frag_kernel, dim3(8 * kSteps * 64 / 256, n_scales), dim3(256), 0, s, sa);
-        st = (int)hipGetLastError();
+        ca.n_split_blocks = n_scales * kSplitBlocks;
     }
-    return st;
+    if (n_views <= 8) hipLaunchKernelGGL(tile_chunks_kernel<1>, dim3(1 + ca.n_split_blocks), dim3(1024), 0, s, ca);
+    else hipLaunchKernelGGL(tile_chunks_kernel<4>, dim3(1 + ca.n_split_blocks), dim3(1024), 0, s, ca);
+    return (int)hipGetLastError();
 }
 
 // a single entry point = few launches: boxes (memset + records kernel), then the work cuts and one weight-split launch
