@@ -70,15 +70,22 @@ __device__ __forceinline__ void fp16_saturate_mode(bool on)
     asm volatile("" ::: "memory");
 }
 
-// four fp32 values (already scaled) -> hi / lo fp16 quads: 2 x v_cvt_pk_f16_f32, 4 x v_cvt_f32_f16, 4 x v_sub_f32, 2 x v_cvt_pk_f16_f32
+// four fp32 values (already scaled) -> hi / lo fp16 quads: 2 x v_cvt_pk_f16_f32 for the hi pieces, then ONE v_fma_mix{lo,hi}_f16 per lo
+// piece -- fma(float(hi), -1, x) rounded to fp16 in the instruction: x - float(hi) is exact in fp32 (hi is x rounded to 11 bits), so the
+// one rounding is the rounding of the three-instruction form (v_cvt_f32_f16, v_sub_f32, v_cvt_pk_f16_f32: 12 instructions per quad, 6
+// now).  Bit-identical on 1.7e7 values of every kind -- NaN, infinities, denormals, the fp16 limit -- with MODE.FP16_OVFL on and off
+// (round 5, tools/micro/mix_split.hip).
 __device__ __forceinline__ void split_f16x4(float x0, float x1, float x2, float x3, uint2 &hi, uint2 &lo)
 {
     const f32x4v x = {x0, x1, x2, x3};
     const f16x4 h = __builtin_convertvector(x, f16x4);
-    const f32x4v r = x - __builtin_convertvector(h, f32x4v);
-    const f16x4 l = __builtin_convertvector(r, f16x4);
     hi = __builtin_bit_cast(uint2, h);
-    lo = __builtin_bit_cast(uint2, l);
+    unsigned l0, l1;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi.x), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(hi.x), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi.y), "v"(x2));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(hi.y), "v"(x3));
+    lo = make_uint2(l0, l1);
 }
 
 // wave-wide maximum of an unsigned value (all lanes get it)
