@@ -5,6 +5,9 @@
 //   MODE 1  anti-phase halves: the item in two 128-channel halves; waves 0-3 (X) and 4-7 (Y) alternate roles every half-step --
 //           X pools its boxes of half j while Y multiplies half j - 1, then Y pools half j while X multiplies half j - 1.  Same
 //           instruction counts, four barriers per item instead of two, tap windows as 512-byte half slots in two buffers.
+//   MODE 2  serial, but the lo fragments of k-steps 8-15 are NOT resident (requested behind the pooling pass, 8 KiB per wave and item
+//           out of L2, used from k-step 8 on): 32 registers for all sixteen taps of a quarter pass in flight -- one LDS round trip per
+//           quarter instead of two.
 //   hipcc --offload-arch=gfx950 -O3 -o stagger tools/micro/stagger.hip && ./stagger
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -52,13 +55,13 @@ __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ wsrc, const u
                                          unsigned long long *cyc)
 {
     // MODE 0: one window of 1 KiB slots; MODE 1: two buffers of 512-byte half slots
-    __shared__ __align__(16) unsigned char s_win[MODE == 0 ? kSlots * 1024 : 2 * kSlots * 256];
+    __shared__ __align__(16) unsigned char s_win[MODE != 1 ? kSlots * 1024 : 2 * kSlots * 256];
     __shared__ __align__(16) unsigned char s_planes[2 * kPlane];
     __shared__ __align__(16) unsigned char s_rec[2][32 * kRecBytes];
     __shared__ float s_sum[MODE == 1 ? 8 * 16 * 64 : 64];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int grp = lane >> 4, cq = lane & 15;
-    for (int i = tid; i < (MODE == 0 ? kSlots * 256 : 2 * kSlots * 64); i += 512) reinterpret_cast<float *>(s_win)[i] = (float)((i * 2654435761u) >> 20) * 1e-3f;
+    for (int i = tid; i < (MODE != 1 ? kSlots * 256 : 2 * kSlots * 64); i += 512) reinterpret_cast<float *>(s_win)[i] = (float)((i * 2654435761u) >> 20) * 1e-3f;
     for (int i = tid; i < (MODE == 1 ? 8 * 16 * 64 : 64); i += 512) s_sum[i] = 0.0f;
     for (int i = tid; i < 2 * kPlane / 4; i += 512) reinterpret_cast<unsigned *>(s_planes)[i] = 0x3c003c00u;
     for (int i = tid; i < 2 * 32 * kRecBytes / 16; i += 512) reinterpret_cast<uint4 *>(s_rec)[i] = recs[(size_t)blockIdx.x * 2 * 32 * 6 + i];
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ wsrc, const u
     const unsigned win = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)s_win;
     const unsigned pla = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)s_planes;
     const int row = 4 * wave + grp;
-    constexpr unsigned kUnit = MODE == 0 ? 1024u : 256u; // bytes per window slot
+    constexpr unsigned kUnit = MODE != 1 ? 1024u : 256u; // bytes per window slot
 
     BoxState bs;
     auto unpack = [&](int buf) {
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ wsrc, const u
 #pragma unroll
             for (int j = 0; j < 4; ++j) bs.tb[i * 4 + j] = rw[i] + cl[j];
         bs.rs = (vis ? rcp : masked) * 0x1p3f; bs.as = area * 0x1p-3f;
-        if constexpr (MODE == 0) bs.plane0 = pla + (unsigned)(row * kRowBytes + (((((cq >> 1) ^ (row & 15)) << 4)) | ((cq & 1) << 3)));
+        if constexpr (MODE != 1) bs.plane0 = pla + (unsigned)(row * kRowBytes + (((((cq >> 1) ^ (row & 15)) << 4)) | ((cq & 1) << 3)));
         else bs.plane0 = pla + (unsigned)((cq >> 1) * kQStride + row * 16 + (cq & 1) * 8); // chunk-major quarter buffer: [chunk of 8 k][row][16 B], padded
     };
     // one 64-channel quarter pass of this lane's box: tap reads at byte offset OFF from the box's tap addresses, planes chunk flip PX
@@ -108,24 +111,40 @@ __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ wsrc, const u
     auto pass = [&](auto off_tag, auto px_tag) {
         constexpr int OFF = decltype(off_tag)::value, PX = decltype(px_tag)::value;
         f32x4 a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3, d0, d1, d2, d3;
+        f32x4 lt, rb, rt, lb;
+        if constexpr (MODE == 2) {
+            lds_read4<OFF>(a0, a1, a2, a3, bs.tb[0], bs.tb[1], bs.tb[4], bs.tb[5]);
+            lds_read4<OFF>(b0, b1, b2, b3, bs.tb[10], bs.tb[11], bs.tb[14], bs.tb[15]);
+            lds_read4<OFF>(c0, c1, c2, c3, bs.tb[2], bs.tb[3], bs.tb[6], bs.tb[7]);
+            lds_read4<OFF>(d0, d1, d2, d3, bs.tb[8], bs.tb[9], bs.tb[12], bs.tb[13]);
+            lds_wait4<12>(a0, a1, a2, a3);
+            lt = sample4(a0, a1, a2, a3, wt[0], wt[1], wt[2], wt[3]);
+            lds_wait4<8>(b0, b1, b2, b3);
+            rb = sample4(b0, b1, b2, b3, wt[4], wt[5], wt[6], wt[7]);
+            lds_wait4<4>(c0, c1, c2, c3);
+            rt = sample4(c0, c1, c2, c3, wt[8], wt[9], wt[10], wt[11]);
+            lds_wait4<0>(d0, d1, d2, d3);
+            lb = sample4(d0, d1, d2, d3, wt[12], wt[13], wt[14], wt[15]);
+        } else {
         lds_read4<OFF>(a0, a1, a2, a3, bs.tb[0], bs.tb[1], bs.tb[4], bs.tb[5]);
         lds_read4<OFF>(b0, b1, b2, b3, bs.tb[10], bs.tb[11], bs.tb[14], bs.tb[15]);
         lds_wait4<4>(a0, a1, a2, a3);
-        const f32x4 lt = sample4(a0, a1, a2, a3, wt[0], wt[1], wt[2], wt[3]);
+        lt = sample4(a0, a1, a2, a3, wt[0], wt[1], wt[2], wt[3]);
         lds_read4<OFF>(c0, c1, c2, c3, bs.tb[2], bs.tb[3], bs.tb[6], bs.tb[7]);
         lds_wait4<4>(b0, b1, b2, b3);
-        const f32x4 rb = sample4(b0, b1, b2, b3, wt[4], wt[5], wt[6], wt[7]);
+        rb = sample4(b0, b1, b2, b3, wt[4], wt[5], wt[6], wt[7]);
         lds_read4<OFF>(d0, d1, d2, d3, bs.tb[8], bs.tb[9], bs.tb[12], bs.tb[13]);
         lds_wait4<4>(c0, c1, c2, c3);
-        const f32x4 rt = sample4(c0, c1, c2, c3, wt[8], wt[9], wt[10], wt[11]);
+        rt = sample4(c0, c1, c2, c3, wt[8], wt[9], wt[10], wt[11]);
         lds_wait4<0>(d0, d1, d2, d3);
-        const f32x4 lb = sample4(d0, d1, d2, d3, wt[12], wt[13], wt[14], wt[15]);
+        lb = sample4(d0, d1, d2, d3, wt[12], wt[13], wt[14], wt[15]);
+        }
         f32x4 v = ((lt + rb) - rt) - lb;
         v = f32x4{quot(v[0], bs.as, bs.rs), quot(v[1], bs.as, bs.rs), quot(v[2], bs.as, bs.rs), quot(v[3], bs.as, bs.rs)};
         const f16x4 hi = __builtin_convertvector(v, f16x4);
         const f32x4 back = __builtin_convertvector(hi, f32x4);
         const f16x4 lo = __builtin_convertvector(v - back, f16x4);
-        if constexpr (MODE == 0) {
+        if constexpr (MODE != 1) {
             const unsigned at = bs.plane0 ^ (unsigned)(PX << 7);
             asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:%3" :: "v"(at), "v"(hi), "v"(lo), "n"(kPlane) : "memory");
         } else {
@@ -150,12 +169,12 @@ __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ wsrc, const u
     unsigned qa = pla + (unsigned)(h * kQStride + r * 16);
     // MODE 0: the MFMAs of k-steps [K0, K0 + 16); MODE 1: k-steps [K0, K0 + 4) out of quarter buffer B.  `nf` window pieces issued in between.
     auto multiply = [&](auto k0_tag, auto b_tag, int item, int nf, unsigned dst) {
-        constexpr int K0 = decltype(k0_tag)::value, B = decltype(b_tag)::value, NK = MODE == 0 ? 16 : 4;
+        constexpr int K0 = decltype(k0_tag)::value, B = decltype(b_tag)::value, NK = MODE != 1 ? 16 : 4;
         f16x8 fh[3], fl[3];
         unsigned qb = qa;
         auto rd = [&](auto kk_tag, f16x8 &hh, f16x8 &ll, unsigned qaddr) {
             constexpr int KK = decltype(kk_tag)::value;
-            if constexpr (MODE == 0) frags(K0 + KK, hh, ll);
+            if constexpr (MODE != 1) frags(K0 + KK, hh, ll);
             else asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(hh), "=&v"(ll)
                               : "v"(qaddr), "n"(B * kQBuf + 2 * KK * kQStride), "n"(B * kQBuf + 2 * KK * kQStride + kQPlane) : "memory");
         };
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ wsrc, const u
             __builtin_amdgcn_sched_barrier(0);
         };
         step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
-        if constexpr (MODE == 0) {
+        if constexpr (MODE != 1) {
             step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
             step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
             step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
@@ -193,7 +212,27 @@ __global__ __launch_bounds__(512) void k(const uint4 *__restrict__ wsrc, const u
     using I8 = std::integral_constant<int, 8>;
     using I16 = std::integral_constant<int, 16>;
 
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 2) {
+        const uint4 *wlo = wsrc + (size_t)(wave * 16 + 8) * 2 * 64 + 64 + lane; // lo fragment of k-step 8 of this wave
+        for (int item = 0; item < items; ++item) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unpack(item & 1);
+            weights(item & 1);
+            pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            pass(std::integral_constant<int, 256>{}, std::integral_constant<int, 1>{});
+            pass(std::integral_constant<int, 512>{}, std::integral_constant<int, 2>{});
+            pass(std::integral_constant<int, 768>{}, std::integral_constant<int, 3>{});
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ks = 8; ks < 16; ++ks) wl[ks] = __builtin_bit_cast(f16x8, wlo[(size_t)((ks - 8) * 2 + (item & 1) * 0) * 64]); // (lands under k-steps 0-7)
+            __syncthreads();
+            multiply(I0{}, I0{}, item, wave < 4 ? 9 : 0, 0u);
+            epilogue();
+#pragma unroll
+            for (int ks = 8; ks < 16; ++ks) asm volatile("" : "=v"(wl[ks])); // (dead until the next item requests them again)
+        }
+    } else if constexpr (MODE == 0) {
         for (int item = 0; item < items; ++item) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -310,7 +349,8 @@ int main()
     hipMemcpy(recs, hr, nrec * kRecBytes, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("serial (pool | multiply)", w, recs, image, out, cyc);
-        run<1>("anti-phase halves", w, recs, image, out, cyc);
+        run<1>("anti-phase quarters", w, recs, image, out, cyc);
+        run<2>("serial, 16 taps in flight", w, recs, image, out, cyc);
     }
     return 0;
 }
