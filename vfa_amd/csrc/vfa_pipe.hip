@@ -108,9 +108,16 @@ struct RecordArgs {
 
 __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
 {
+    // a half-wave per (view, tile, LAYER) (round 5, second session: one per (view, tile) walked its layers one after the other -- 15
+    // dependent (layer, scale) rounds of shuffles, LDS staging and stores on the 5-layer MultiviewC frame, 113 us beside the integral
+    // images with 2.7 waves per SIMD: the geometry stream, not the integral images, decided when the frame kernel could start.  Now
+    // 84 us; a half-wave per (view, tile, layer, SCALE) was slower again (107: 41 000 one-wave workgroups), and so was writing the
+    // records without the LDS staging (85, and the integral images beside it 93 instead of 84))
     __shared__ uint4 stage[2][kTileBoxes * 3];
     const int lane = threadIdx.x, half = lane >> 5, b = lane & 31;
-    const long long pair = (long long)blockIdx.x * 2 + half;
+    const long long unit = (long long)blockIdx.x * 2 + half;
+    const long long pair = unit / a.nl;
+    const int layer0 = (int)(unit - pair * a.nl);
     const bool pair_ok = pair < (long long)a.n_views * a.n_tiles;
     const int view = pair_ok ? (int)(pair / a.n_tiles) : 0, tile = pair_ok ? (int)(pair % a.n_tiles) : 0;
     const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
@@ -122,8 +129,8 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
     bool live_any[kMaxScales] = {false, false, false};
     int shift_max[kMaxScales] = {0, 0, 0};
     unsigned n_glob = 0;
-#pragma unroll 1
-    for (int layer = 0; layer < a.nl; ++layer) {
+    {
+        const int layer = layer0;
         // the cube once per (view, cell, layer): scale-independent                     vfa_op.py:64-88, utils.py:56-59
         float l, t, r, bt;
         {
@@ -232,20 +239,9 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
 // planes x = p0 + p1 + p2 (+ r, |r| <= 2^-25 |x|; p0 + p1 is the two-piece split) in MFMA B-fragment order, 384 KiB per layer:
 //   out[(((layer * 8 + wave) * 16 + s) * 3 + plane) * 64 + lane] (16 B) = W[n = 32 wave + (lane & 31)][c = 16 s + 8 (lane >> 5) + j], j = 0..7
 // F16 (VFA_FLAG_TERMS 2, the default): the two-piece fp16 split of vfa_split.h in planes 0 and 1, scaled by 2^ew with
-// max|W| 2^ew in [2^14, 2^15) (pipe_weight_absmax_kernel: kWmaxParts partial maxima per scale); ew is left in wexp[scale].
+// max|W| 2^ew in [2^14, 2^15) (kWmaxParts partial maxima per scale, left by the spare blocks of pipe_cuts_kernel); ew is left in wexp[scale].
 constexpr int kWmaxParts = 32;
 struct SplitArgs { const float *w[kMaxScales]; uint4 *out[kMaxScales]; int nl; unsigned *wmax; int *wexp; int f16; };
-__global__ __launch_bounds__(256) void pipe_weight_absmax_kernel(SplitArgs sa, long long count)
-{
-    __shared__ unsigned part[4];
-    const float *__restrict__ w = sa.w[blockIdx.y];
-    unsigned m = 0u;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += kWmaxParts * 256) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
-    m = wave_max_u32(m);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) sa.wmax[blockIdx.y * kWmaxParts + blockIdx.x] = max(max(part[0], part[1]), max(part[2], part[3]));
-}
 __global__ __launch_bounds__(256) void pipe_split_weight_kernel(SplitArgs sa)
 {
     const int scale = blockIdx.y / sa.nl, layer = blockIdx.y - scale * sa.nl;
@@ -296,10 +292,29 @@ struct CutArgs {
     int n_scales, n_tiles, n_views, nl;
     int *chunk_start, *chunk_rank;
     unsigned long long *chunk_cost; // (kChunks + 1): estimated cost of everything in front of the group boundary a piece starts at
+    SplitArgs split;                // wmax_count > 0: the blocks behind block 0 leave the partial maxima of |W| (they need nothing of the frame)
+    long long wmax_count;           // weights per scale
 };
 __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
 {
     __shared__ unsigned long long part[1024];
+    if (blockIdx.x > 0) {
+        // the partial maxima of max|W| (block 1 + scale * kWmaxParts + part), riding in this launch: as a launch of its own behind the
+        // cuts (rounds 3-4) it was 13 us of the geometry stream's tail
+        const int scale = ((int)blockIdx.x - 1) / kWmaxParts, pi = ((int)blockIdx.x - 1) % kWmaxParts;
+        const float *__restrict__ w = a.split.w[scale];
+        unsigned m = 0u;
+        for (long long i = (long long)pi * 1024 + threadIdx.x; i < a.wmax_count; i += (long long)kWmaxParts * 1024) m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+        m = wave_max_u32(m);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned mm = 0u;
+            for (int i = 0; i < 16; ++i) mm = max(mm, (unsigned)part[i]);
+            a.split.wmax[scale * kWmaxParts + pi] = mm;
+        }
+        return;
+    }
     const int tid = threadIdx.x, n_tiles = a.n_tiles;
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
     const int per = (n_tiles + 1023) / 1024, t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
@@ -1738,8 +1753,9 @@ int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_la
     a.globs = reinterpret_cast<unsigned *>(ws + lay.globs);
     const hipError_t e = zero_fill(ws, lay.masks_bytes, s); // view masks, tile tickets, counters (a kernel, not hipMemsetAsync: see vfa_geom.h)
     if (e != hipSuccess) return (int)e;
-    const long long pairs = (long long)n_views * lay.n_tiles;
-    hipLaunchKernelGGL(pipe_records_kernel, dim3((unsigned)((pairs + 1) / 2)), dim3(kWave), 0, s, a);
+    const long long units = (long long)n_views * lay.n_tiles * n_layers; // (view, tile, layer)
+    if ((units + 1) / 2 >= (1ll << 31)) return VFA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pipe_records_kernel, dim3((unsigned)((units + 1) / 2)), dim3(kWave), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -1762,11 +1778,9 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
     ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
     ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);
     ca.chunk_cost = reinterpret_cast<unsigned long long *>(ws + lay.costs);
-    hipLaunchKernelGGL(pipe_cuts_kernel, dim3(1), dim3(1024), 0, s, ca);
-    int st = (int)hipGetLastError();
-    if (st) return st;
+    SplitArgs sa = {};
+    ca.wmax_count = 0;
     if (weights) {
-        SplitArgs sa;
         sa.nl = n_layers;
         for (int k = 0; k < kMaxScales; ++k) {
             sa.w[k] = weights[k < n_scales ? k : 0];
@@ -1776,11 +1790,13 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
         sa.wmax = reinterpret_cast<unsigned *>(ws + lay.wmax);
         sa.wexp = reinterpret_cast<int *>(ws + lay.wexp);
         sa.f16 = (terms == 0 || terms == 2) ? 1 : 0;
-        if (sa.f16) {
-            hipLaunchKernelGGL(pipe_weight_absmax_kernel, dim3(kWmaxParts, n_scales), dim3(256), 0, s, sa, (long long)kC * kC * n_layers);
-            st = (int)hipGetLastError();
-            if (st) return st;
-        }
+        if (sa.f16) ca.wmax_count = (long long)kC * kC * n_layers; // the partial maxima: spare blocks of the cuts launch
+    }
+    ca.split = sa;
+    hipLaunchKernelGGL(pipe_cuts_kernel, dim3(1 + (ca.wmax_count ? kWmaxParts * n_scales : 0)), dim3(1024), 0, s, ca);
+    int st = (int)hipGetLastError();
+    if (st) return st;
+    if (weights) {
         hipLaunchKernelGGL(pipe_split_weight_kernel, dim3(8 * kSteps * 64 / 256, n_scales * n_layers), dim3(256), 0, s, sa);
         st = (int)hipGetLastError();
     }
