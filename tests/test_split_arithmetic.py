@@ -191,3 +191,66 @@ def test_fp16_split_range_nan_and_saturation():
     assert hi[5] + lo[5] == 3.0 * 2 ** 10
     assert split_exponent(0.0, EXP_A) == 0 and split_exponent(np.nan, EXP_A) == 0 and split_exponent(np.inf, EXP_A) == 0
     assert split_exponent(1e-30, EXP_A) == EXP_LIM and split_exponent(1e30, EXP_A) == -EXP_LIM
+
+
+def _np_split_fragments(w, n_layers):
+    """numpy restatement of the device weight split (vfa_split.h; vfa_fused.hip: split_block, vfa_pipe.hip: pipe_split_weight_kernel):
+    w (256, 256 * nl) in the reference's column order c * nl + layer -> per layer the hi / lo fp16 planes in MFMA B-fragment order,
+    (8 waves, 16 k-steps, 64 lanes, 8 values), and the scale exponent ew with max|w| 2^ew in [2^14, 2^15)."""
+    w = np.asarray(w, dtype=np.float32)
+    amax = np.abs(w).max()
+    ew = 14 - int(np.floor(np.log2(amax)))
+    x = (w * np.float32(2.0 ** ew)).astype(np.float32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    wave, s, lane, j = np.meshgrid(np.arange(8), np.arange(16), np.arange(64), np.arange(8), indexing="ij")
+    n = 32 * wave + (lane & 31)
+    c = 16 * s + 8 * (lane >> 5) + j
+    return [(hi[n, c * n_layers + layer], lo[n, c * n_layers + layer]) for layer in range(n_layers)], ew
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_layers", [1, 3])
+def test_device_weight_fragments_are_the_fp16_split(n_layers):
+    """The collapse weights as the frame kernels read them -- split in the spare blocks of the work-cuts launch (serial path) / after the
+    partial maxima those blocks leave (pipelined path) -- are, bit for bit, hi = RN_f16(w 2^ew), lo = RN_f16(w 2^ew - hi) in MFMA
+    B-fragment order with the exponent of vfa_split.h (reference: the fp32 nn.Linear of vfa_op.py:59, :123)."""
+    import torch
+    from vfa_amd import _lib, ops
+    import vfa_amd
+    from vfa_amd.synthetic import make_workload
+    dev = torch.device("cuda:0")
+    wl = make_workload("multiviewc_200x200x1", channels=256, seed=1, n_cam=2)
+    grid = wl["grid"][:, 40:64, 30:70].contiguous().to(dev)
+    L, W = grid.shape[1:3]
+    calibs = wl["calibs"].to(dev)
+    sizes = [tuple(s) for s in wl["feat_sizes"]]
+    gen = torch.Generator().manual_seed(7)
+    # three scales with maxima in different binades, one of them tiny
+    weights = [(torch.randn(256, 256 * n_layers, generator=gen) * sc).to(dev) for sc in (0.05, 3.0, 1e-4)]
+    kind, img_wh = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
+    if n_layers == 1:
+        mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
+        zl, co = mod._kernel_geometry(dev)
+        ws = ops.frame_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights)
+        lay = ops.frame_workspace_layout(2, L, W, 3)
+        planes = 2
+    else:
+        mod = vfa_amd.VFA(256, grid_height=96, cube_size=(wl["cube_size"][0], wl["cube_size"][1], 32), args=wl["args"]).to(dev)
+        assert mod.num_grid_layer == n_layers
+        zl, co = mod._kernel_geometry(dev)
+        ws = ops.pipe_records(calibs, grid, zl, co, kind, img_wh, sizes, weights=weights)
+        lay = ops.pipe_workspace_layout(2, L, W, n_layers, 3)
+        planes = 3
+    torch.cuda.synchronize()
+    host = ws.cpu().numpy()
+    for s in range(3):
+        want, _ = _np_split_fragments(weights[s].cpu().numpy(), n_layers)
+        per_layer = 8 * 16 * planes * 64 * 16
+        for layer in range(n_layers):
+            raw = host[lay["wfrag"][s] + layer * per_layer:lay["wfrag"][s] + (layer + 1) * per_layer].view(np.float16).reshape(8, 16, planes, 64, 8)
+            hi, lo = want[layer]
+            assert np.array_equal(raw[:, :, 0].view(np.uint16), hi.view(np.uint16)), (s, layer, "hi")
+            assert np.array_equal(raw[:, :, 1].view(np.uint16), lo.view(np.uint16)), (s, layer, "lo")
+            if planes == 3:
+                assert not raw[:, :, 2].view(np.uint16).any()
