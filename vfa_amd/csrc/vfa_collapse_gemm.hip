@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float *__restri
 
 // fp16 form (VFA_FLAG_TERMS 2: the arithmetic of the fused frame kernels, vfa_split.h): max |W| in kWmaxParts partial maxima, then the
 // fragments of W 2^ew split into two fp16 pieces, ew = the exponent that brings max|W| into [2^14, 2^15) -- what
-// split_weight_frag_kernel / pipe_split_weight_kernel of the frame kernels compute, so that the recomputed product of the training
+// split_block (vfa_fused.hip) / pipe_split_weight_kernel of the frame kernels compute, so that the recomputed product of the training
 // backward sees the forward's operands bit for bit.  `tail` (behind the fragments): kWmaxParts partial maxima, then ew.
 constexpr int kWmaxParts = 32;
 __global__ __launch_bounds__(256) void gemm_weight_absmax_kernel(const float *__restrict__ weight, unsigned *tail, size_t count)

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(ChunkArgs a)
 struct FusedScale {
     const float *integral;          // (n_views, Hf+2, Wf+2, 256) zero-bordered channels-last
     const float *bias;              // (256) or NULL
-    const uint4 *wfrag;             // split_weight_frag_kernel output
+    const uint4 *wfrag;             // the split collapse weights (split_block: the spare blocks of the work-cuts launch)
     const unsigned *live, *direct, *overflow; // (n_tiles) each
     const unsigned char *hdrs, *recs;
     int Hf, Wf;
@@ -478,7 +478,7 @@ struct FusedArgs {
     const unsigned *row_counter;    // direct items of the frame
     int rows_cap;                   // row slots in the workspace
     int accumulate;
-    const int *wexp;                // (kMaxScales) scale exponent of the split collapse weight (split_weight_frag_kernel; fp16 form); [kMaxScales]: 2 = fp16 fragments, 3 = bf16
+    const int *wexp;                // (kMaxScales) scale exponent of the split collapse weight (split_block; fp16 form); [kMaxScales]: 2 = fp16 fragments, 3 = bf16
     int debug;                      // diagnostic build only: ablation mask (kDbg*), results are then meaningless
     unsigned long long *diag;       // diagnostic build only: per workgroup 8 cycle counters
 };
