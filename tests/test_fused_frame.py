@@ -477,8 +477,8 @@ def test_two_call_forms_of_the_entry_points_are_bitwise_the_one_call_forms():
 def test_work_cuts_cover_every_item_once(name, n_cam, crop):
     """`tile_chunks_kernel`: the n_chunks + 1 cuts (tile, rank) of the item sequence are monotonic, start at (0, 0), end at (n_tiles, 0),
     never point behind the last item of a tile, and the pieces between them carry equal estimated COST (the kernel's cost model,
-    restated here: an item 330 + its window slots, a row item 280, + 110 for the first item of a (tile, scale), + 380 for the first
-    of a tile, a tile without items 16) to within one item: cuts fall inside tiles."""
+    restated here: an item 704 + its window slots, a row item 522, + 294 for the first item of a (tile, scale), + 330 for the first
+    of a tile, a tile without items 32) to within one item: cuts fall inside tiles."""
     import vfa_amd
     from vfa_amd import _lib, ops
     from vfa_amd.synthetic import make_workload
@@ -505,8 +505,8 @@ def test_work_cuts_cover_every_item_once(name, n_cam, crop):
             for v in range(n_cam):
                 if (int(live[t]) & ~int(ovf[t])) >> v & 1:
                     h = hdr[v, t]
-                    w = 280 if h[0] & 4 else 330 + int(h[1])
-                    weights[t].append(w + (110 if first else 0) + (380 if not weights[t] else 0))
+                    w = 522 if h[0] & 4 else 704 + int(h[1])
+                    weights[t].append(w + (294 if first else 0) + (330 if not weights[t] else 0))
                     first = False
     K = lay["n_chunks"]
     cs = host[lay["chunks"]:lay["chunks"] + (K + 1) * 4].view(np.int32).astype(np.int64)
@@ -519,7 +519,7 @@ def test_work_cuts_cover_every_item_once(name, n_cam, crop):
     before = np.concatenate([[0], np.cumsum(items)])
     upto = before[np.minimum(cs, nt)] + cr          # items in front of each cut
     assert upto[-1] == items.sum()
-    cost_before = np.concatenate([[0], np.cumsum([sum(w) if w else 16 for w in weights])])
+    cost_before = np.concatenate([[0], np.cumsum([sum(w) if w else 32 for w in weights])])
     inner = [np.concatenate([[0], np.cumsum(w)]) for w in weights]
     cost_upto = np.array([cost_before[t] + (inner[t][r] if t < nt else 0) for t, r in zip(np.minimum(cs, nt), cr)])
     biggest = max(max(w) for w in weights if w)
@@ -528,7 +528,8 @@ def test_work_cuts_cover_every_item_once(name, n_cam, crop):
         per = np.diff(upto[idx])
         assert per.sum() == items.sum()
         cost = np.diff(cost_upto[idx])
-        assert cost.max() - cost.min() <= biggest + 0.03 * cost.mean(), (cost.min(), cost.max(), biggest)
+        # (a cut sits at the item boundary nearest to its ideal position: at most half an item off, a piece at most one item, two pieces two)
+        assert cost.max() - cost.min() <= 2 * biggest + 0.03 * cost.mean(), (cost.min(), cost.max(), biggest)
 
 
 def test_serial_kernel_default_product_has_the_width_of_the_reference_sgemm(monkeypatch):

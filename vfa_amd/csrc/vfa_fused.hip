@@ -40,8 +40,8 @@ constexpr int kRecBytes = 96, kHdrBytes = 32;
 constexpr int kMaxScales = 3;
 constexpr int kSlotBytes = kC * 4;                                  // one tap = 256 fp32
 constexpr int kMaxSlots = 123;                                      // LDS tap window of a (tile, view, scale)
-// cost estimate of an item of the persistent kernel in units of 32 cycles (tile_chunks_kernel): base + 1 per window slot
-constexpr unsigned kItemCost = 330, kRowItemCost = 280;
+// cost estimate of an item of the persistent kernel in units of 16 cycles (tile_chunks_kernel): base + 1 per window slot
+constexpr unsigned kItemCost = 704, kRowItemCost = 522; // (unit: 16 cycles -- refitted in the second session of round 5, see tile_chunks_kernel)
 constexpr int kRecSlots = 3;                                        // + the 32 box records of the item (3 KiB) behind it
 constexpr int kThreads = 512;
 constexpr int kRowBytes = 2 * kC;                                   // one bf16 plane row; 16-byte chunks XOR-swizzled with (row & 15)
@@ -361,7 +361,10 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(ChunkArgs a)
     const int tid = threadIdx.x, n_tiles = a.n_tiles;
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
     const int per = (n_tiles + 1023) / 1024, t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
-    constexpr unsigned kScale = 110, kTile = 380, kEmpty = 16;
+    // (refit of round 5, second session, least squares over the 256 workgroups of the bench frame, diagnostic build: cycles ~ 11 255 per
+    // item + 18.6 per slot - 2 894 for a row item + 4 699 per scale change + 5 271 per tile; in units of 16 cycles.  The round-4 constants
+    // -- 330 + slots, 280, 110, 380 in units of 32 -- priced a tile at 12 160 cycles and left the heaviest workgroup 2.7 % above the mean.)
+    constexpr unsigned kScale = 294, kTile = 330, kEmpty = 32;
     // This kernel runs beside the bandwidth-bound integral-image kernels, where every dependent memory round trip costs
     // microseconds: everything a tile needs is requested at once and -- for the first two tiles of a thread, i.e. all of
     // them up to 2048 tiles -- kept in registers for the second walk.
