@@ -103,12 +103,15 @@ with torch.no_grad():
                 seq = np.array(seq)
                 first = np.searchsorted(seq[:, 0], np.arange(tiles + 1))
                 feats = []
+                feats2 = []
                 for wg in range(nblk):
                     c0, c1 = K * wg // nblk, K * (wg + 1) // nblk
                     i0, i1 = first[min(cs[c0], tiles)] + cr[c0], first[min(cs[c1], tiles)] + cr[c1]
                     part = seq[i0:i1]
                     changes = 1 + int(np.count_nonzero(np.diff(part[:, 0] * 4 + part[:, 1]))) if len(part) else 0
                     feats.append((len(part), part[:, 3].sum(), part[:, 4].sum(), changes, len(np.unique(part[:, 0])), 1.0))
+                    feats2.append((np.count_nonzero(part[:, 1] == 0), np.count_nonzero(part[:, 1] == 1), np.count_nonzero(part[:, 1] == 2),
+                                   part[:, 3].sum(), np.maximum(part[:, 3] - 64, 0).sum(), part[:, 4].sum(), changes, len(np.unique(part[:, 0])), 1.0))
                 feats = np.array(feats, dtype=np.float64)
                 # diag rows are indexed by blockIdx.x; the kernel maps it to a range index XCD-contiguously
                 per = (nblk + 7) // 8
@@ -116,6 +119,11 @@ with torch.no_grad():
                 y = np.zeros(nblk)
                 full = ws[diag_off:diag_off + 256 * 64].cpu().numpy().view(np.uint64).reshape(256, 8).astype(np.float64)
                 y[lb] = full[:, :7].sum(1)
+                f2 = np.array(feats2, dtype=np.float64)
+                c2, *_ = np.linalg.lstsq(f2, y, rcond=None)
+                r2 = y - f2 @ c2
+                print("    richer model (items of scale 0 / 1 / 2, slots, slots above 64, row items, scale changes, tiles, 1):", np.array2string(np.round(c2, 1), max_line_width=1000),
+                      f"residual std {r2.std():.3g}, max {r2.max():.3g} of mean {y.mean():.3g}")
                 coef, *_ = np.linalg.lstsq(feats, y, rcond=None)
                 res = y - feats @ coef
                 xcd_of = np.arange(nblk) // per  # (range index -> XCD: xcd_contiguous)
