@@ -143,9 +143,27 @@ def int_array(values):
     return (ctypes.c_int * len(values))(*[int(v) for v in values])
 
 
-def current_stream_handle():
+def current_device_index():
+    """Index of the current device, straight from the runtime binding: `torch.cuda.current_stream(device)` and friends go through
+    `torch.cuda.is_available()` for anything but an int -- an `os.environ.get` each, 10 us per call, seven calls per frame: a third of
+    the host time of a frame (round 5, cProfile of a one-camera frame)."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch._C._cuda_getDevice()
+
+
+def current_stream_handle():
+    """hipStream_t of torch's current stream on the current device."""
+    import torch
+    try:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:  # (an older torch)
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def current_stream(dev):
+    """torch's current stream of `dev` as a Stream object, without the detour described above."""
+    import torch
+    return torch.cuda.current_stream(dev.index if dev.index is not None else current_device_index())
 
 
 def require_device(*tensors):

@@ -15,7 +15,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import ops, vfa_op
+from . import _lib, ops, vfa_op
 
 # The three scale chains (integral image -> projection + pooling -> collapse GEMM) are independent until the final
 # sum, so they are issued on separate HIP streams: the MFMA-bound GEMM of one scale overlaps the latency-bound
@@ -269,7 +269,7 @@ def aggregate_views(vfa8, vfa16, vfa32, lat8, lat16, lat32, calibs, grid, crange
         if N_STREAMS == 1 or not grid.is_cuda:
             lins = [m.project_views(lat, calibs, grid, crange, reserved_cus=reserved) for m, lat in work]
         else:
-            main = torch.cuda.current_stream(grid.device)
+            main = _lib.current_stream(grid.device)
             side = _streams(grid.device)
             lins = []
             for i, (m, lat) in enumerate(work):

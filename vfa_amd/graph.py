@@ -7,6 +7,7 @@ hipGraph on ROCm) and replayed per frame on static input buffers.  Inference onl
 """
 import torch
 
+from . import _lib
 from .aggregate import aggregate_views
 
 
@@ -24,11 +25,11 @@ class GraphedAggregate:
         self.grid = grid.detach().clone()
         self.crange = crange
         side = torch.cuda.Stream(device=grid.device)
-        side.wait_stream(torch.cuda.current_stream(grid.device))
+        side.wait_stream(_lib.current_stream(grid.device))
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):  # allocator / library warm-up outside the capture
                 self._run()
-        torch.cuda.current_stream(grid.device).wait_stream(side)
+        _lib.current_stream(grid.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.static_out = self._run()

@@ -175,7 +175,7 @@ def lateral_conv(feat, weight, bias, gamma, beta, eps=1e-5):
     scale = torch.empty((n, 256), dtype=torch.float32, device=dev)
     shift = torch.empty((n, 256), dtype=torch.float32, device=dev)
     need = _lib.lib().vfa_lateral_conv_workspace_bytes(n, h, w)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, need)
+    key = (dev.index, _lib.current_stream(dev).cuda_stream, need)
     ws = _lateral_ws.get(key)  # (one per (device, stream, size): the three scales of a frame are in flight on one stream together)
     if ws is None:
         ws = _lateral_ws[key] = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
@@ -207,7 +207,7 @@ def lateral_convs(branches):
         scales.append(torch.empty((n, 256), dtype=torch.float32, device=dev))
         shifts.append(torch.empty((n, 256), dtype=torch.float32, device=dev))
         need = _lib.lib().vfa_lateral_conv_workspace_bytes(n, h, w)
-        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, need, len(wss))  # (one per scale: they are in flight together)
+        key = (dev.index, _lib.current_stream(dev).cuda_stream, need, len(wss))  # (one per scale: they are in flight together)
         ws = _lateral_ws.get(key)
         if ws is None:
             ws = _lateral_ws[key] = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
@@ -412,7 +412,7 @@ def grad_weight(g_lin, vox, out=None, accumulate=False):
         accumulate = False
     assert tuple(out.shape) == (256, K) and out.is_contiguous() and out.dtype == torch.float32
     need = _lib.lib().vfa_grad_weight_workspace_bytes(rows, K)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _lib.current_stream(dev).cuda_stream)
     ws = _grad_w_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _grad_w_ws[key] = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
@@ -433,7 +433,7 @@ def grad_input(g_lin, w, out=None):
         out = torch.empty((rows, K), dtype=torch.float32, device=dev)
     assert tuple(out.shape) == (rows, K) and out.is_contiguous() and out.dtype == torch.float32
     need = _lib.lib().vfa_grad_input_workspace_bytes(K)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, "x")
+    key = (dev.index, _lib.current_stream(dev).cuda_stream, "x")
     ws = _grad_w_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _grad_w_ws[key] = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
@@ -498,7 +498,7 @@ def collapse_gemm(vox2d, weight, out=None, terms=0, reserved_cus=0):
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=vox2d.device)
     need = _lib.lib().vfa_collapse_gemm_workspace_bytes(K, N)
-    key = (vox2d.device.index, torch.cuda.current_stream(vox2d.device).cuda_stream)
+    key = (vox2d.device.index, _lib.current_stream(vox2d.device).cuda_stream)
     ws = _gemm_ws.get(key)
     if ws is None or ws.numel() < need:  # one scratch buffer per (device, stream): calls on a stream are ordered
         ws = _gemm_ws[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=vox2d.device)
@@ -523,7 +523,7 @@ def collapse_gemm_relu_backward(vox, weight, bias, grad_out, terms=0, reserved_c
     glin = torch.empty((n, cells, 256), dtype=torch.float32, device=dev)
     gbias = torch.zeros(256, dtype=torch.float32, device=dev)
     need = _lib.lib().vfa_collapse_gemm_workspace_bytes(K, 256)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _lib.current_stream(dev).cuda_stream)
     ws = _gemm_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _gemm_ws[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)

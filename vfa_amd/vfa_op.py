@@ -177,7 +177,7 @@ def fused_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accum
     z_layers, corner_off = m0._kernel_geometry(dev)
     with torch.no_grad():
         # geometry (camera + grid only) on a second HIP stream, beside the integral images (bandwidth-bound, feature maps only)
-        cur = torch.cuda.current_stream(dev)
+        cur = _lib.current_stream(dev)
         # (inside a hipGraph capture the frame stays on ONE stream: a replayed graph pays more for its cross-stream edges than the
         # overlap of geometry and integral images gives -- 0.44 against 0.20 ms per frame on a one-camera bench frame)
         side = _side_stream(dev) if SIDE_STREAM and integrals is None and not torch.cuda.is_current_stream_capturing() else cur
@@ -278,7 +278,7 @@ def pipe_frame(mods, features, calibs, grid, crange=(-1, 0.95), out=None, accumu
     while rows > 4 and ops.pipe_workspace_bytes(n, rows, width, nl, ns) > PIPE_WS_LIMIT:
         rows = max(4, ((rows + 1) // 2 + 3) // 4 * 4)
     with torch.no_grad():
-        cur = torch.cuda.current_stream(dev)
+        cur = _lib.current_stream(dev)
         # (inside a hipGraph capture the frame stays on ONE stream: a replayed graph pays more for its cross-stream edges than the
         # overlap of geometry and integral images gives -- 0.44 against 0.20 ms per frame on a one-camera bench frame)
         side = _side_stream(dev) if SIDE_STREAM and integrals is None and not torch.cuda.is_current_stream_capturing() else cur
@@ -334,7 +334,7 @@ _pipe_pinned = []  # ... and those a captured hipGraph replays into
 def _pipe_state(dev, key, ws_bytes, n_bands):
     # one workspace per (geometry, stream): the geometry call of a frame on another stream must not overwrite records the
     # previous frame's kernel on THIS stream is still reading (`side.wait_stream(cur)` only orders against the current one)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream) + key
+    key = (dev.index, _lib.current_stream(dev).cuda_stream) + key
     capturing = torch.cuda.is_current_stream_capturing()
     st = _pipe_states.pop(key, None)
     if st is None and capturing:
