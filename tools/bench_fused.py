@@ -14,7 +14,8 @@ from vfa_amd.synthetic import make_workload  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "multiviewc_200x200x1"
 dev = torch.device("cuda:0")
-wl = make_workload(name, channels=256, seed=0)
+n_cam_arg = int(sys.argv[2]) if len(sys.argv) > 2 else None
+wl = make_workload(name, channels=256, seed=0, **({"n_cam": n_cam_arg} if n_cam_arg else {}))
 n = wl["n_cam"]
 torch.manual_seed(0)
 mods = [vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev) for _ in range(3)]
