@@ -687,8 +687,28 @@ def test_captured_frames_keep_a_workspace_of_their_own(name):
             assert torch.equal(eager, want_a), rnd
             assert torch.equal(g1(*lats_b), want_b) and torch.equal(g2(*lats_a), want_a), rnd
     if mods[0].num_grid_layer > 1:  # (the pipelined path keeps persistent states; the serial path allocates per frame)
-        pinned = vfa_op._pipe_pinned[pinned_before:]
+        # the workspaces belong to the graph objects (round-5 advisor finding: the process-wide list grew with every capture) ...
+        assert len(vfa_op._pipe_pinned) == pinned_before
+        pinned = g1._states.states + g2._states.states
         assert len(pinned) == 2 and all(st["pinned"] for st in pinned)
         assert not any(st.get("pinned") for st in vfa_op._pipe_states.values())
         owners = [st["ws"].data_ptr() for st in pinned] + [st["ws"].data_ptr() for st in vfa_op._pipe_states.values()]
         assert len(set(owners)) == len(owners)
+        # ... two frames of one geometry inside ONE capture share a workspace (and the balanced shares of the warm-up frame) ...
+        g3 = torch.cuda.CUDAGraph()
+        with torch.no_grad():
+            with vfa_op.owned_capture_states() as keep, torch.cuda.graph(g3):
+                o1 = vfa_amd.aggregate_views(*mods, *lats_a, calibs, grid)
+                o2 = vfa_amd.aggregate_views(*mods, *lats_b, calibs, grid)
+            g3.replay()
+            torch.cuda.synchronize()
+        assert len(keep.states) == 1 and keep.states[0]["frames"] > 0
+        assert torch.equal(o1, want_a) and torch.equal(o2, want_b)
+        # ... and a bare capture (no owner named) still gets a workspace nobody else touches, kept by the process
+        g4 = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(g4):
+            o4 = vfa_amd.aggregate_views(*mods, *lats_a, calibs, grid)
+        g4.replay()
+        torch.cuda.synchronize()
+        assert len(vfa_op._pipe_pinned) == pinned_before + 1 and torch.equal(o4, want_a)
+        del vfa_op._pipe_pinned[pinned_before:]

@@ -16,8 +16,9 @@
 //       that found no row slot)
 //
 // Numerics: tap chains and the box sum are the reference's exact fp32 sequence (same device code as the bit-exact pooling
-// kernels); the quotient is v * RN(1 / area) (<= 1 ulp from the reference's division: VFA_FLAG_DUMP_VOX stores the rows this
-// code forms, tests/test_fused_frame.py); the product, default (TERMS 2): both operands scaled by a power of two and split into two
+// kernels); the quotient is the reference's correctly rounded v / area (vfa_op.py:118-119), formed as RN(1 / area) and two Markstein
+// corrections (box_quotient_scaled, vfa_geom.h): VFA_FLAG_DUMP_VOX stores the rows this code forms and tests/test_fused_frame.py
+// finds them bit for bit the reference's voxel features; the product, default (TERMS 2): both operands scaled by a power of two and split into two
 // fp16 pieces, hi.lo + hi.hi + lo.hi -- the width of the reference's fp32 nn.Linear (vfa_split.h) --; TERMS 3 / 4: two bf16
 // pieces (16-bit operands).  Within the path's post-GEMM tolerance (rtol 1e-4, atol 1e-5 max|ref|), not bitwise -- no GEMM order is.
 #include <hip/hip_runtime.h>
@@ -488,7 +489,7 @@ struct FusedArgs {
 // diagnostic ablations (VFA_FLAG_DEBUG(mask), pool_collapse_kernel<TERMS, true> only)
 constexpr int kDbgNoFills = 1, kDbgNoPool = 2, kDbgNoMfma = 4, kDbgOneW = 8, kDbgNoRecords = 16, kDbgNoExtra = 32, kDbgStamps = 128; // (64: only the direct-item launch)
 // VFA_FLAG_DUMP_VOX: with ONE view and ONE scale, `out` receives the pooled fp32 voxel features (cell, channel) exactly as the
-// pooling code of THIS kernel forms them in front of the operand split -- (((lt + rb) - rt) - lb) * RN(1 / area), masked boxes their
+// pooling code of THIS kernel forms them in front of the operand split -- RN((((lt + rb) - rt) - lb) / area), masked boxes their
 // masked value -- instead of the map: what tests/test_fused_frame.py compares with the reference's voxel features.
 constexpr int kDbgDumpVox = 0x1000; // (set by VFA_FLAG_DUMP_VOX; bits 0-11 are VFA_FLAG_DEBUG's)
 
@@ -1408,7 +1409,7 @@ __global__ __launch_bounds__(512) void pool_direct_kernel(PoolArgs a)
 // 2a. pre-pass of the fused path: the direct items (tap window larger than LDS: boxes right in front of a camera) are pooled
 // here, at full occupancy and with every tap load of a box in flight at once, into fp32 rows in the workspace.  Inside the
 // persistent kernel those loads had nothing to hide behind (W takes half of the register file: 8 taps per round trip,
-// ~53 000 cycles per item).  Same arithmetic as the persistent kernel's own pooling (v * RN(1 / area)).
+// ~53 000 cycles per item).  Same arithmetic as the persistent kernel's own pooling (the correctly rounded v / area: box_quotient_scaled).
 // A fixed grid walks the list of direct items the geometry pass appended to (a grid over all tiles spent its 27 us launching
 // 15 000 workgroups, 95 % of which had nothing to do); one wave = 4 boxes x 64 channels.
 // ------------------------------------------------------------------------------------------------

@@ -21,8 +21,8 @@
 // is finished by whichever of them arrives LAST (a ticket per tile: no workgroup ever waits for another; the last arriver
 // puts the ticket back to zero).  Frames of one or two views run the four-step phase (template parameter SMALL).
 //
-// Numerics: pooling = the reference's exact fp32 sequence up to `v * RN(1 / area)` (<= 1 ulp from its division;
-// VFA_FLAG_DUMP_VOX stores the rows this code forms); product, default: both operands scaled by a power of two and split into two
+// Numerics: pooling = the reference's exact fp32 sequence including the correctly rounded quotient v / area (box_quotient_scaled,
+// vfa_geom.h; VFA_FLAG_DUMP_VOX stores the rows this code forms: bit for bit the reference's voxel features); product, default: both operands scaled by a power of two and split into two
 // fp16 pieces, three MFMA products hi.lo + hi.hi + lo.hi with fp32 accumulation, k ascending (vfa_split.h: the width of the
 // reference's fp32 nn.Linear); VFA_FLAG_TERMS 3 / 4: two bf16 pieces (16-bit operands), 6: three bf16 pieces, six products.  On a
 // single-layer grid the product sequence is vfa_fused.hip's; the two kernels differ by the association of the view sum only.

@@ -74,17 +74,19 @@ __device__ __forceinline__ void fp16_saturate_mode(bool on)
 // piece -- fma(float(hi), -1, x) rounded to fp16 in the instruction: x - float(hi) is exact in fp32 (hi is x rounded to 11 bits), so the
 // one rounding is the rounding of the three-instruction form (v_cvt_f32_f16, v_sub_f32, v_cvt_pk_f16_f32: 12 instructions per quad, 6
 // now).  Bit-identical on 1.7e7 values of every kind -- NaN, infinities, denormals, the fp16 limit -- with MODE.FP16_OVFL on and off
-// (round 5, tools/micro/mix_split.hip).
+// (round 5, tools/micro/mix_split.hip).  The statements are `volatile`: their rounding and saturation read MODE.FP16_OVFL, which the
+// compiler does not know of an asm statement -- volatile keeps them in program order against the s_setreg of fp16_saturate_mode (a
+// side-effecting intrinsic) and its fences instead of leaving that to luck (round-5 advisor finding).
 __device__ __forceinline__ void split_f16x4(float x0, float x1, float x2, float x3, uint2 &hi, uint2 &lo)
 {
     const f32x4v x = {x0, x1, x2, x3};
     const f16x4 h = __builtin_convertvector(x, f16x4);
     hi = __builtin_bit_cast(uint2, h);
     unsigned l0, l1;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi.x), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(hi.x), "v"(x1));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi.y), "v"(x2));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(hi.y), "v"(x3));
+    asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi.x), "v"(x0));
+    asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l0) : "v"(hi.x), "v"(x1));
+    asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi.y), "v"(x2));
+    asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(hi.y), "v"(x3));
     lo = make_uint2(l0, l1);
 }
 

@@ -9,6 +9,7 @@ import torch
 
 from . import _lib
 from .aggregate import aggregate_views
+from .vfa_op import owned_capture_states
 
 
 class GraphedAggregate:
@@ -31,7 +32,8 @@ class GraphedAggregate:
                 self._run()
         _lib.current_stream(grid.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # (the workspaces the captured frame replays into live and die with this object, not with the process)
+        with owned_capture_states() as self._states, torch.cuda.graph(self.graph), torch.no_grad():
             self.static_out = self._run()
 
     def _run(self):

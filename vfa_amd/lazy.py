@@ -16,14 +16,32 @@ is ``F.conv2d``), any tensor method, indexing, arithmetic with a real tensor (al
 the path ``aggregate_views`` takes) computes it: the loop costs the batched frame plus bookkeeping.
 
 Sums are re-associated exactly as ``aggregate_views`` re-associates them (inside the post-GEMM tolerance; pre-GEMM tensors are
-bitwise either way).  A feature map modified IN PLACE between the call and the use would be read in its new state: the record
-keeps the tensor's version counter and raises if it moved.  ``VFA_AMD_LAZY=0`` switches the deferral off (every call computes at once).
+bitwise either way).  A feature map, calibration or grid modified IN PLACE between the call and the use would be read in its new
+state: the record keeps the tensors' version counters and raises if one moved (inference tensors -- ``torch.inference_mode()`` -- have no
+counter and cannot be modified in place outside the mode: nothing to check).  ``VFA_AMD_LAZY=0`` switches the deferral off (every call
+computes at once).
+
+Caveats, by construction:
+* ``a += b`` on two records returns a NEW record (a wrapper has no storage to update): another name bound to ``a`` before the ``+=``
+  keeps the old sum, where a real tensor would have seen the update.  The reference's loop rebinds ``ortho`` and holds no alias.
+* The frame is computed on the stream that is current at FIRST USE, not on the one the feature maps were produced on; a caller that
+  moves between streams between the call and the use orders them itself (as it would for any tensor produced on another stream).
+* Every Python-level use (functions, methods, ``data_ptr()``, ``numpy()``, ``torch.save``, ``copy.deepcopy``, ``__dlpack__`` /
+  ``torch.from_dlpack``) goes through ``__torch_function__`` and sees the real tensor; operators reached below the Python API arrive at
+  ``__torch_dispatch__`` and do too.  The legacy capsule function ``torch.utils.dlpack.to_dlpack`` reads the storage of its argument
+  in C++ without either hook: this module wraps it (below) so that a record is computed first.  A C++ extension that takes the
+  ``at::Tensor`` of a record directly (pybind11, not ``torch.ops``) would still find no storage: call ``vfa_amd.materialize`` first.
 """
 import os
 
 import torch
 
 LAZY = os.environ.get("VFA_AMD_LAZY", "1") == "1"
+
+
+def version_of(t):
+    """The in-place version counter of a tensor; None for inference tensors (they have none, and raise when asked)."""
+    return None if t.is_inference() else t._version
 
 
 def _is_zero(x):
@@ -48,6 +66,7 @@ class DeferredOrtho(torch.Tensor):
     def __new__(cls, terms, grid, crange, shape, device):
         r = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=torch.float32, device=device, requires_grad=False)
         r._terms, r._grid, r._crange, r._value = terms, grid, crange, None
+        r._grid_version = version_of(grid)
         return r
 
     def __init__(self, *a, **k):
@@ -56,6 +75,8 @@ class DeferredOrtho(torch.Tensor):
     def materialize(self):
         if self._value is None:
             from . import vfa_op
+            if version_of(self._grid) != self._grid_version:
+                raise RuntimeError("the grid passed to VFA.forward was modified in place before the (deferred) result was used")
             self._value = vfa_op._materialize(self._terms, self._grid, self._crange)
             self._terms = None
         return self._value
@@ -103,6 +124,27 @@ _METADATA = {_T.shape.__get__, _T.dtype.__get__, _T.device.__get__, _T.requires_
 _ADDS = {_T.add, _T.__add__, _T.__radd__, _T.__iadd__, _T.add_, torch.add}
 
 
+def _guard_legacy_dlpack():
+    """``torch.utils.dlpack.to_dlpack`` (``torch._C._to_dlpack``) exports the storage of its argument without passing through
+    ``__torch_function__`` / ``__torch_dispatch__``: on a record it would hand out (and on this torch: crash on) null storage."""
+    import torch.utils.dlpack as _dl
+    inner = _dl.to_dlpack
+    if getattr(inner, "_vfa_amd_guard", False):
+        return
+
+    def to_dlpack(tensor, *args, **kwargs):
+        return inner(materialize(tensor), *args, **kwargs)
+
+    to_dlpack.__doc__ = inner.__doc__
+    to_dlpack._vfa_amd_guard = True
+    _dl.to_dlpack = to_dlpack
+    if getattr(torch, "to_dlpack", None) is inner:
+        torch.to_dlpack = to_dlpack
+
+
 def materialize(x):
     """The tensor behind a ``DeferredOrtho`` (computing it if need be); anything else is returned as it is."""
     return x.materialize() if isinstance(x, DeferredOrtho) else x
+
+
+_guard_legacy_dlpack()

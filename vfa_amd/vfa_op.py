@@ -328,7 +328,29 @@ PIPE_BALANCE = os.environ.get("VFA_AMD_PIPE_BALANCE", "1") == "1"
 # entries every call missed, re-allocated, re-zeroed and re-balanced (a single-workgroup kernel of milliseconds per call)
 PIPE_STATES_KEPT = int(os.environ.get("VFA_AMD_PIPE_STATES", "8"))
 _pipe_states = {}
-_pipe_pinned = []  # ... and those a captured hipGraph replays into
+_pipe_pinned = []  # ... and those a captured hipGraph replays into, when the capture named no owner (`owned_capture_states`)
+_capture_owner = None
+
+
+class owned_capture_states:
+    """Context manager around a hipGraph capture: the workspaces the captured frames replay into are collected in ``self.states``
+    instead of the process-wide ``_pipe_pinned``, so they live exactly as long as whoever keeps this object beside the graph
+    (``vfa_amd.graph.GraphedAggregate`` does) -- a re-capture after a shape change frees the old ones.  Inside ONE such capture, frames
+    of the same geometry share one workspace (they are ordered on the capture stream like eager frames on a stream) and find the
+    balanced shares of the first."""
+
+    def __init__(self):
+        self.states = []
+
+    def __enter__(self):
+        global _capture_owner
+        self._outer, _capture_owner = _capture_owner, self
+        return self
+
+    def __exit__(self, *exc):
+        global _capture_owner
+        _capture_owner = self._outer
+        return False
 
 
 def _pipe_state(dev, key, ws_bytes, n_bands):
@@ -336,6 +358,10 @@ def _pipe_state(dev, key, ws_bytes, n_bands):
     # previous frame's kernel on THIS stream is still reading (`side.wait_stream(cur)` only orders against the current one)
     key = (dev.index, _lib.current_stream(dev).cuda_stream) + key
     capturing = torch.cuda.is_current_stream_capturing()
+    if capturing and _capture_owner is not None:
+        for st in _capture_owner.states:  # an earlier frame of this capture with the same geometry
+            if st["key"] == key:
+                return st
     st = _pipe_states.pop(key, None)
     if st is None and capturing:
         # A capture runs on a stream of its own: it takes over the workspace a warm-up frame of the same geometry left on another
@@ -353,11 +379,14 @@ def _pipe_state(dev, key, ws_bytes, n_bands):
         ws[lay["balance"]:lay["balance"] + ops.BALANCE_STATE_BYTES].zero_()  # (= vfa_pipe_balance_f32 mode 0)
     if capturing:
         # A hipGraph that is being captured replays into this workspace for as long as it lives: the state belongs to that graph
-        # from here on.  It is kept alive in `_pipe_pinned` and NEVER goes back into `_pipe_states` -- torch hands stream handles out
-        # of a pool of 32, so an eager frame (or a second capture) on a stream with the same handle would otherwise pop it and
-        # write geometry, tickets and balance state into a workspace a live graph replays into.
+        # from here on and NEVER goes back into `_pipe_states` -- torch hands stream handles out of a pool of 32, so an eager frame
+        # (or a second capture) on a stream with the same handle would otherwise pop it and write geometry, tickets and balance state
+        # into a workspace a live graph replays into.  Who keeps it alive: the owner the capture named (`owned_capture_states`:
+        # freed with the graph), else `_pipe_pinned` for the life of the process (a bare ``torch.cuda.graph`` gives this module
+        # nothing to tie the lifetime to: one workspace per captured frame and capture stays allocated).
         st["pinned"] = True
-        _pipe_pinned.append(st)
+        st["key"] = key
+        (_capture_owner.states if _capture_owner is not None else _pipe_pinned).append(st)
         return st
     _pipe_states[key] = st  # (most recent last)
     while len(_pipe_states) > PIPE_STATES_KEPT:
@@ -702,8 +731,9 @@ class VFA(nn.Module):
             # Inference through a per-frame kernel: the result is DEFERRED (vfa_amd/lazy.py) -- the reference's loop over cameras and
             # scales (vfanet.py:64-82) then costs one batched frame instead of 21 launches of a persistent kernel.  (The check is the
             # cheap one on purpose: this branch is taken 21 times per frame on the host.)
-            return lazy.DeferredOrtho([(self, feature, feature._version, calib)], grid, (float(crange[0]), float(crange[1])),
-                                      (1, self.collapse.out_features, length, width), feature.device)
+            return lazy.DeferredOrtho([(self, feature, lazy.version_of(feature), calib, lazy.version_of(calib))], grid,
+                                      (float(crange[0]), float(crange[1])), (1, self.collapse.out_features, length, width),
+                                      feature.device)
         if grid.dim() >= 3 and fused_train_ok([self], 1, (feature,)):
             ortho = fused_frame_train([self], [feature], calib.reshape(1, 3, 4), grid, crange)
         elif self.mfma_collapse_ok(feature) or (grid.dim() >= 3 and pipe_frame_ok([self], 1, (feature,))):
@@ -743,16 +773,16 @@ class VFA(nn.Module):
 
 
 def _materialize(terms, grid, crange):
-    """The tensor behind a ``lazy.DeferredOrtho``: terms = [(module, feature (1,C,h,w), version, calib (3,4)), ...] in call order ->
+    """The tensor behind a ``lazy.DeferredOrtho``: terms = [(module, feature (1,C,h,w), version, calib (3,4), version), ...] in call order ->
     (1, C_out, L, W) = sum over the terms of ``module.forward`` (reference vfa_op.py:61-125 per term, vfanet.py:79, 82 for the sums).
     The terms are grouped by module; when the (at most three) modules saw the same cameras in the same order -- the reference's loop --
     the whole sum is ONE batched frame (``pipe_frame`` / ``fused_frame``: what ``aggregate_views`` runs), otherwise one batched call
     per module, accumulated."""
     groups = {}
-    for mod, feat, version, calib in terms:
-        if feat._version != version:
-            raise RuntimeError("a feature map passed to VFA.forward was modified in place before its (deferred) result was used; "
-                               "clone it, or set VFA_AMD_LAZY=0")
+    for mod, feat, version, calib, calib_version in terms:
+        if lazy.version_of(feat) != version or lazy.version_of(calib) != calib_version:
+            raise RuntimeError("a feature map or calibration passed to VFA.forward was modified in place before its (deferred) "
+                               "result was used; clone it, or set VFA_AMD_LAZY=0")
         groups.setdefault(id(mod), (mod, [], []))
         groups[id(mod)][1].append(feat)
         groups[id(mod)][2].append(calib)
@@ -837,11 +867,23 @@ class FrameGeometry:
                 self.ws = ops.frame_records(calibs, grid3, z_layers, corner_off, conv_kind, (img_w, img_h), self.feat_hws,
                                             weights=[m.layer_major_weight() for m in mods], crange=crange, terms=self.terms)
         self._versions = [(m.collapse.weight._version, m.collapse.weight.data_ptr()) for m in mods]
+        # the cameras and the grid are the caller's contract (a static rig), but an in-place edit is cheap to notice
+        self._rig = (calibs, grid)
+        self._rig_versions = (lazy.version_of(calibs), lazy.version_of(grid))
+        # the records were formed on the stream current HERE: a frame on another stream waits for them
+        self._built_on = _lib.current_stream(dev).cuda_stream
+        self._built = torch.cuda.Event()
+        self._built.record(_lib.current_stream(dev))
 
     def frame(self, features=None, integrals=None, out=None, accumulate=False):
         """features: one (n, 256, Hf, Wf) lateral batch per scale (or ``integrals``: their integral images) -> (1, C, L, W)."""
         if [(m.collapse.weight._version, m.collapse.weight.data_ptr()) for m in self.mods] != self._versions:
             raise RuntimeError("FrameGeometry: a collapse.weight changed since the geometry (which holds its split fragments) was built")
+        if (lazy.version_of(self._rig[0]), lazy.version_of(self._rig[1])) != self._rig_versions:
+            raise RuntimeError("FrameGeometry: calibs or grid were modified in place since the geometry was built (a static rig is the contract)")
+        cur = _lib.current_stream(self.ws.device)
+        if cur.cuda_stream != self._built_on:
+            cur.wait_event(self._built)
         with torch.no_grad():
             if integrals is None:
                 _lib.require_device(*features)
