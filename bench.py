@@ -393,11 +393,16 @@ def roofline_fused(g, workload, entry, live=None, terms=2):
     issued = products * per_launch * live_frac
     achieved = issued / avg_s / 1e12
     waves = "8 matrix waves + 4 pooling waves" if terms == 6 else "8 matrix waves + 8 pooling waves"
-    small = pipe and all(tag[0] <= 2 for tag in g["by_tag"])  # (frames of one or two views run the four-step phase: pipe_kernel<.., SMALL>)
+    def _small(tag):  # (SMALL one- and two-view frames keep the four-step phase: vfa_pipe_seq.h run_tiles_of, restated)
+        nv, L, W, nl, hws = tag
+        tiles = ((L + 3) // 4) * ((W + 7) // 8)
+        nblk = (min(256, tiles) + 7) // 8 * 8
+        return nv <= 2 and 2 * nl * nv * len(hws) * tiles // nblk < 1000
+    small = pipe and all(_small(tag) for tag in g["by_tag"])
     kernel_id = (f"pipe_kernel<{terms}, false, {'true' if small else 'false'}>" if pipe else f"pool_collapse_kernel<{terms}, false, false>")
     kname = (f"{kernel_id} (persistent; {waves} per CU: box pooling from LDS tap windows beside the {label}-split MFMA "
-             "collapse of the previous 64 rows x 64 channels; accumulators of four views in registers across all z-layers; bias + "
-             "ReLU + view / scale sum)") if pipe else \
+             "collapse of the previous 64 rows x 64 channels; accumulators of four (tile, view) sub-tiles in registers across all z-layers; "
+             "bias + ReLU + view / scale sum)") if pipe else \
             (f"pool_collapse_kernel<{terms}, false, false> (persistent, one launch per frame: box pooling of all views x scales from LDS "
              f"tap windows -> {label}-split MFMA collapse -> bias + ReLU + view / scale sum); the HIP events bracket the call that "
              "launches it (+ the empty launch for direct items without a row slot, ~5 us); its pre-pass pool_rows_kernel (the 4 % "

@@ -1,6 +1,7 @@
 // CPU check of vfa_amd/csrc/vfa_pipe_seq.h (the step order of the pipelined frame kernel): for random live-view masks and
-// random work cuts every (tile, scale, live view, layer, quarter) is visited exactly once, in groups of <= 4 views, with
-// consistent first / last flags.  Built and run by tests/test_pipe_seq.py.
+// random work cuts every (tile, scale, live view, layer, quarter) is visited exactly once, in groups of <= 4 sub-tiles of ONE run and
+// ONE scale taken in (tile, view) order across the tiles of the run, with consistent first / last flags; the group count of the
+// cost walk (walk_run) equals the generator's (walk_groups).  Built and run by tests/test_pipe_seq.py.
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -20,39 +21,52 @@ struct HostMasks {
 
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s (seed %u)\n", __FILE__, __LINE__, #c, seed); return 1; } } while (0)
 
-// serial restatement of pipe_cuts_kernel: chunk c starts at the group (start[c], rank[c])
-static void serial_cuts(const std::vector<unsigned> &live, int n_tiles, int n_scales, int nl, int n_chunks, std::vector<int> &start,
+static void counts_of(const std::vector<unsigned> &live, int n_tiles, int n_scales, int rt, int run, int *counts, int &tiles)
+{
+    tiles = 0;
+    for (int s = 0; s < 3; ++s) counts[s] = 0;
+    for (int off = 0; off < rt; ++off) {
+        const int t = run * rt + off;
+        if (t >= n_tiles) break;
+        ++tiles;
+        for (int s = 0; s < n_scales; ++s) counts[s] += __builtin_popcount(live[(size_t)s * n_tiles + t]);
+    }
+}
+
+// serial restatement of pipe_cuts_kernel: chunk c starts at the group (start[c], rank[c]) -- start in RUNS
+static void serial_cuts(const std::vector<unsigned> &live, int n_tiles, int n_scales, int nl, int rt, int n_chunks, std::vector<int> &start,
                         std::vector<int> &rank)
 {
-    std::vector<unsigned long long> before(n_tiles + 1, 0);
-    for (int t = 0; t < n_tiles; ++t) {
-        unsigned m[3] = {0, 0, 0};
-        for (int s = 0; s < n_scales; ++s) m[s] = live[(size_t)s * n_tiles + t];
-        before[t + 1] = before[t] + walk_tile(m, n_scales, nl, 0u, [](int, unsigned, unsigned) {});
+    const int n_runs = runs_of(n_tiles, rt);
+    std::vector<unsigned long long> before(n_runs + 1, 0);
+    for (int r = 0; r < n_runs; ++r) {
+        int counts[3], tiles;
+        counts_of(live, n_tiles, n_scales, rt, r, counts, tiles);
+        before[r + 1] = before[r] + walk_run(counts, n_scales, nl, 0u, tiles, [](int, unsigned, unsigned) {});
     }
-    const unsigned long long total = before[n_tiles];
-    start.assign(n_chunks + 1, n_tiles);
+    const unsigned long long total = before[n_runs];
+    start.assign(n_chunks + 1, n_runs);
     rank.assign(n_chunks + 1, 0);
     auto pos_of = [&](long long c) { return (total * (unsigned long long)c + n_chunks - 1) / n_chunks; };
     long long c = 0;
-    for (int t = 0; t < n_tiles; ++t) {
-        unsigned m[3] = {0, 0, 0};
-        for (int s = 0; s < n_scales; ++s) m[s] = live[(size_t)s * n_tiles + t];
-        const unsigned long long tb = before[t];
+    for (int r = 0; r < n_runs; ++r) {
+        int counts[3], tiles;
+        counts_of(live, n_tiles, n_scales, rt, r, counts, tiles);
+        const unsigned long long tb = before[r];
         int n_groups = 0;
-        walk_tile(m, n_scales, nl, 0u, [&](int k, unsigned, unsigned) { n_groups = k + 1; });
-        const unsigned w = walk_tile(m, n_scales, nl, 0u, [&](int kk, unsigned w0, unsigned w1) {
+        walk_run(counts, n_scales, nl, 0u, tiles, [&](int k, unsigned, unsigned) { n_groups = k + 1; });
+        const unsigned w = walk_run(counts, n_scales, nl, 0u, tiles, [&](int kk, unsigned w0, unsigned w1) {
             while (c < n_chunks) {
                 const unsigned long long pc = pos_of(c);
                 if (pc >= tb + w1) break;
                 const int k = ((unsigned)(pc - tb) - w0) * 2 < (w1 - w0) ? kk : kk + 1;
-                if (k >= n_groups) { start[c] = t + 1 < n_tiles ? t + 1 : n_tiles; rank[c] = 0; }
-                else { start[c] = t; rank[c] = k; }
+                if (k >= n_groups) { start[c] = r + 1 < n_runs ? r + 1 : n_runs; rank[c] = 0; }
+                else { start[c] = r; rank[c] = k; }
                 ++c;
             }
         });
         if (n_groups == 0)
-            for (; c < n_chunks && pos_of(c) < tb + w; ++c) { start[c] = t; rank[c] = 0; }
+            for (; c < n_chunks && pos_of(c) < tb + w; ++c) { start[c] = r; rank[c] = 0; }
     }
 }
 
@@ -65,6 +79,9 @@ int main(int argc, char **argv)
         std::mt19937 rng(seed);
         const int n_tiles = 1 + (int)(rng() % 40), n_scales = 1 + (int)(rng() % 3), nl = 1 + (int)(rng() % 5);
         const int n_views = 1 + (int)(rng() % 12), n_chunks = 64, nblk = 1 + (int)(rng() % 24);
+        const int rts[3] = {1, 2, 4};
+        const int rt = rts[rng() % 3];
+        const int n_runs = runs_of(n_tiles, rt);
         const unsigned vm = (1u << n_views) - 1u;
         const unsigned density = rng() % 4;
         std::vector<unsigned> live((size_t)n_scales * n_tiles);
@@ -74,49 +91,78 @@ int main(int argc, char **argv)
             if (density == 1 && rng() % 3 == 0) x = 0;
             if (density == 2) x = vm;
         }
+        // the cost walk and the generator agree on the number of groups of every run, and a run's groups are full except the last
+        // one of a scale
+        for (int r = 0; r < n_runs; ++r) {
+            int counts[3], tiles, n_cost = 0;
+            counts_of(live, n_tiles, n_scales, rt, r, counts, tiles);
+            walk_run(counts, n_scales, nl, 0u, tiles, [&](int k, unsigned, unsigned) { n_cost = k + 1; });
+            int last_scale = -1, last_nj = 4;
+            const int n_gen = walk_groups(n_scales, rt, 0, [&](int s, int off) { return r * rt + off < n_tiles ? live[(size_t)s * n_tiles + r * rt + off] : 0u; },
+                                          [&](int, int s, unsigned, int nj, int) { if (s == last_scale && last_nj != 4) std::abort(); last_scale = s; last_nj = nj; });
+            CHECK(n_cost == n_gen);
+        }
         std::vector<int> start, rank;
-        serial_cuts(live, n_tiles, n_scales, nl, n_chunks, start, rank);
+        serial_cuts(live, n_tiles, n_scales, nl, rt, n_chunks, start, rank);
         CHECK(start[0] == 0 && rank[0] == 0);
-        CHECK(start[n_chunks] == n_tiles && rank[n_chunks] == 0);
+        CHECK(start[n_chunks] == n_runs && rank[n_chunks] == 0);
         // (tile, scale, view) -> count of (layer, q) visits
         std::map<std::tuple<int, int, int>, int> seen;
-        std::map<int, int> tile_last_count, tile_parts;
+        std::map<int, int> run_last_count, run_parts;
         for (int wg = 0; wg < nblk; ++wg) {
             const int c0 = (int)((long long)n_chunks * wg / nblk), c1 = (int)((long long)n_chunks * (wg + 1) / nblk);
-            const int tb = start[c0], kb = rank[c0], te = start[c1], ke = rank[c1];
-            CHECK(tb < te || (tb == te && kb <= ke));
-            if (tb > te || (tb == te && kb >= ke)) continue;
+            const int rb = start[c0], kb = rank[c0], re = start[c1], ke = rank[c1];
+            CHECK(rb < re || (rb == re && kb <= ke));
+            if (rb > re || (rb == re && kb >= ke)) continue;
             Sequencer<HostMasks> sq;
             sq.masks = HostMasks{&live, n_tiles};
-            sq.begin(n_scales, nl, tb, kb, te, ke);
-            Step prev; prev.tile = -1;
+            sq.begin(n_scales, nl, n_tiles, rt, rb, kb, re, ke);
+            Step prev; prev.run = -1;
             int steps = 0, cur_phase = -1;
             std::map<int, int> touched;
+            // contributions of this workgroup: (tile, scale) -> indices stored so far (one per (group, tile): vfa_pipe_seq.h)
+            std::map<std::pair<int, int>, int> contrib;
+            int prev_group_phase = -1;
             for (;;) {
                 const Step st = sq.next();
                 if (!st.valid()) break;
                 CHECK(st.index == steps);
                 ++steps;
-                CHECK(st.tile >= tb && st.tile < (ke > 0 ? te + 1 : te));
+                CHECK(st.run >= rb && st.run < (ke > 0 ? re + 1 : re));
                 CHECK(st.nj >= 1 && st.nj <= 4 && st.set == (st.index & 1));
                 CHECK(st.layer >= 0 && st.layer < nl && st.q >= 0 && st.q < 4);
                 CHECK(st.phase == cur_phase || st.phase == cur_phase + 1);
                 cur_phase = st.phase;
                 CHECK(st.grp_first == (st.layer == 0 && st.q == 0));
                 CHECK(st.grp_last == (st.layer == nl - 1 && st.q == 3));
-                if (prev.valid() && prev.tile == st.tile) CHECK(!prev.tile_last);
-                if (prev.valid() && prev.tile != st.tile) CHECK(prev.tile_last);
+                if (prev.valid() && prev.run == st.run) CHECK(!prev.run_last);
+                if (prev.valid() && prev.run != st.run) CHECK(prev.run_last);
+                for (int j = 1; j < st.nj; ++j) // sub-tiles of a group in (tile, view) order
+                    CHECK(st.tile(j, rt) > st.tile(j - 1, rt) || (st.tile(j, rt) == st.tile(j - 1, rt) && st.view(j) > st.view(j - 1)));
                 for (int x = 0; x < st.in_set(); ++x) {
-                    const int v = st.view(2 * st.set + x);
-                    CHECK(v < n_views && ((live[(size_t)st.scale * n_tiles + st.tile] >> v) & 1u));
-                    seen[std::make_tuple(st.tile, st.scale, v)] += 1;
+                    const int j = 2 * st.set + x, v = st.view(j), t = st.tile(j, rt);
+                    CHECK(t < n_tiles && t / rt == st.run);
+                    CHECK(v < n_views && ((live[(size_t)st.scale * n_tiles + t] >> v) & 1u));
+                    seen[std::make_tuple(t, st.scale, v)] += 1;
                 }
-                if (st.tile_last) tile_last_count[st.tile] += 1;
-                touched[st.tile] = 1;
+                if (st.grp_last && st.set == 1 && st.phase != prev_group_phase) { // the group ends: one contribution per tile of the group
+                    prev_group_phase = st.phase;
+                    CHECK(st.ci >= 0 && st.ci < contributions_of(n_views));
+                    for (int j = 0; j < st.nj; ++j) {
+                        if (j > 0 && st.tile(j, rt) == st.tile(j - 1, rt)) continue;
+                        const int ci = j == 0 ? st.ci : 0;
+                        int &cnt = contrib[std::make_pair(st.tile(j, rt), st.scale)];
+                        CHECK(ci == cnt); // indices of a (tile, scale) are handed out consecutively from 0 inside a workgroup
+                        ++cnt;
+                        CHECK(cnt <= contributions_of(n_views));
+                    }
+                }
+                if (st.run_last) run_last_count[st.run] += 1;
+                touched[st.run] = 1;
                 prev = st;
             }
-            if (prev.valid()) CHECK(prev.tile_last);
-            for (auto &kv : touched) tile_parts[kv.first] += 1;
+            if (prev.valid()) CHECK(prev.run_last);
+            for (auto &kv : touched) run_parts[kv.first] += 1;
         }
         for (int t = 0; t < n_tiles; ++t)
             for (int s = 0; s < n_scales; ++s)
@@ -125,7 +171,7 @@ int main(int argc, char **argv)
                     auto it = seen.find(std::make_tuple(t, s, v));
                     CHECK((it == seen.end() ? 0 : it->second) == (on ? 4 * nl : 0));
                 }
-        for (auto &kv : tile_parts) CHECK(tile_last_count[kv.first] == kv.second); // every part of a tile ends with a tile_last step
+        for (auto &kv : run_parts) CHECK(run_last_count[kv.first] == kv.second); // every part of a run ends with a run_last step
     }
     std::printf("ok %d rounds\n", rounds);
     return 0;

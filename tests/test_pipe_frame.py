@@ -8,6 +8,8 @@ vfa/model/vfanet.py:64-82 (camera loop); shipped layer counts vfa/config.py:22-2
 """
 from types import SimpleNamespace
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -168,10 +170,11 @@ def test_pipe_multi_layer_vs_float64_and_the_vox_through_hbm_path(name, n_cam, c
     ("multiviewc_200x200x1", 2, None, None),              # single layer, 1250 tiles, tiles cut between workgroups
     ("wildtrack_120x360x8", 2, (24, 96), (50, 130)),      # eight layers, many masked boxes
 ])
-def test_four_step_phase_of_one_and_two_view_frames_equals_the_eight_step_form(name, n_cam, crop, origin):
-    """A frame of at most two views (a rank's share of a camera-sharded rig) runs ``pipe_kernel<.., SMALL>``: four steps per phase, no
-    empty set-1 steps.  Same pooling, same product sequence, same association of the view sum as the eight-step form -- which the
-    diagnostic build still runs (VFA_FLAG_DEBUG 8: "no wave priorities", nothing else) --: bit for bit the same map."""
+def test_one_and_two_view_frames_fill_their_groups_across_tiles(name, n_cam, crop, origin):
+    """A frame of one or two views (a rank's share of a camera-sharded rig): a group takes its four sub-tiles from up to four TILES of a
+    run (round 6; rounds 4-5 ran a four-step phase with one or two sub-tiles per pass of the weight).  Against float64, and the
+    production build against the diagnostic build (VFA_FLAG_DEBUG 8: "no wave priorities", nothing else) bit for bit, on 256 and
+    on 8 workgroups (runs shared between workgroups at other places)."""
     from vfa_amd import _lib, ops
     dev = _dev()
     wl, grid, lats, calibs = _frame(name, n_cam, crop, dev, origin=origin or (11, 5))
@@ -474,24 +477,34 @@ def test_pipe_work_cuts_match_the_serial_restatement():
 
     globs = host[lay["globs"]:lay["globs"] + 4 * tiles].view(np.uint32)
 
-    def groups_of(t):  # costs of the groups of tile t in (scale, view) order (vfa_pipe_seq.h: group_cost, walk_tile)
+    # tiles of a run (vfa_pipe_seq.h: run_tiles_of, restated): a group takes up to four live (tile, view) sub-tiles of one (run, scale)
+    nblk = min(256, tiles)
+    nblk = (nblk + 7) // 8 * 8
+    steps = 2 * nl * n * ns * tiles // nblk
+    RUN = (4 if steps >= 1000 else 1) if n <= 2 else (4 if steps >= 4000 else (2 if steps >= 1200 else 1))
+    forced = os.environ.get("VFA_AMD_PIPE_RT")
+    RUN = int(forced) if forced in ("1", "2", "4") else RUN
+    runs = (tiles + RUN - 1) // RUN
+
+    def groups_of(r):  # costs of the groups of run r in (scale, tile, view) order (vfa_pipe_seq.h: group_cost, walk_run)
         out = []
+        ts = range(r * RUN, min(tiles, (r + 1) * RUN))
         for s in range(ns):
-            left = bin(int(live[s][t])).count("1")
+            left = sum(bin(int(live[s][t])).count("1") for t in ts)
             while left > 0:
                 nj = min(left, 4)
                 sets = (nj + 1) // 2
-                out.append(4 * nl * (69 * sets + 46 * (2 - sets)) + 14 + ((36 + 4 * 35 * int(globs[t])) if not out else 0))
+                out.append(4 * nl * (69 * sets + 46 * (2 - sets)) + 14 + ((36 * len(ts) + 4 * 35 * sum(int(globs[t]) for t in ts)) if not out else 0))
                 left -= nj
         return out
 
-    costs = [groups_of(t) for t in range(tiles)]
-    weight = [sum(c) if c else 1 for c in costs]
+    costs = [groups_of(r) for r in range(runs)]
+    weight = [sum(c) if c else min(RUN, tiles - r * RUN) for r, c in enumerate(costs)]
     before = np.concatenate([[0], np.cumsum(weight)])
     total = int(before[-1])
-    exp_start, exp_rank = np.full(K + 1, tiles, np.int32), np.zeros(K + 1, np.int32)
+    exp_start, exp_rank = np.full(K + 1, runs, np.int32), np.zeros(K + 1, np.int32)
     c = 0
-    for t in range(tiles):
+    for t in range(runs):
         tb, w0 = int(before[t]), 0
         for k, wi in enumerate(costs[t]):
             while c < K:
@@ -500,13 +513,13 @@ def test_pipe_work_cuts_match_the_serial_restatement():
                     break
                 kk = k if (pc - tb - w0) * 2 < wi else k + 1
                 if kk >= len(costs[t]):
-                    exp_start[c], exp_rank[c] = (t + 1 if t + 1 < tiles else tiles), 0
+                    exp_start[c], exp_rank[c] = (t + 1 if t + 1 < runs else runs), 0
                 else:
                     exp_start[c], exp_rank[c] = t, kk
                 c += 1
             w0 += wi
         if not costs[t]:
-            while c < K and (total * c + K - 1) // K < tb + 1:
+            while c < K and (total * c + K - 1) // K < tb + weight[t]:
                 exp_start[c], exp_rank[c] = t, 0
                 c += 1
     assert np.array_equal(start, exp_start) and np.array_equal(rank, exp_rank)

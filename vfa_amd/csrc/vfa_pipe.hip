@@ -28,6 +28,7 @@
 // single-layer grid the product sequence is vfa_fused.hip's; the two kernels differ by the association of the view sum only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vfa_geom.h"
 #include "vfa_pipe_seq.h"
@@ -83,6 +84,13 @@ constexpr int kTileLive = 1, kTileDirect = 2;
 // VFA_FLAG_DUMP_VOX (diagnostic build): with ONE view, ONE scale and ONE layer `out` receives the pooled fp32 voxel features (cell,
 // channel) exactly as the pooling waves form them in front of the operand split, instead of the map (tests/test_pipe_frame.py)
 constexpr int kDbgDumpVox = 0x1000; // (set by VFA_FLAG_DUMP_VOX; bits 0-11 are VFA_FLAG_DEBUG's)
+// Compile-time ablation of the PRODUCTION kernels (tools/ablate_pipe.sh builds one library per mask; results are then meaningless):
+// 1 no window fills, 2 no pooling, 4 no MFMAs, 64 loop + tables + barriers only.  The run-time masks of the diagnostic build
+// (VFA_FLAG_DEBUG) time a kernel with other registers and a kernel-argument load per check: 17 % slower before anything is ablated.
+#ifndef VFA_PIPE_ABLATE
+#define VFA_PIPE_ABLATE 0
+#endif
+constexpr int kAblate = VFA_PIPE_ABLATE;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -284,12 +292,12 @@ __global__ __launch_bounds__(256) void pipe_split_weight_kernel(SplitArgs sa)
     out[((size_t)(wave * kSteps + s) * kWPlanes + 2) * 64 + lane] = p2.u;
 }
 
-// work cuts (vfa_pipe_seq.h: walk_tile): one workgroup, an LDS scan over per-thread sums, then every thread places the cuts
-// that fall into its tiles
+// work cuts (vfa_pipe_seq.h: walk_run): one workgroup, an LDS scan over per-thread sums, then every thread places the cuts
+// that fall into its RUNS of tiles (chunk_start counts runs, chunk_rank groups of the run)
 struct CutArgs {
     const unsigned *live[kMaxScales];
     const unsigned *globs;
-    int n_scales, n_tiles, n_views, nl;
+    int n_scales, n_tiles, n_views, nl, rt; // rt: tiles of a run (vfa_pipe_seq.h: run_tiles_of)
     int *chunk_start, *chunk_rank;
     unsigned long long *chunk_cost; // (kChunks + 1): estimated cost of everything in front of the group boundary a piece starts at
     SplitArgs split;                // wmax_count > 0: the blocks behind block 0 leave the partial maxima of |W| (they need nothing of the frame)
@@ -315,21 +323,32 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
         }
         return;
     }
-    const int tid = threadIdx.x, n_tiles = a.n_tiles;
+    const int tid = threadIdx.x, n_tiles = a.n_tiles, rt = a.rt, n_runs = runs_of(n_tiles, rt);
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
-    const int per = (n_tiles + 1023) / 1024, t0 = min(n_tiles, tid * per), t1 = min(n_tiles, t0 + per);
-    auto masks_of = [&](int t, unsigned *m) {
+    const int per = (n_runs + 1023) / 1024, r0 = min(n_runs, tid * per), r1 = min(n_runs, r0 + per);
+    // live sub-tiles of (run, scale), the run's tiles and its items pooled from L2
+    auto counts_of = [&](int r, int *cnt, int &tiles, unsigned &globs) {
+        tiles = min(rt, n_tiles - r * rt);
+        globs = 0u;
 #pragma unroll
-        for (int s = 0; s < kMaxScales; ++s) m[s] = s < a.n_scales ? (a.live[s][t] & view_mask) : 0u;
+        for (int s = 0; s < kMaxScales; ++s) cnt[s] = 0;
+        for (int off = 0; off < tiles; ++off) {
+            const int t = r * rt + off;
+            globs += a.globs[t];
+#pragma unroll
+            for (int s = 0; s < kMaxScales; ++s)
+                if (s < a.n_scales) cnt[s] += __popc(a.live[s][t] & view_mask);
+        }
     };
     unsigned long long local = 0;
-    for (int t = t0; t < t1; ++t) {
-        unsigned m[kMaxScales];
-        masks_of(t, m);
-        local += walk_tile(m, a.n_scales, a.nl, a.globs[t], [](int, unsigned, unsigned) {});
+    for (int r = r0; r < r1; ++r) {
+        int cnt[kMaxScales], tiles;
+        unsigned globs;
+        counts_of(r, cnt, tiles, globs);
+        local += walk_run(cnt, a.n_scales, a.nl, globs, tiles, [](int, unsigned, unsigned) {});
     }
     part[tid] = local;
-    for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_tiles; a.chunk_rank[c] = 0; a.chunk_cost[c] = ~0ull; }
+    for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_runs; a.chunk_rank[c] = 0; a.chunk_cost[c] = ~0ull; }
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
         const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
@@ -342,28 +361,28 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
     // (pieces behind the last group keep chunk_cost = ~0: the balance kernel reads them as `total`)
     unsigned long long before = part[tid] - local;
     auto pos_of = [&](long long cc) { return (total * (unsigned long long)cc + kChunks - 1) / kChunks; };
-    for (int t = t0; t < t1; ++t) {
+    for (int r = r0; r < r1; ++r) {
         const unsigned long long tb = before;
         long long c = tb > 0 ? (long long)((tb - 1) * kChunks / total) : 0;
         while (c < kChunks && pos_of(c) < tb) ++c;
-        unsigned m[kMaxScales];
-        masks_of(t, m);
+        int cnt[kMaxScales], tiles;
+        unsigned globs;
+        counts_of(r, cnt, tiles, globs);
         int n_groups = 0;
-        const unsigned globs = a.globs[t];
-        walk_tile(m, a.n_scales, a.nl, globs, [&](int kk, unsigned, unsigned) { n_groups = kk + 1; });
-        const unsigned w = walk_tile(m, a.n_scales, a.nl, globs, [&](int kk, unsigned w0, unsigned w1) {
+        walk_run(cnt, a.n_scales, a.nl, globs, tiles, [&](int kk, unsigned, unsigned) { n_groups = kk + 1; });
+        const unsigned w = walk_run(cnt, a.n_scales, a.nl, globs, tiles, [&](int kk, unsigned w0, unsigned w1) {
             while (c < kChunks) {
                 const unsigned long long pc = pos_of(c);
                 if (pc >= tb + w1) break;
                 const int k = ((unsigned)(pc - tb) - w0) * 2 < (w1 - w0) ? kk : kk + 1;
-                if (k >= n_groups) { a.chunk_start[c] = t + 1 < n_tiles ? t + 1 : n_tiles; a.chunk_rank[c] = 0; }
-                else { a.chunk_start[c] = t; a.chunk_rank[c] = k; }
+                if (k >= n_groups) { a.chunk_start[c] = r + 1 < n_runs ? r + 1 : n_runs; a.chunk_rank[c] = 0; }
+                else { a.chunk_start[c] = r; a.chunk_rank[c] = k; }
                 a.chunk_cost[c] = tb + (k == kk ? w0 : w1);
                 ++c;
             }
         });
         if (n_groups == 0)
-            for (; c < kChunks && pos_of(c) < tb + w; ++c) { a.chunk_start[c] = t; a.chunk_rank[c] = 0; a.chunk_cost[c] = tb; }
+            for (; c < kChunks && pos_of(c) < tb + w; ++c) { a.chunk_start[c] = r; a.chunk_rank[c] = 0; a.chunk_cost[c] = tb; }
         before += w;
     }
 }
@@ -384,11 +403,13 @@ struct PipeScale {
 };
 struct PipeArgs {
     PipeScale sc[kMaxScales];
-    int n_scales, n_views, nl, L, W, tiles_w, n_tiles;
+    int n_scales, n_views, nl, L, W, tiles_w, n_tiles, rt; // rt: tiles of a run (vfa_pipe_seq.h: run_tiles_of -- the cuts were made for the same)
     float *out;                     // (L * W, 256)
     const int *chunk_start, *chunk_rank;
-    float *partial;                 // (kMaxBlocks, 2) x 8 waves x 16 registers x 64 lanes: sums of a workgroup's part of a shared tile
-    unsigned *tickets;              // (n_tiles): parts of a shared tile that have arrived (zero between launches: the geometry call, then the last arriver)
+    float *partial;                 // (kMaxBlocks, 2, kRunTiles) x 8 waves x 16 registers x 64 lanes: a workgroup's sums of the tiles of a run it shares (first / last run)
+    float *slots;                   // (blocks, kRunTiles, kMaxScales, n_contrib) x 8 waves x 16 x 64: the contributions to the tiles of the run a workgroup is in (private to it)
+    int n_contrib;                  // contributions a (tile, scale) can get from one workgroup (vfa_pipe_seq.h: contributions_of)
+    unsigned *tickets;              // (runs, 8 matrix waves): parts of a shared run that have arrived, per wave (zero between launches: the geometry call, then the last arriver)
     int accumulate;
     unsigned long long *diag;       // per workgroup 8 counters (VFA_FLAG_DEBUG)
     int debug;
@@ -535,7 +556,6 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     __shared__ __align__(16) unsigned char s_rec0[2 * kTileBoxes * kRecBytes];
     __shared__ __align__(16) unsigned char s_rec1[2 * kTileBoxes * kRecBytes];
     __shared__ __align__(16) unsigned s_hdr[4][64];                         // headers of the phases in flight: [phase & 3][sub-tile][8]
-    __shared__ unsigned s_misc[16];
     // per scale: integral, recs, wfrag, hdrs (lo, hi each), Hf, Wf | (ea + 128) << 16, nl * n_views, n_views; fp16 form: 2^(ea+ew), 2^-(ea+ew)
     __shared__ __align__(16) unsigned s_sc[kMaxScales][16];
     __shared__ unsigned s_amax[kMaxScales];
@@ -567,10 +587,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         tb = uniform_i(a.chunk_start[c0]); kb = uniform_i(a.chunk_rank[c0]);
         te = uniform_i(a.chunk_start[c1]); ke = uniform_i(a.chunk_rank[c1]);
     };
-    int t_begin, k_begin, t_end, k_end;
-    range_of(lb, t_begin, k_begin, t_end, k_end);
+    const int rt = a.rt;                // tiles of a run: 1, 2 or 4
+    int r_begin, k_begin, r_end, k_end; // runs of rt tiles, groups of a run (vfa_pipe_seq.h)
+    range_of(lb, r_begin, k_begin, r_end, k_end);
     unsigned long long *wg_cycles = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(a.balance) + kBalCyclesAt) + lb;
-    if (t_begin > t_end || (t_begin == t_end && k_begin >= k_end)) {
+    if (r_begin > r_end || (r_begin == r_end && k_begin >= k_end)) {
         if (tid == 0) *wg_cycles = 0ull;
         return;
     }
@@ -579,30 +600,30 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     masks.l0 = a.sc[0].live; masks.l1 = a.sc[1].live; masks.l2 = a.sc[2].live;
     masks.view_mask = view_mask;
 
-    // a tile is SHARED when another workgroup holds groups of it too
-    auto shared_tile = [&](int tile) { return (tile == t_begin && k_begin > 0) || (tile == t_end && k_end > 0); };
+    // a run is SHARED when another workgroup holds groups of it too
+    auto shared_run = [&](int run) { return (run == r_begin && k_begin > 0) || (run == r_end && k_end > 0); };
 
-    // the workgroups that hold groups of `tile` beside this one: first, last, how many (this one included)
-    auto share_of = [&](int tile, int &first, int &last, int &parts) {
+    // the workgroups that hold groups of `run` beside this one: first, last, how many (this one included)
+    auto share_of = [&](int run, int &first, int &last, int &parts) {
         first = lb; last = lb; parts = 1;
         for (int j = lb - 1; j >= 0; --j) {
             int tb, kb, te, ke;
             range_of(j, tb, kb, te, ke);
-            if (te < tile || (te == tile && ke == 0)) break; // ends in front of the tile
+            if (te < run || (te == run && ke == 0)) break; // ends in front of the run
             if (tb > te || (tb == te && kb >= ke)) continue; // (empty range)
             first = j; ++parts;
         }
         for (int j = lb + 1; j < nblk; ++j) {
             int tb, kb, te, ke;
             range_of(j, tb, kb, te, ke);
-            if (tb > tile) break;
+            if (tb > run) break;
             if (tb > te || (tb == te && kb >= ke)) continue;
             last = j; ++parts;
         }
     };
     int sh_b_first = lb, sh_b_last = lb, sh_b_parts = 1, sh_e_first = lb, sh_e_last = lb, sh_e_parts = 1;
-    if (k_begin > 0) share_of(t_begin, sh_b_first, sh_b_last, sh_b_parts);
-    if (k_end > 0) share_of(t_end, sh_e_first, sh_e_last, sh_e_parts);
+    if (k_begin > 0) share_of(r_begin, sh_b_first, sh_b_last, sh_b_parts);
+    if (k_end > 0) share_of(r_end, sh_e_first, sh_e_last, sh_e_parts);
 
     // The loop below exists twice, once per role (`POOL`): a wave never changes its role, and inside ONE loop the registers of
     // both roles would be live at once.  Both copies take the same steps, hence the same barriers.
@@ -660,7 +681,6 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         f32x16 acc[4];
         Frag3 wq[4]; // (lo2: the three-piece variant only)
         float bc[kMaxScales];
-        bool tile_open = false; // an earlier group of this workgroup left the tile's running sum in the workspace
         if constexpr (!POOL) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -678,26 +698,30 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         LaneBox boxA, boxB;
         bool globA = false, globB = false, liveA = false, liveB = false;
 
-        // A phase record (LDS, written by wave 0): tile, the views of the group, w = scale | layer << 2 | nj << 15 | more << 20
+        // A phase record (LDS, written by the table wave): the run, the sub-tiles of the group (vfa_pipe_seq.h: sub_byte -- view and tile
+        // offset inside the run, one byte each), w = scale | layer << 2 | nj << 15 | more << 20, the sliver shifts of the sub-tiles' (tile,
+        // scale) (one byte each)
         struct PhaseRec {
-            int tile; unsigned views, w, sh;
-            __device__ __forceinline__ bool valid() const { return tile >= 0; }
-            __device__ __forceinline__ int shift() const { return (int)sh; } // sliver shift of (tile, scale): fp16 form only, else 0
+            int run; unsigned subs, w, sh;
+            __device__ __forceinline__ bool valid() const { return run >= 0; }
+            __device__ __forceinline__ int shift(int j) const { return (int)((sh >> (8 * j)) & 0xffu); } // fp16 form only, else 0
             __device__ __forceinline__ int scale() const { return (int)(w & 3u); }
             __device__ __forceinline__ int layer() const { return (int)((w >> 2) & 1023u); }
             __device__ __forceinline__ int nj() const { return (int)((w >> 15) & 7u); }
-            __device__ __forceinline__ bool more() const { return (w >> 20) & 1u; }
-            __device__ __forceinline__ int view(int j) const { return (int)((views >> (8 * j)) & 0xffu); }
+            __device__ __forceinline__ bool more() const { return (w >> 20) & 1u; } // another group of this workgroup follows in the run
+            __device__ __forceinline__ int ci() const { return (int)((w >> 21) & 15u); } // contribution index of the head tile (vfa_pipe_seq.h)
+            __device__ __forceinline__ int view(int j) const { return sub_view(subs, j); }
+            __device__ __forceinline__ int tile(int j, int rt_) const { return run * rt_ + sub_tile_off(subs, j); }
         };
         auto phase_rec = [&](int n) {
             const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
             PhaseRec p;
-            p.tile = uniform_i((int)v.x); p.views = (unsigned)uniform_i((int)v.y); p.w = (unsigned)uniform_i((int)v.z);
+            p.run = uniform_i((int)v.x); p.subs = (unsigned)uniform_i((int)v.y); p.w = (unsigned)uniform_i((int)v.z);
             p.sh = F16 ? (unsigned)uniform_i((int)v.w) : 0u;
             return p;
         };
         // output rows of a tile: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h of the 32 x 32 block, column r
-        auto write_tile = [&](int tile, const f32x16 &v, bool have) {
+        auto write_tile = [&](int tile, const f32x16 &v, bool have) __attribute__((always_inline)) {
             if (DIAG && (a.debug & kDbgDumpVox)) return; // (the output buffer holds the dumped voxel features)
             const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w;
             float extra = 0.0f; // fully masked (view, scale) of this tile: vox = 0 -> relu(bias)
@@ -719,7 +743,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 }
             }
         };
-        auto empty_tiles = [&](int t0, int t1) { // tiles without a group inside this workgroup's range
+        auto empty_tiles = [&](int t0, int t1) __attribute__((always_inline)) { // tiles without a group inside this workgroup's range
             if constexpr (!POOL) {
                 for (int t2 = t0; t2 < t1; ++t2) write_tile(t2, acc[0], false);
             }
@@ -729,6 +753,9 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         int dbg_pos = 0; // position of the current step in its phase (i & 7)
         auto tick = [&](int k) {
             if (DIAG) {
+                // (stamps only where they are asked for: a stamp is an s_memtime round trip, seven per step -- the ablation masks without
+                // 0x80 then time the kernel, not the clock reads: until round 6 they carried ~450 us of them on the five-layer MultiviewC frame)
+                if (!(a.debug & 0x80)) return;
                 if (a.debug & 32) { // (diagnostic 32: only the wait at the step barrier, by position of the step in its phase)
                     if (k == 5) t_prev = __builtin_amdgcn_s_memtime();
                     else if (k == 6) {
@@ -756,19 +783,27 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // steps of every phase, and every wave waits for wave 0 at the barrier.  Now lane = tile: 64 tiles of the workgroup's range
         // at a time are expanded into a ring of group records in LDS (view masks by vector loads, a lane scan for the positions,
         // the cut at both ends of the range by rank); a phase is then a counter and one LDS read.
-        int gen_t = t_begin, gen_filled = 0, gen_next = 0, gen_layer = 0; // next tile to expand; groups written / handed out; layer
-        const int gen_t_lim = k_end > 0 ? t_end + 1 : t_end;
-        auto fill_groups = [&]() { // (table wave, all lanes)
+        int gen_t = r_begin, gen_filled = 0, gen_next = 0, gen_layer = 0; // next RUN to expand; groups written / handed out; layer
+        const int gen_t_lim = k_end > 0 ? r_end + 1 : r_end;
+        auto fill_groups = [&]() { // (table wave, all lanes; lane = run)
             const int t = gen_t + lane;
             const bool on = t < gen_t_lim;
-            const unsigned m0 = on ? (a.sc[0].live[t] & view_mask) : 0u;
-            const unsigned m1 = (on && a.n_scales > 1) ? (a.sc[1].live[t] & view_mask) : 0u;
-            const unsigned m2 = (on && a.n_scales > 2) ? (a.sc[2].live[t] & view_mask) : 0u;
-            const unsigned sh0 = (F16 && on) ? a.sc[0].shift[t] : 0u, sh1 = (F16 && on && a.n_scales > 1) ? a.sc[1].shift[t] : 0u,
-                           sh2 = (F16 && on && a.n_scales > 2) ? a.sc[2].shift[t] : 0u; // (fp16 split: the sliver shift of (tile, scale))
-            const int gt = groups_of(m0) + groups_of(m1) + groups_of(m2);
-            const int lo = t == t_begin ? k_begin : 0;
-            const int hi = min(t == t_end ? k_end : gt, gt);
+            const int base_tile = t * rt;
+            // live-view mask of (scale s2, tile `off` of the lane's run): vector loads (L2 hits: the geometry pass wrote them)
+            auto mask_of = [&](int s2, int off) -> unsigned {
+                const unsigned *lv = s2 == 0 ? a.sc[0].live : (s2 == 1 ? a.sc[1].live : a.sc[2].live);
+                return (on && base_tile + off < a.n_tiles) ? (lv[base_tile + off] & view_mask) : 0u;
+            };
+            int gt = 0; // groups of the run: per scale, its live sub-tiles in fours
+#pragma unroll 1
+            for (int s2 = 0; s2 < a.n_scales; ++s2) {
+                int cnt_s = 0;
+#pragma unroll 1
+                for (int off = 0; off < rt; ++off) cnt_s += __popc(mask_of(s2, off));
+                gt += groups_of_count(cnt_s);
+            }
+            const int lo = t == r_begin ? k_begin : 0;
+            const int hi = min(t == r_end ? k_end : gt, gt);
             const int cnt = on ? max(hi - lo, 0) : 0;
             int incl = cnt;
 #pragma unroll
@@ -781,26 +816,18 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const int tiles_taken = __popcll(__ballot(take)); // (a prefix of the lanes: incl does not decrease)
             const int groups_taken = tiles_taken > 0 ? __shfl(incl, tiles_taken - 1) : 0;
             if (take && cnt > 0) {
-                int r = 0;
                 const int base = gen_filled + incl - cnt - lo;
-#pragma unroll
-                for (int s2 = 0; s2 < kMaxScales; ++s2) {
-                    unsigned rest = s2 == 0 ? m0 : (s2 == 1 ? m1 : m2);
-                    while (rest) {
-                        unsigned views = 0;
-                        int nj = 0;
-                        for (; nj < kGroupViews && rest; ++nj) {
-                            views |= (unsigned)__builtin_ctz(rest) << (8 * nj);
-                            rest &= rest - 1u;
+                walk_groups(a.n_scales, rt, lo, mask_of, [&](int r, int s2, unsigned subs, int nj, int ci) {
+                    if (r >= lo && r < hi) {
+                        unsigned shifts = 0u; // (fp16 split: the sliver shift of every sub-tile's (tile, scale))
+                        if constexpr (F16) {
+                            const unsigned *shp = s2 == 0 ? a.sc[0].shift : (s2 == 1 ? a.sc[1].shift : a.sc[2].shift);
+                            for (int j = 0; j < nj; ++j) shifts |= (shp[base_tile + sub_tile_off(subs, j)] & 0xffu) << (8 * j);
                         }
-                        if (r >= lo && r < hi) {
-                            const unsigned w = (unsigned)s2 | ((unsigned)nj << 15) | (r + 1 < hi ? 1u << 20 : 0u);
-                            *reinterpret_cast<uint4 *>(&s_groups[(base + r) & (kGroupRing - 1)][0]) =
-                                make_uint4((unsigned)t, views, w, s2 == 0 ? sh0 : (s2 == 1 ? sh1 : sh2));
-                        }
-                        ++r;
+                        const unsigned w = (unsigned)s2 | ((unsigned)nj << 15) | (r + 1 < hi ? 1u << 20 : 0u) | ((unsigned)ci << 21);
+                        *reinterpret_cast<uint4 *>(&s_groups[(base + r) & (kGroupRing - 1)][0]) = make_uint4((unsigned)t, subs, w, shifts);
                     }
-                }
+                });
             }
             gen_filled += uniform_i(groups_taken);
             gen_t += uniform_i(tiles_taken);
@@ -809,7 +836,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         auto gen_phase = [&](int n) { // (table wave)
-            while (gen_layer == 0 && gen_next == gen_filled && gen_t < gen_t_lim) fill_groups(); // (tiles without a live view add none)
+            // (cold: the register allocator must spill INSIDE the expansion, not take a box of the pooling loops out of its registers)
+            while (__builtin_expect(gen_layer == 0 && gen_next == gen_filled && gen_t < gen_t_lim, 0)) fill_groups(); // (runs without a live view add none)
             const uint4 g = *reinterpret_cast<const uint4 *>(&s_groups[gen_next & (kGroupRing - 1)][0]);
             const bool end = uniform_i((int)g.x) < 0;
             {
@@ -822,10 +850,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         auto hdr_dma = [&](int n) { // (wave 0) the headers of the sub-tiles of phase n: 8 lanes each, per-lane addresses
             const uint4 v = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][0]);
             if (uniform_i((int)v.x) < 0) return;
-            const int tile = (int)v.x, layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
+            const int layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
             int j = lane >> 3;
             j = j < nj ? j : nj - 1;
-            const int view = (int)((v.y >> (8 * j)) & 0xffu);
+            const int view = sub_view(v.y, j), tile = (int)v.x * rt + sub_tile_off(v.y, j);
             const uint4 c1 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][8]), c2 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][12]);
             const unsigned long long item = (unsigned long long)((unsigned)tile * c2.z + (unsigned)layer * c2.w + (unsigned)view);
             const unsigned long long p = ((unsigned long long)c1.w << 32 | c1.z) + item * kHdrBytes + (unsigned)(lane & 7) * 4u;
@@ -840,16 +868,17 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             const uint4 c0 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][4]), c1 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][8]),
                         c2 = *reinterpret_cast<const uint4 *>(&s_phase[n & 3][12]);
             if (uniform_i((int)v.x) < 0) return;
-            const int tile = (int)v.x, layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
+            const int layer = (int)((v.z >> 2) & 1023u), nj = (int)((v.z >> 15) & 7u);
             const int jj = j < nj ? j : 0;
+            const int tile = (int)v.x * rt + sub_tile_off(v.y, jj);
             // (the header read stays BEHIND the validity branch and indexed by jj: reading slot j in front of it -- one round trip
             // less -- ended in memory faults on full-size frames in the optimised build only; not understood, not used)
             const uint2 hd = *reinterpret_cast<const uint2 *>(&s_hdr[n & 3][jj * 8]);
-            const int view = (int)((v.y >> (8 * jj)) & 0xffu);
+            const int view = sub_view(v.y, jj);
             const unsigned flags = hd.x, n_slots = hd.y;
             const int Hf = (int)c2.x, Wf = (int)(c2.y & 0xffffu);
             // (fp16 form: the exponent of the phase's voxel-feature factor 2^(ea - shift), + 128, in the upper half)
-            const unsigned ea64 = (c2.y & 0xffff0000u) - (F16 ? v.w << 16 : 0u);
+            const unsigned ea64 = (c2.y & 0xffff0000u) - (F16 ? ((v.w >> (8 * jj)) & 0xffu) << 16 : 0u); // (the shift of the sub-tile's (tile, scale))
             const unsigned long long item = (unsigned long long)((unsigned)tile * c2.z + (unsigned)layer * c2.w + (unsigned)view);
             const unsigned long long img = ((unsigned long long)c0.y << 32 | c0.x) +
                                            (unsigned long long)view * (unsigned)((Hf + 2) * (Wf + 2)) * kSlotBytes + (unsigned)(q * kQSlot);
@@ -880,7 +909,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                                  (__attribute__((address_space(3))) void *)((DSET ? s_rec1 : s_rec0) + x * kTileBoxes * kRecBytes + wq4 * 1024), 16, 0, 0);
             }
-            if ((fw & kTileDirect) || (DIAG && (a.debug & 1))) return; // (diagnostic 1: no window fills; the records still come)
+            if ((fw & kTileDirect) || ((kAblate & 1) || (DIAG && (a.debug & 1)))) return; // (diagnostic 1: no window fills; the records still come)
             const int n_slots = fw >> 8;
             const int cw = (int)h0.z, inv = (int)h0.w, x0 = (int)h1.x, t0 = (int)h1.y, top = (int)h1.z, b0 = (int)h1.w;
             const int n_fill = (n_slots + 3) >> 2;
@@ -935,16 +964,18 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 // The bias rides in the accumulator: at the first step of a group both accumulators of the set restart from it.  A
                 // SELECT (on the first quarter of every layer), not an assignment under `grp_first`: the assignment made the
                 // allocator keep the old and the new accumulators in different registers and copy all 32 at the join.
-                const float b0 = (ph.scale() == 0 ? bc[0] : (ph.scale() == 1 ? bc[1] : bc[2])) * pow2f(-ph.shift()); // (in the group's units)
+                const float bsc = ph.scale() == 0 ? bc[0] : (ph.scale() == 1 ? bc[1] : bc[2]);
+                // (in each sub-tile's units: the sub-tiles of a group may sit in different tiles, with different sliver shifts)
+                const float b0 = bsc * pow2f(-ph.shift(2 * SET)), b1 = bsc * pow2f(-ph.shift(2 * SET + 1));
                 int first = grp_first ? 1 : 0;
                 asm volatile("" : "+v"(first)); // (opaque: keeps the compiler from turning the selects back into that assignment)
-                f32x16 bv;
+                f32x16 bv0, bv1;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) bv[i] = b0;
-                acc[2 * SET] = first ? bv : acc[2 * SET];
-                acc[2 * SET + 1] = first ? bv : acc[2 * SET + 1];
+                for (int i = 0; i < 16; ++i) { bv0[i] = b0; bv1[i] = b1; }
+                acc[2 * SET] = first ? bv0 : acc[2 * SET];
+                acc[2 * SET + 1] = first ? bv1 : acc[2 * SET + 1];
             }
-            const bool work = 2 * SET < ph.nj() && !(DIAG && (a.debug & 4)); // (set 1 of a group of one or two views is empty)
+            const bool work = 2 * SET < ph.nj() && !((kAblate & 4) || (DIAG && (a.debug & 4))); // (set 1 of a group of one or two views is empty)
             // A fragments: lane (r, h) of row block rb reads chunk 2 ks + h, row 32 rb + r (read_frags)
             const unsigned pa = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)s_planes +
                                 (unsigned)(par * kPieces * kPlaneBytes + h * kChunkStride + r * 16);
@@ -1025,62 +1056,76 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 for (int ks = 0; ks < 4; ++ks) w_load(ks);
             }
         };
-        // A group ends: relu and the view sum, vfa_op.py:124; vfanet.py:79, 82.  The tile's running sum lives in the WORKSPACE between
-        // the groups (slot 2 of the workgroup: written and read back by the same lane) -- sixteen registers for the whole kernel do
-        // not fit at four waves per SIMD.  No exposed round trip: in front of the group's LAST step (set 1 of the last quarter;
-        // the accumulators of set 0 are complete) r0 + r1 moves into acc[0] and the running sum is requested into the registers of
-        // acc[1]; behind the step, tile = s + (((r0 + r1) + r2) + r3), views in index order inside the group.
-        auto group_begin = [&](const PhaseRec &ph) {
-            const float *slot = a.partial + (((size_t)lb * 3 + 2) * 8 + wave) * 16 * 64 + lane;
-            const bool two = ph.nj() > 1;
-            if constexpr (SMALL) { // (the last step still adds to acc[0], acc[1]: the running sum waits in the unused registers of set 1)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[2][i] = slot[i * 64];
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float r0 = relu_t(acc[0][i]), r1 = relu_t(acc[1][i]);
-                acc[0][i] = two ? r0 + r1 : r0;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[1][i] = slot[i * 64]; // (always: what an unopened tile's slot holds is never used)
+        // A group ends: relu and the view sum, vfa_op.py:124; vfanet.py:79, 82.  The sub-tiles of a group may belong to different tiles of
+        // the run, and a tile gets contributions from several groups (its views may straddle two or three groups; its three scales are
+        // three separate passes over the run).  The sub-tiles of ONE tile inside the group are added in registers, views in index order
+        // (sub-tiles 0, 1 in front of the group's last step -- set 1 of the last quarter; set 0 is complete --, 2, 3 behind it), and the
+        // result times 2^-(ea+ew-shift) is STORED as one contribution to a buffer of the workgroup's own, [tile of the run][scale][index]
+        // (vfa_pipe_seq.h: walk_groups hands out the index): plain stores, nothing to wait for.  finish_run adds the contributions of a
+        // tile in (scale, index) order.  (First attempt of round 6: running sums in the workspace, every sub-tile added with no-return
+        // float atomics -- 134 M atomic dwords per five-layer MultiviewC frame at the L2's one atomic per clock and channel: 375 us of a
+        // 1 690 us launch.)
+        unsigned long long cmask = 0ull; // contributions stored per (tile of the run, scale): 4 bits each, index (off * kMaxScales + s)
+        // The lane's offset inside a 32-row x 256-column buffer of the workspace, formed AT the use: written as `lane` the compiler hoists
+        // these per-lane addresses out of the step loop, keeps them in vector registers across it and spills something else -- the
+        // address of the weight slice, reloaded from scratch inside every k-step behind a vmcnt(0) that also waits for the slice
+        // loads in flight: +1 000 cycles per step in the matrix waves (stamps of the diagnostic build, round 6).
+        auto lane_off = [&]() __attribute__((always_inline)) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            return wave * 16 * 64 + ln;
         };
-        auto group_end = [&](const PhaseRec &ph) {
-            float *slot = a.partial + (((size_t)lb * 3 + 2) * 8 + wave) * 16 * 64 + lane;
-            const bool three = ph.nj() > 2, four = ph.nj() > 3, more = ph.more(), open = tile_open;
-            const float inv = inv_of(ph.scale()) * pow2f(ph.shift()); // 2^-(ea + ew - shift): back to the map's units
-            if constexpr (SMALL) { // tile = s + (r0 + r1): the association of the eight-step form for a group of one or two views
-                const bool two = ph.nj() > 1;
+        auto store_seg = [&](const f32x16 &seg, float inv, int off, int sc, int ci) __attribute__((always_inline)) {
+            if (kAblate & 256) return;
+            float *bp = a.slots + ((((size_t)lb * kRunTiles + off) * kMaxScales + sc) * a.n_contrib + ci) * (8 * 16 * 64) + lane_off();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bp[i * 64] = F16 ? seg[i] * inv : seg[i];
+            const int sh = (off * kMaxScales + sc) * 4;
+            cmask = (cmask & ~(15ull << sh)) | ((unsigned long long)(ci + 1) << sh);
+        };
+        auto relu16 = [&](f32x16 &v) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = relu_t(v[i]);
+        };
+        auto add16 = [&](f32x16 &v, const f32x16 &w) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] += w[i];
+        };
+        // 2^-(ea + ew - shift) of sub-tile j: back to the map's units (exact)
+        auto inv_sub = [&](const PhaseRec &ph, int j) __attribute__((always_inline)) { return F16 ? inv_of(ph.scale()) * pow2f(ph.shift(j)) : 1.0f; };
+        // Straight-line on purpose: one segment (= the sub-tiles of one tile) at a time, summed into ONE temporary from the untouched
+        // accumulators with uniform selects (x + 0 = x), stored, forgotten.  A version that summed in place under uniform branches
+        // (the head tile's sum carried from the first pair to the second) left the compiler with sixteen-register values merging
+        // at every join: it spilled whole accumulators and reloaded all sixteen registers once per element stored.
+        auto group_finish = [&](const PhaseRec &ph) __attribute__((always_inline)) {
+            const int nj = ph.nj(), sc = ph.scale();
+            const int o0 = sub_tile_off(ph.subs, 0), o1 = sub_tile_off(ph.subs, 1), o2 = sub_tile_off(ph.subs, 2), o3 = sub_tile_off(ph.subs, 3);
+            relu16(acc[0]);
+            if (nj >= 2) relu16(acc[1]);
+            if (nj >= 3) relu16(acc[2]);
+            if (nj >= 4) relu16(acc[3]);
+            // seg = first + [c1] a + [c2] b + [c3] c, views in index order
+            auto segment = [&](const f32x16 &first, bool c1, const f32x16 &x1, bool c2, const f32x16 &x2, bool c3, const f32x16 &x3, float inv, int off, int ci)
+                               __attribute__((always_inline)) {
+                f32x16 seg;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float r0 = relu_t(acc[0][i]), r1 = relu_t(acc[1][i]);
-                    const float g = two ? r0 + r1 : r0;
-                    const float s0 = open ? acc[2][i] : 0.0f;
-                    if constexpr (F16) acc[0][i] = fmaf(g, inv, s0);
-                    else acc[0][i] = s0 + g;
+                    float v = first[i];
+                    v += c1 ? x1[i] : 0.0f;
+                    v += c2 ? x2[i] : 0.0f;
+                    v += c3 ? x3[i] : 0.0f;
+                    seg[i] = v;
                 }
-                if (more) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) slot[i * 64] = acc[0][i];
-                }
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float g = acc[0][i];
-                const float r2 = relu_t(acc[2][i]), r3 = relu_t(acc[3][i]);
-                g = three ? g + r2 : g;
-                g = four ? g + r3 : g;
-                const float s0 = open ? acc[1][i] : 0.0f;
-                if constexpr (F16) acc[0][i] = fmaf(g, inv, s0); // (g 2^-(ea+ew) is exact: the same bits as multiply, then add)
-                else acc[0][i] = s0 + g;
-            }
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) slot[i * 64] = acc[0][i];
-            }
+                store_seg(seg, inv, off, sc, ci);
+            };
+            const bool h1 = nj >= 2, h2 = nj >= 3, h3 = nj >= 4;
+            segment(acc[0], h1 && o1 == o0, acc[1], h2 && o2 == o0, acc[2], h3 && o3 == o0, acc[3], inv_sub(ph, 0), o0, ph.ci());
+            if (h1 && o1 != o0) segment(acc[1], h2 && o2 == o1, acc[2], h3 && o3 == o1, acc[3], false, acc[3], inv_sub(ph, 1), o1, 0);
+            if (h2 && o2 != o1) segment(acc[2], h3 && o3 == o2, acc[3], false, acc[3], false, acc[3], inv_sub(ph, 2), o2, 0);
+            if (h3 && o3 != o2) segment(acc[3], false, acc[3], false, acc[3], false, acc[3], inv_sub(ph, 3), o3, 0);
         };
+        auto group_begin = [&](const PhaseRec &) __attribute__((always_inline)) {}; // (twelve-wave layout: everything behind the last step)
+        auto group_end = [&](const PhaseRec &ph) __attribute__((always_inline)) { group_finish(ph); };
 
         // ---------------------------------------------------------------- pooling of one step (pooling waves)
         // returns false when none of the wave's 16 boxes has anything to pool (all masked, none NaN): the wave then writes zeros
@@ -1186,11 +1231,11 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 v = make_float4(v.x - lb2.x, v.y - lb2.y, v.z - lb2.z, v.w - lb2.w);
                 const float xs[4] = {box_quotient_scaled(v.x, bx.asc, bx.scl), box_quotient_scaled(v.y, bx.asc, bx.scl),
                                      box_quotient_scaled(v.z, bx.asc, bx.scl), box_quotient_scaled(v.w, bx.asc, bx.scl)};
-                if (DIAG && (a.debug & kDbgDumpVox)) { // (one view: sub-tile 0 of set 0; the power-of-two factor of the fp16 split taken out again: exact)
+                if (DIAG && (a.debug & kDbgDumpVox)) { // (one view, one scale, one layer: every sub-tile is a tile of its own; the power-of-two factor of the fp16 split taken out again: exact)
                     const int tl = tile / a.tiles_w, tw = tile - tl * a.tiles_w, brow = phalf * 16 + pb;
                     const int cl = tl * kTileL + (brow >> 3), cw = tw * kTileW + (brow & 7);
                     const float back = bx.back;
-                    if (x == 0 && cl < a.L && cw < a.W)
+                    if (cl < a.L && cw < a.W)
                         *reinterpret_cast<float4 *>(a.out + (size_t)(cl * a.W + cw) * kC + quarter_of(k) * 64 + (int)piece * 16 + pi * 4) =
                             make_float4(xs[0] * back, xs[1] * back, xs[2] * back, xs[3] * back);
                 }
@@ -1218,10 +1263,12 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // A set with ONE sub-tile (set 0 of a one-view group, set 1 of a three-view group: one step in five on a seven-camera rig): the
         // waves that would pool the missing sub-tile take half of the pieces of the one there is -- wave (px, phalf, mpar) pools boxes
         // phalf of sub-tile 0, piece mpar + 2 px --, so the step's pooling takes half the time instead of leaving four waves idle.
-        auto pool_step = [&](auto set_tag, int i, int tile, int nj) {
+        auto pool_step = [&](auto set_tag, int i, const PhaseRec &ph) {
             constexpr int SET = SMALL ? 0 : decltype(set_tag)::value; // (the tag is the parity of i)
+            const int nj = ph.nj();
             const bool single = W16 && nj == 2 * SET + 1;
             const int n = i >> kPSh, k = i & (kPS - 1), x = single ? 0 : px;
+            const int tile = DIAG ? ph.tile(2 * SET + x, rt) : 0; // (the diagnostic dump of the voxel features addresses by cell)
             const int m_first = single ? mpar + 2 * px : mpar, m_count = single ? 1 : mcount;
             auto one = [&](LaneBox &bx, bool &glob, bool &live) { // (called with the registers of the step's set)
                 if (quarter_of(k) == 0) { // first quarter of the layer: this wave's 16 boxes for the whole layer
@@ -1244,7 +1291,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     }
                     return;
                 }
-                if (DIAG && (a.debug & 2)) return;
+                if ((kAblate & 2) || (DIAG && (a.debug & 2))) return;
                 if (glob) pool(std::true_type{}, bx, i, x, tile, m_first, m_count);
                 else pool(std::false_type{}, bx, i, x, tile, m_first, m_count);
             };
@@ -1252,63 +1299,150 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             else one(boxB, globB, liveB);
         };
 
-        // ---------------------------------------------------------------- a workgroup's part of a tile is complete
-        auto finish_tile = [&](int tile, int next_tile, const f32x16 &sum) {
-            if (__builtin_expect(!shared_tile(tile), 1)) {
-                if constexpr (!POOL) write_tile(tile, sum, true);
-            } else {
-                // Whoever arrives LAST adds the parts (in workgroup order: one fixed association) and stores the tile; the
-                // others leave their sums in the workspace and go on.  sc1 stores and loads on both sides, every storing wave
-                // drained, then one ticket per workgroup (guide: inter-workgroup visibility, valid forms).  The ticket is an
-                // acquire-release operation at agent scope: the memory model then orders the parts of every earlier arriver in
-                // front of the last arriver's loads (the sc1 forms alone rest on how gfx950 happens to treat them); it runs at most
-                // twice per workgroup and launch.
-                const int which = (tile == t_begin && k_begin > 0) ? 0 : 1;
-                if constexpr (!POOL) {
-                    float *pp = a.partial + (((size_t)lb * 3 + which) * 8 + wave) * 16 * 64 + lane;
+        // ---------------------------------------------------------------- a workgroup's part of a run is complete
+        // Matrix waves: the sum of every tile of the run from its contributions, (scale, index) order, three loads in flight (acc[1..3]
+        // are free between groups).  sc1 loads: the buffers are reused run after run, a plain load could hit a line of the CU's vector
+        // cache from the run before.  A run nobody else holds groups of is written straight to the map; of a SHARED run every tile's sum
+        // goes to the workspace and whoever arrives LAST adds the parts (in workgroup order: one fixed association) and stores the
+        // tiles; the others go on.  sc1 stores and loads on both sides, every storing wave drained, then one ticket per workgroup
+        // (guide: inter-workgroup visibility, valid forms).  The ticket is an acquire-release operation at agent scope: the memory model
+        // then orders the parts of every earlier arriver in front of the last arriver's loads (the sc1 forms alone rest on how gfx950
+        // happens to treat them); it runs at most twice per workgroup and launch.
+        auto finish_run = [&](int run, int next_tile) __attribute__((always_inline)) {
+            const int base = run * rt;
+            if (kAblate & 512) { cmask = 0ull; return; }
+            const bool shared = shared_run(run);
+            const int which = (run == r_begin && k_begin > 0) ? 0 : 1;
+            auto load16 = [&](f32x16 &v, const float *p) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) __hip_atomic_store(pp + i * 64, sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int i = 0; i < 16; ++i) v[i] = __hip_atomic_load(p + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            // a finished tile: to the map (nobody else holds groups of the run) or to this workgroup's part of a shared run
+            auto emit_tile = [&](int off) __attribute__((always_inline)) {
+                if (!shared) write_tile(base + off, acc[0], true);
+                else {
+                    float *pp = a.partial + (((size_t)lb * 2 + which) * kRunTiles + off) * (8 * 16 * 64) + lane_off();
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) __hip_atomic_store(pp + i * 64, acc[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                __builtin_amdgcn_s_barrier();
-                // the workgroups that hold groups of this tile (found once, in front of the loop: share_of)
-                const int first = tile == t_begin && k_begin > 0 ? sh_b_first : sh_e_first;
-                const int last = tile == t_begin && k_begin > 0 ? sh_b_last : sh_e_last;
-                const int parts = tile == t_begin && k_begin > 0 ? sh_b_parts : sh_e_parts;
-                if (tid == 0) {
-                    const unsigned old = __hip_atomic_fetch_add(a.tickets + tile, 1u, VFA_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
-                    s_misc[0] = old;
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                const bool am_last = uniform_i((int)s_misc[0]) == parts - 1;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+            };
+            if constexpr (!POOL) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores of the last group
+                // The contributions of the run as ONE flat sequence (tile, scale, index ascending), three loads in flight all the way
+                // (a batch per (tile, scale) was twelve exposed round trips per run: 85 us per finish on the five-layer MultiviewC frame)
+                const int n_off = min(rt, a.n_tiles - base);
+                auto cnt_of = [&](int off, int sc) { return (int)((cmask >> ((off * kMaxScales + sc) * 4)) & 15ull); };
+                auto seek = [&](int &off, int &sc, int &ci) { // the next contribution at or behind (off, sc, ci); off == n_off: none
+                    while (off < n_off) {
+                        if (ci < cnt_of(off, sc)) return;
+                        ci = 0;
+                        if (++sc == a.n_scales) { sc = 0; ++off; }
+                    }
+                };
+                int p_off = 0, p_sc = 0, p_ci = 0, c_off = 0, c_sc = 0, c_ci = 0, cur = 0;
+                auto issue = [&](f32x16 &buf) __attribute__((always_inline)) {
+                    seek(p_off, p_sc, p_ci);
+                    if (p_off >= n_off) return;
+                    load16(buf, a.slots + ((((size_t)lb * kRunTiles + p_off) * kMaxScales + p_sc) * a.n_contrib + p_ci) * (8 * 16 * 64) + lane_off());
+                    ++p_ci;
+                };
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+                issue(acc[1]); issue(acc[2]); issue(acc[3]);
+                bool going = true;
+                auto consume = [&](f32x16 &buf) __attribute__((always_inline)) {
+                    if (!going) return;
+                    seek(c_off, c_sc, c_ci);
+                    while (cur < min(c_off, n_off)) { emit_tile(cur); ++cur; } // every tile in front of the next contribution is complete
+                    if (c_off >= n_off) { going = false; return; }
+                    add16(acc[0], buf);
+                    ++c_ci;
+                    issue(buf);
+                };
+                while (going) { consume(acc[1]); consume(acc[2]); consume(acc[3]); }
+                cmask = 0ull;
+            }
+            if (__builtin_expect(shared, 0)) {
                 if constexpr (!POOL) {
+                    // Every matrix wave owns 32 columns of every tile from the first product to the store: the hand-off is PER WAVE -- its
+                    // part drained, then its own ticket (tickets[run][wave]) --, no barrier, and the pooling waves are not involved at all
+                    // (they go on pooling the next step).  Until round 6 the whole workgroup met at two barriers here.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // the workgroups that hold groups of this run (found once, in front of the loop: share_of)
+                    const int first = run == r_begin && k_begin > 0 ? sh_b_first : sh_e_first;
+                    const int last = run == r_begin && k_begin > 0 ? sh_b_last : sh_e_last;
+                    const int parts = run == r_begin && k_begin > 0 ? sh_b_parts : sh_e_parts;
+                    unsigned *ticket = a.tickets + (size_t)run * 8 + wave;
+                    unsigned old = 0u;
+                    if (lane == 0) old = __hip_atomic_fetch_add(ticket, 1u, VFA_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool am_last = uniform_i((int)old) == parts - 1;
                     if (am_last) {
                         // (nobody else touches this ticket in this launch: clear it for the next call on the same workspace)
-                        if (tid == 0) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        f32x16 tot;
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) tot[i] = 0.0f;
+                        if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // The workgroups that hold groups of the run, in workgroup order, found ONCE (their ranges are two dependent
+                        // loads each: inside the loop over the tiles that was 4 x parts x 2 round trips for whoever arrived last):
+                        // (j << 1 | which part of j) in ten bits each, twelve of them; more sharers (a frame of a handful of runs
+                        // on 256 workgroups) are looked up again tile by tile.
+                        unsigned long long plist0 = 0ull, plist1 = 0ull;
+                        int n_parts = 0;
+#pragma unroll 1
                         for (int j = first; j <= last; ++j) {
-                            if (j == lb) {
-#pragma unroll
-                                for (int i = 0; i < 16; ++i) tot[i] += sum[i];
-                                continue;
-                            }
                             int tb, kb, te, ke;
                             range_of(j, tb, kb, te, ke);
                             if (tb > te || (tb == te && kb >= ke)) continue;
-                            const int wj = (tile == tb && kb > 0) ? 0 : 1;
-                            const float *pp = a.partial + (((size_t)j * 3 + wj) * 8 + wave) * 16 * 64 + lane;
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) tot[i] += __hip_atomic_load(pp + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long e = ((unsigned long long)j << 1) | ((run == tb && kb > 0) ? 0ull : 1ull);
+                            if (n_parts < 6) plist0 |= e << (10 * n_parts);
+                            else if (n_parts < 12) plist1 |= e << (10 * (n_parts - 6));
+                            ++n_parts;
                         }
-                        write_tile(tile, tot, true);
+#pragma unroll 1
+                        for (int off = 0; off < rt; ++off) {
+                            if (base + off >= a.n_tiles) break;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+                            // (this workgroup's own part comes back from the workspace like the others'; three parts per round trip)
+                            int k = 0, jslow = first;
+                            auto next_part = [&]() -> const float * {
+                                int j, wj;
+                                if (n_parts <= 12) {
+                                    if (k >= n_parts) return nullptr;
+                                    const unsigned e = (unsigned)((k < 6 ? plist0 >> (10 * k) : plist1 >> (10 * (k - 6))) & 1023ull);
+                                    ++k;
+                                    j = (int)(e >> 1); wj = (int)(e & 1u);
+                                } else {
+                                    for (;; ++jslow) {
+                                        if (jslow > last) return nullptr;
+                                        int tb, kb, te, ke;
+                                        range_of(jslow, tb, kb, te, ke);
+                                        if (tb > te || (tb == te && kb >= ke)) continue;
+                                        j = jslow++; wj = (run == tb && kb > 0) ? 0 : 1;
+                                        break;
+                                    }
+                                }
+                                return a.partial + (((size_t)j * 2 + wj) * kRunTiles + off) * (8 * 16 * 64) + lane_off();
+                            };
+#pragma unroll 1
+                            for (;;) {
+                                const float *q1 = next_part(), *q2 = next_part(), *q3 = next_part();
+                                if (!q1) break;
+                                load16(acc[1], q1);
+                                if (q2) load16(acc[2], q2);
+                                if (q3) load16(acc[3], q3);
+                                add16(acc[0], acc[1]);
+                                if (q2) add16(acc[0], acc[2]);
+                                if (q3) add16(acc[0], acc[3]);
+                                if (!q3) break;
+                            }
+                            write_tile(base + off, acc[0], true);
+                        }
                     }
                 }
             }
-            empty_tiles(tile + 1, next_tile);
+            empty_tiles(min(base + rt, a.n_tiles), next_tile);
         };
+        const int end_tile = min(r_end * rt, a.n_tiles); // the first tile behind this workgroup's whole runs
 
         // ---------------------------------------------------------------- the loop
         auto lds_fence_barrier = [&]() {
@@ -1322,7 +1456,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         }
         lds_fence_barrier();
         PhaseRec rec = phase_rec(0); // matrix waves: the phase of the step being multiplied; pooling waves: of the step being pooled
-        empty_tiles(k_begin == 0 ? t_begin : t_begin + 1, rec.valid() ? rec.tile : t_end);
+        empty_tiles(min((k_begin == 0 ? r_begin : r_begin + 1) * rt, a.n_tiles), rec.valid() ? rec.run * rt : end_tile);
         if (!rec.valid()) return;
         if (table_wave) hdr_dma(0);
         if (W16 && table_wave) { // (sixteen waves: the tables run a phase further ahead, see `body`)
@@ -1352,7 +1486,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             if constexpr (POOL) {
                 if (m == 0 && i > 0) rec = phase_rec(i >> kPSh);
                 // the next step's windows (and records) first, so that they land under this step's pooling
-                const bool bare = DIAG && (a.debug & 64); // (diagnostic 64: the loop, the tables and the barrier only)
+                const bool bare = (kAblate & 64) || (DIAG && (a.debug & 64)); // (diagnostic 64: the loop, the tables and the barrier only)
                 // The tables of the next phase (see `tables and DMA`: steps 4, 5, 6 of this one), FIRST in the step: make_desc reads
                 // the header buffer, a DMA target -- behind this step's window requests the compiler drains them in front of that
                 // read, and the table wave was 3 000-4 500 cycles late at every sixth step.
@@ -1369,7 +1503,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 }
                 if (W16 && table_wave && m == 2) hdr_dma((i >> kPSh) + 2); // (first too: its 256 bytes land under the pooling)
                 if (!dma_matrix && (live & 4u) && !bare) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
-                if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i, rec.tile, rec.nj());
+                if ((live & 2u) && !bare) pool_step(std::integral_constant<int, PSET>{}, i, rec);
                 // The tables (see `tables and DMA`), a phase further ahead than on twelve waves and behind the pooling: the descriptors
                 // of phase n + 1 (~1 000 cycles; its headers were requested a phase ago) in the FIRST step of phase n, where the
                 // matrix waves end a group (relu, view sum, tile store) and the pooling waves wait longest at the barrier; the record
@@ -1399,7 +1533,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 if (!W16 && dma_first && (live & 4u)) step_dma(std::integral_constant<int, PSET ^ 1>{}, i + 1);
                 // (step i - 1 ends its group: the last quarter of the last layer, set 1 -- `rec` is still that step's phase)
                 const bool group_ends = MSET == 1 && ((i - 1) & 7) == 7 && (live & 1u) && rec.layer() == a.nl - 1;
-                if ((live & 1u) && !(DIAG && (a.debug & 64))) {
+                if ((live & 1u) && !((kAblate & 64) || (DIAG && (a.debug & 64)))) {
                     if (MSET == 1 && group_ends) group_begin(rec);
                     // the slice of the next chunk: behind the k-steps of set 1 (steps i - 1 = set 1, i = set 0 of the next chunk), or,
                     // when set 1 of the group is empty, already behind set 0 (steps i - 1 = set 0, i = set 1, i + 1 = the next chunk)
@@ -1417,20 +1551,12 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             if constexpr (MSET == 1) { // (step i - 1 was the last of its phase's quarter 3?)
                 const PhaseRec &pr = rec; // matrix waves: the record of step i - 1; pooling waves hold the record of step i
                 if constexpr (POOL) {
-                    // the pooling waves only need to know whether the hand-off barriers of a SHARED tile are due
-                    if (__builtin_expect(((i - 1) & (kPS - 1)) == kPS - 1 && (live & 1u), 0)) {
-                        const PhaseRec prev = phase_rec((i - 1) >> kPSh);
-                        if (prev.layer() == a.nl - 1 && !prev.more()) {
-                            const PhaseRec nxt = phase_rec(((i - 1) >> kPSh) + 1);
-                            finish_tile(prev.tile, nxt.valid() ? nxt.tile : t_end, acc[0]);
-                        }
-                    }
+                    // (the pooling waves have no part in the end of a run: the matrix waves hand off wave by wave, finish_run)
                 } else {
                     if (__builtin_expect(((i - 1) & 7) == 7 && (live & 1u) && pr.layer() == a.nl - 1, 0)) {
-                        tile_open = pr.more();
                         if (!pr.more()) {
                             const PhaseRec nxt = phase_rec(((i - 1) >> 3) + 1);
-                            finish_tile(pr.tile, nxt.valid() ? nxt.tile : t_end, acc[0]);
+                            finish_run(pr.run, nxt.valid() ? nxt.run * rt : end_tile);
                         }
                     }
                 }
@@ -1464,9 +1590,15 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            // The steps of a GROUP are the inner loop; what follows a group -- relu, the tiles' contributions, and at the end of a run the
+            // tiles' sums and the hand-off -- sits BEHIND it, outside: inside the loop body the temporaries of that code spilled the
+            // loop's own values (25 scratch operations per phase in the matrix waves: +13 % on the five-layer MultiviewC frame).  The
+            // accumulators of a finished group are untouched until the next group's first product, and nothing here meets a barrier.
             int n = 0;
+            PhaseRec nx = rec;
+            for (bool done = false; !done;) {
+            bool group_ended = false;
             for (;;) {
-                PhaseRec nx = rec;
                 auto iter = [&](auto j_tag) {
                     constexpr int J = decltype(j_tag)::value, SET = SMALL ? 0 : J & 1, PAR = J & 1;
                     dbg_pos = (J + 1) & (kPS - 1);
@@ -1475,34 +1607,27 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     tick(1);
                     // (the tables of the next phase are the last pooling wave's job in this layout: `body`)
                     if constexpr (J == kPS - 2) nx = phase_rec(n + 1); // (written a phase ago)
-                    const bool group_ends = J == kPS - 1 && rec.layer() == a.nl - 1;
                     // the windows of step 8 n + J + 2 (the pooling waves are at 8 n + J + 1): the two matrix waves of a SIMD take
                     // their two jobs in opposite order (waves 0-3 request and then multiply, waves 4-7 multiply first)
-                    const bool dma_now = dma_matrix && (J < kPS - 2 || nx.valid()) && !(DIAG && (a.debug & 64));
+                    const bool dma_now = dma_matrix && (J < kPS - 2 || nx.valid()) && !((kAblate & 64) || (DIAG && (a.debug & 64)));
                     if (dma_now && wave < 4) step_dma(std::integral_constant<int, J & 1>{}, kPS * n + J + 2);
-                    if (!(DIAG && (a.debug & 64))) {
-                        if (J == kPS - 1 && group_ends) group_begin(rec);
+                    if (!((kAblate & 64) || (DIAG && (a.debug & 64)))) {
                         // the slice of the next chunk: behind the k-steps of set 1, or, when set 1 of the group is empty, already
                         // behind set 0; the chunk after quarter 3 is the next phase's first
                         bool next_chunk = false;
                         if (SMALL || SET == 1 || rec.nj() <= 2) {
                             const int jn = (SMALL || SET == 1) ? J + 1 : J + 2; // first step of the next chunk
                             if (jn < kPS) { w_set(rec.scale(), rec.layer(), quarter_of(jn)); next_chunk = true; }
-                            else if (nx.valid()) { w_set(nx.scale(), nx.layer(), 0); next_chunk = true; }
+                            // (not across the end of a GROUP: the code behind it needs the registers of the weight slice -- with the slice
+                            // of the next group in them the compiler spilled whole accumulators around the contributions' stores)
+                            else if (nx.valid() && rec.layer() != a.nl - 1) { w_set(nx.scale(), nx.layer(), 0); next_chunk = true; }
                         }
                         multiply(std::integral_constant<int, SET>{}, rec, J, PAR, next_chunk);
-                        if (J == kPS - 1 && group_ends) group_end(rec);
                     }
                     if (dma_now && wave >= 4) step_dma(std::integral_constant<int, J & 1>{}, kPS * n + J + 2);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (dma_matrix) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (what this wave requested has landed)
                     tick(4);
-                    if constexpr (J == kPS - 1) {
-                        if (__builtin_expect(group_ends, 0)) {
-                            tile_open = rec.more();
-                            if (!rec.more()) finish_tile(rec.tile, nx.valid() ? nx.tile : t_end, acc[0]);
-                        }
-                    }
                     tick(5);
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
@@ -1519,9 +1644,22 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     iter(std::integral_constant<int, 6>{});
                     iter(std::integral_constant<int, 7>{});
                 }
-                if (!nx.valid()) break;
+                group_ended = rec.layer() == a.nl - 1;
+                if (group_ended || !nx.valid()) break;
                 rec = nx;
                 ++n;
+            }
+            if (group_ended && nx.valid()) { // the first weight slice of the next group: requested here, it lands under the stores below
+                w_set(nx.scale(), nx.layer(), 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) w_load(ks);
+            }
+            if (group_ended && !((kAblate & 64) || (DIAG && (a.debug & 64)))) {
+                group_finish(rec);
+                if (!rec.more()) finish_run(rec.run, nx.valid() ? nx.run * rt : end_tile);
+            }
+            if (!nx.valid()) done = true;
+            else { rec = nx; ++n; }
             }
         } else {
         for (int i = 0;; i += 2) {
@@ -1618,10 +1756,26 @@ __global__ __launch_bounds__(kMaxBlocks) void pipe_balance_kernel(int *bal, cons
     }
 }
 
+// workgroups of a launch of the frame kernel: one per CU (less the reserved ones), a multiple of eight
+inline int pipe_blocks(int n_tiles, int reserved_cus)
+{
+    int n_cu = 256;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            cus > 0)
+            n_cu = cus;
+    }
+    if (reserved_cus > 0 && n_cu - reserved_cus >= 8) n_cu -= reserved_cus;
+    int nblk = n_tiles < n_cu ? n_tiles : n_cu;
+    nblk = (nblk + 7) / 8 * 8; // xcd_contiguous deals whole eighths; surplus workgroups find an empty range and leave
+    return nblk > kMaxBlocks ? kMaxBlocks : nblk;
+}
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PipeLayout {
-    size_t live[kMaxScales], shifts[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, costs, partial, diag, balance, wmax, wexp, amax, total;
+    size_t live[kMaxScales], shifts[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, costs, partial, slots, diag, balance, wmax, wexp, amax, total;
     int tiles_l, tiles_w, n_tiles;
 };
 inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
@@ -1639,8 +1793,8 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
         w.shifts[s] = off;
         off = align_up(off + (s < n_scales ? (size_t)w.n_tiles * 4 : 0), 256);
     }
-    w.tickets = off;
-    off = align_up(off + (size_t)w.n_tiles * 4, 256);
+    w.tickets = off; // (one per (run, matrix wave); sized for runs of one tile)
+    off = align_up(off + (size_t)w.n_tiles * 8 * 4, 256);
     w.globs = off;
     off = align_up(off + (size_t)w.n_tiles * 4, 256);
     w.masks_bytes = off;
@@ -1654,7 +1808,8 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
     w.chunks = off;  off = align_up(off + (kChunks + 1) * sizeof(int), 256);
     w.ranks = off;   off = align_up(off + (kChunks + 1) * sizeof(int), 256);
     w.costs = off;   off = align_up(off + (kChunks + 1) * sizeof(unsigned long long), 256);
-    w.partial = off; off = align_up(off + (size_t)kMaxBlocks * 3 * 8 * 16 * 64 * sizeof(float), 256);
+    w.partial = off; off = align_up(off + (size_t)kMaxBlocks * 2 * kRunTiles * 8 * 16 * 64 * sizeof(float), 256); // hand-off parts of the (first, last) run of a workgroup
+    w.slots = off;   off = align_up(off + (size_t)pipe_blocks(w.n_tiles, 0) * kRunTiles * kMaxScales * contributions_of(n_views) * 8 * 16 * 64 * sizeof(float), 256); // contributions to the tiles of the run a workgroup is in
     w.diag = off;    off = align_up(off + (size_t)kMaxBlocks * 8 * sizeof(unsigned long long), 256);
     w.balance = off; off = align_up(off + kBalanceBytes, 256); // work-cut bounds per workgroup + the last launch's times (vfa_pipe_balance_f32)
     w.wmax = off;    off = align_up(off + (size_t)kMaxScales * kWmaxParts * sizeof(unsigned), 256); // fp16 split: partial maxima of |W| per scale,
@@ -1664,20 +1819,14 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
     return w;
 }
 
-// workgroups of a launch of the frame kernel: one per CU (less the reserved ones), a multiple of eight
-inline int pipe_blocks(int n_tiles, int reserved_cus)
+// run length of a frame (vfa_pipe_seq.h: run_tiles_of); VFA_AMD_PIPE_RT = 1 | 2 | 4 overrides it for A/B measurements (tools/)
+inline int frame_run_tiles(int n_views, int n_tiles, int n_scales, int nl)
 {
-    int n_cu = 256;
-    {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            cus > 0)
-            n_cu = cus;
+    if (const char *e = getenv("VFA_AMD_PIPE_RT")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) return v;
     }
-    if (reserved_cus > 0 && n_cu - reserved_cus >= 8) n_cu -= reserved_cus;
-    int nblk = n_tiles < n_cu ? n_tiles : n_cu;
-    nblk = (nblk + 7) / 8 * 8; // xcd_contiguous deals whole eighths; surplus workgroups find an empty range and leave
-    return nblk > kMaxBlocks ? kMaxBlocks : nblk;
+    return run_tiles_of(n_views, n_tiles, n_scales, nl, pipe_blocks(n_tiles, 0));
 }
 
 inline bool dims_ok(int n_views, int L, int W, int nl, int n_scales)
@@ -1775,6 +1924,7 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
     for (int k = 0; k < kMaxScales; ++k) ca.live[k] = reinterpret_cast<const unsigned *>(ws + lay.live[k < n_scales ? k : 0]);
     ca.globs = reinterpret_cast<const unsigned *>(ws + lay.globs);
     ca.n_scales = n_scales; ca.n_tiles = lay.n_tiles; ca.n_views = n_views; ca.nl = n_layers;
+    ca.rt = frame_run_tiles(n_views, lay.n_tiles, n_scales, n_layers);
     ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);
     ca.chunk_rank = reinterpret_cast<int *>(ws + lay.ranks);
     ca.chunk_cost = reinterpret_cast<unsigned long long *>(ws + lay.costs);
@@ -1881,10 +2031,13 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
     }
     a.wexp = reinterpret_cast<const int *>(ws + lay.wexp);
     a.n_scales = n_scales; a.n_views = n_views; a.nl = n_layers; a.L = L; a.W = W; a.tiles_w = lay.tiles_w; a.n_tiles = lay.n_tiles;
+    a.rt = frame_run_tiles(n_views, lay.n_tiles, n_scales, n_layers); // (the same for every launch size: the cuts were made once)
     a.out = out; a.accumulate = accumulate;
     a.chunk_start = reinterpret_cast<const int *>(ws + lay.chunks);
     a.chunk_rank = reinterpret_cast<const int *>(ws + lay.ranks);
     a.partial = reinterpret_cast<float *>(ws + lay.partial);
+    a.slots = reinterpret_cast<float *>(ws + lay.slots);
+    a.n_contrib = contributions_of(n_views);
     a.tickets = reinterpret_cast<unsigned *>(ws + lay.tickets);
     a.diag = reinterpret_cast<unsigned long long *>(ws + lay.diag);
     a.debug = debug;
@@ -1896,17 +2049,20 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
         if (e0 != hipSuccess) return (int)e0;
     }
     // (the tickets are clear: zeroed with the masks by the geometry call, and put back by the last arriver of every earlier launch)
-    if (debug) // (diagnostic build of the default arithmetic)
+    const bool small = n_views <= 2 && a.rt == 1; // (groups of at most two sub-tiles: the four-step phase)
+    if (debug && small && !(debug & kDbgDumpVox)) // (diagnostic build of the default arithmetic)
+        hipLaunchKernelGGL((pipe_kernel<2, true, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
+    else if (debug)
         hipLaunchKernelGGL((pipe_kernel<2, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     else if (terms == 4)
         hipLaunchKernelGGL((pipe_kernel<4, false>), dim3(nblk), dim3(threads_of(4)), 0, s, a);
     else if (terms == 6)
         hipLaunchKernelGGL((pipe_kernel<6, false>), dim3(nblk), dim3(threads_of(6)), 0, s, a);
-    else if (terms == 3 && n_views <= 2)
+    else if (terms == 3 && small)
         hipLaunchKernelGGL((pipe_kernel<3, false, true>), dim3(nblk), dim3(threads_of(3)), 0, s, a);
     else if (terms == 3)
         hipLaunchKernelGGL((pipe_kernel<3, false>), dim3(nblk), dim3(threads_of(3)), 0, s, a);
-    else if (n_views <= 2) // (one or two views: the four-step phase)
+    else if (small)
         hipLaunchKernelGGL((pipe_kernel<2, false, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     else
         hipLaunchKernelGGL((pipe_kernel<2, false>), dim3(nblk), dim3(threads_of(2)), 0, s, a);

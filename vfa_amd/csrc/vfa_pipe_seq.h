@@ -1,19 +1,25 @@
 // vfa_pipe_seq.h -- the order in which a workgroup of the pipelined frame kernel (vfa_pipe.hip) walks its share of the frame,
-// as plain host / device code: tests/pipe_seq_harness.cpp compiles it with g++ and checks it on the CPU.
+// as plain host / device code: tests/native/pipe_seq_harness.cpp compiles it with g++ and checks it on the CPU.
 //
 // Work of a frame, for ANY number of z-layers (reference vfa/model/vfa_op.py:50-59, 118-125: K = nl * C):
-//   tile  = 8 x 4 BEV cells = one 32-row block of the matrix pipe
-//   group = up to four live views of one (tile, scale): their accumulators (4 x 32 rows x 256 columns, fp32) stay in
-//           registers over all layers, because `relu` follows the sum over the WHOLE K = nl * 256 (vfa_op.py:123-124)
-//   phase = (group, layer)
-//   step  = (phase, channel quarter q, set): set 0 = sub-tiles 0, 1 of the group, set 1 = sub-tiles 2, 3; one step is 64 rows x
-//           64 channels of voxel features, pooled by the four pooling waves while the eight matrix waves multiply the
-//           previous step; both sets of a (layer, quarter) use the same 64 x 256 slice of `collapse.weight`.
-//           EVERY (phase, quarter) has both steps, also when the group has no third view (the step is then empty: a barrier
-//           and nothing else): the set of a step is the parity of its index, so the kernel's loop, unrolled by two, addresses
-//           the accumulators of each set statically.
-// A workgroup owns the groups from the k_begin-th group of tile t_begin up to (not including) the k_end-th group of tile
-// t_end (groups of a tile in (scale, view) order).
+//   tile     = 8 x 4 BEV cells = one 32-row block of the matrix pipe
+//   sub-tile = one live view of one (tile, scale): 32 rows x 256 columns of accumulators
+//   run      = rt consecutive tiles, rt = 1, 2 or 4 (run_tiles_of: chosen per frame; rt = 1 is the order of rounds 3-5, tile by tile)
+//   group    = up to four sub-tiles of one (run, scale), taken in (tile, view) order ACROSS the tiles of the run (round 6): their
+//              accumulators (4 x 32 rows x 256 columns, fp32) stay in registers over all layers, because `relu` follows the sum over
+//              the WHOLE K = nl * 256 (vfa_op.py:123-124), while `collapse.weight` streams through once per group and layer.  Until
+//              round 5 a group held views of ONE tile: a rig of seven cameras ran groups of 4 + 3 (every eighth sub-tile slot empty),
+//              one of six 4 + 2, and a rank that holds ONE camera of a sharded rig streamed the whole weight for 32 rows.  Now the
+//              28 sub-tiles of a seven-camera run are seven full groups, and a one-camera frame fills a group with four tiles.
+//   phase    = (group, layer)
+//   step     = (phase, channel quarter q, set): set 0 = sub-tiles 0, 1 of the group, set 1 = sub-tiles 2, 3; one step is 64 rows x
+//              64 channels of voxel features, pooled by the pooling waves while the eight matrix waves multiply the
+//              previous step; both sets of a (layer, quarter) use the same 64 x 256 slice of `collapse.weight`.
+//              EVERY (phase, quarter) has both steps, also when the group has no third sub-tile (the step is then empty: a barrier
+//              and nothing else): the set of a step is the parity of its index, so the kernel's loop, unrolled by two, addresses
+//              the accumulators of each set statically.
+// Order: run -> scale -> groups -> layers.  A workgroup owns the groups from the k_begin-th group of run r_begin up to (not
+// including) the k_end-th group of run r_end (groups of a run numbered across its scales).
 #ifndef VFA_PIPE_SEQ_H
 #define VFA_PIPE_SEQ_H
 
@@ -26,7 +32,8 @@
 namespace vfa_pipe {
 
 constexpr int kSeqMaxScales = 3;
-constexpr int kGroupViews = 4;
+constexpr int kGroupViews = 4;             // sub-tiles of a group
+constexpr int kRunTiles = 4;               // the LARGEST run (the tile offset of a sub-tile takes two bits of its byte); a frame's run length is `rt`
 
 VFA_SEQ_HD int seq_popc(unsigned v)
 {
@@ -38,148 +45,181 @@ VFA_SEQ_HD int seq_popc(unsigned v)
 }
 VFA_SEQ_HD int seq_ctz(unsigned v) { return __builtin_ctz(v); }
 
-// groups of a (tile, scale) whose live-view mask is `m`, and the sets (pairs of sub-tiles) of all of them
-VFA_SEQ_HD int groups_of(unsigned m) { return (seq_popc(m) + kGroupViews - 1) / kGroupViews; }
-VFA_SEQ_HD int sets_of(unsigned m) { return (seq_popc(m) + 1) / 2; }
+// groups of a (run, scale) that holds `n_sub` live sub-tiles
+VFA_SEQ_HD int groups_of_count(int n_sub) { return (n_sub + kGroupViews - 1) / kGroupViews; }
+VFA_SEQ_HD int runs_of(int n_tiles, int rt) { return (n_tiles + rt - 1) / rt; }
+
+// Run length of a frame (measured, round 6, one MI355X; launch time of the frame kernel in us, rt = 1 / 2 / 4):
+//   seven cameras, MultiviewC 156 x 156 x 5     1 545 / 1 585 / 1 650     (tile by tile until round 5: 1 455)
+//   six cameras,   MultiviewX 160 x 250 x 8     3 475 / 3 255 / 3 315     (3 430)
+//   seven cameras, Wildtrack 120 x 360 x 8      3 840 / 3 810 / 3 785     (3 765)
+//   eight cameras, 512 x 512 x 32, one band     27 100 / 25 250 / 24 850   (27 000)
+//   one camera,    512 x 512 x 32               28 500 / 19 000 / 14 050   (four-step phase of rounds 4-5: 20 900)
+//   one camera,    MultiviewC 156 x 156 x 5     555 / 450 / 480            (four-step phase: 305)
+// Longer runs fill the groups (fewer steps: -12 % for seven cameras, -25 % for six, -75 % for one) and keep a workgroup on one
+// image for longer (the eight-camera frame has nothing to fill and still gains 8 %); they cost at the end of a run -- every
+// workgroup that holds groups of a run reads its contributions to ALL tiles of the run back, and a group, the unit of the work cuts,
+// gets no smaller --: what a frame can afford grows with the steps a workgroup has between two ends of runs.  Frames of one or two
+// views are a rank's share of a camera-sharded rig: big ones fill their groups from four tiles, small ones keep the four-step phase
+// (rt = 1, two sub-tiles per group at most: pipe_kernel<.., SMALL>).
+VFA_SEQ_HD int run_tiles_of(int n_views, int n_tiles, int n_scales, int nl, int n_blocks)
+{
+    const long long steps = 2ll * nl * n_views * n_scales * n_tiles / (n_blocks > 0 ? n_blocks : 1); // per workgroup, full groups
+    if (n_views <= 2) return steps >= 1000 ? kRunTiles : 1;
+    return steps >= 4000 ? kRunTiles : (steps >= 1200 ? 2 : 1);
+}
+
+// sub-tile j of a group in byte j of `subs`: view in bits 0-4, tile offset inside the run in bits 5-6
+VFA_SEQ_HD unsigned sub_byte(int view, int tile_off) { return (unsigned)view | ((unsigned)tile_off << 5); }
+VFA_SEQ_HD int sub_view(unsigned subs, int j) { return (int)((subs >> (8 * j)) & 31u); }
+VFA_SEQ_HD int sub_tile_off(unsigned subs, int j) { return (int)((subs >> (8 * j + 5)) & 3u); }
 
 struct Step {
-    int tile;        // < 0: no step
+    int run;         // < 0: no step
     int scale, layer, q, set;
-    int nj;          // sub-tiles (views) of the group, 1..4
-    unsigned views;  // view of sub-tile j in bits 8 j .. 8 j + 7
+    int nj;          // sub-tiles of the group, 1..4
+    unsigned subs;   // sub-tile j in byte j (sub_byte)
     int phase;       // running number of the (group, layer) of this step within the workgroup
-    int rank;        // index of the group among the groups of its tile
+    int rank;        // index of the group among the groups of its run
+    int ci;          // contribution index of the group's head tile (walk_groups)
     int index;       // running number of the step within the workgroup (parity = LDS buffer)
     bool grp_first;  // first step of the group for this set: the accumulators of the set start from the bias
     bool grp_last;   // last step of the group for this set: relu and the view sum follow
-    bool tile_last;  // last step of this workgroup's part of the tile
-    VFA_SEQ_HD bool valid() const { return tile >= 0; }
-    VFA_SEQ_HD int view(int j) const { return (int)((views >> (8 * j)) & 0xffu); }
+    bool run_last;   // last step of this workgroup's part of the run
+    VFA_SEQ_HD bool valid() const { return run >= 0; }
+    VFA_SEQ_HD int view(int j) const { return sub_view(subs, j); }
+    VFA_SEQ_HD int tile(int j, int rt) const { return run * rt + sub_tile_off(subs, j); }
     VFA_SEQ_HD int in_set() const { return nj - 2 * set >= 2 ? 2 : (nj - 2 * set > 0 ? nj - 2 * set : 0); } // sub-tiles of this step: 0, 1 or 2
-    VFA_SEQ_HD bool same_chunk(const Step &o) const { return scale == o.scale && layer == o.layer && q == o.q; }
 };
 
 // A phase = (group, layer): eight steps, quarter q = k >> 1, set = k & 1 for k = 0 .. 7.  The kernel hands PHASES from the one
 // wave that runs the generator to the others (through LDS) and every wave derives the steps itself (step_of).
 struct Phase {
-    int tile;        // < 0: no phase
+    int run;         // < 0: no phase
     int scale, layer, nj;
-    unsigned views;
-    int phase, rank;
-    bool more_in_tile; // another group of this workgroup follows in the same tile
-    VFA_SEQ_HD bool valid() const { return tile >= 0; }
+    unsigned subs;
+    int phase, rank, ci;
+    bool more_in_run; // another group of this workgroup follows in the same run
+    VFA_SEQ_HD bool valid() const { return run >= 0; }
 };
 
 VFA_SEQ_HD Step step_of(const Phase &ph, int k, int nl, int index)
 {
     Step st;
-    st.tile = ph.tile; st.scale = ph.scale; st.layer = ph.layer; st.q = k >> 1; st.set = k & 1; st.nj = ph.nj; st.views = ph.views;
-    st.phase = ph.phase; st.rank = ph.rank; st.index = index;
+    st.run = ph.run; st.scale = ph.scale; st.layer = ph.layer; st.q = k >> 1; st.set = k & 1; st.nj = ph.nj; st.subs = ph.subs;
+    st.phase = ph.phase; st.rank = ph.rank; st.ci = ph.ci; st.index = index;
     st.grp_first = ph.layer == 0 && st.q == 0;
     st.grp_last = ph.layer == nl - 1 && st.q == 3;
-    st.tile_last = st.grp_last && st.set == 1 && !ph.more_in_tile;
+    st.run_last = st.grp_last && st.set == 1 && !ph.more_in_run;
     return st;
 }
 
-// Generator of the phases / steps of one workgroup.  `Masks` returns the live-view mask of (scale, tile).
+// The sums of a tile.  A group ends with relu and the view sum (vfa_op.py:124; vfanet.py:79, 82): the sub-tiles of one tile inside a
+// group are added in registers and the result -- one CONTRIBUTION per (group, tile) -- is stored to a buffer of the workgroup's own,
+// [tile of the run][scale][index]; when the workgroup leaves the run it adds the contributions of every tile in (scale, index) order.
+// A tile that enters a group behind another tile starts at index 0; the HEAD tile of a group (its first sub-tile's) continues from
+// the group before when that one ended in the same tile: index + 1.  A tile of n live views touches at most (n + 2) / 4 + 1 groups.
+VFA_SEQ_HD int contributions_of(int n_views) { return (n_views + 2) / 4 + 1; }
+
+// Walks the groups of ONE run: emit(k, scale, subs, nj, ci) for the k-th group, in the kernel's order; ci = the contribution index
+// of the group's head tile (every other tile of the group has index 0).  `mask(s, off)` = live-view mask of (scale s, tile run *
+// rt + off), 0 beyond the last tile; `lo` = the first group the caller's workgroup owns in this run (its indices start there).
+// Returns the number of groups.  The generator of the kernel (vfa_pipe.hip: fill_groups) and the CPU harness enumerate through
+// this one function; the work cuts count the same groups from the live sub-tiles per scale (walk_run below).
+template <class Mask, class Emit>
+VFA_SEQ_HD int walk_groups(int n_scales, int rt, int lo, Mask &&mask, Emit &&emit)
+{
+    int k = 0;
+    for (int s = 0; s < n_scales; ++s) {
+        unsigned subs = 0;
+        int nj = 0, last_off = -1, last_ci = 0; // the tile the group before ended in (this scale), and its contribution index there
+        auto flush = [&]() {
+            const int head = sub_tile_off(subs, 0), tail = sub_tile_off(subs, nj - 1);
+            const int ci = (k != lo && head == last_off) ? last_ci + 1 : 0;
+            emit(k, s, subs, nj, ci);
+            last_off = tail;
+            last_ci = tail == head ? ci : 0;
+            ++k; subs = 0; nj = 0;
+        };
+        for (int off = 0; off < rt; ++off) {
+            unsigned rest = mask(s, off);
+            while (rest) {
+                subs |= sub_byte(seq_ctz(rest), off) << (8 * nj);
+                rest &= rest - 1u;
+                if (++nj == kGroupViews) flush();
+            }
+        }
+        if (nj) flush();
+    }
+    return k;
+}
+
+// Generator of the phases / steps of one workgroup (CPU harness; the kernel expands runs into a ring of group records with
+// walk_groups and counts the layers itself).  `Masks` returns the live-view mask of (scale, tile).
 template <class Masks>
 struct Sequencer {
     Masks masks;
-    int n_scales, nl, t_end, k_end, t_lim;
-    // position
-    int tile, scale, rank, layer, q, set, nj, phase, index;
-    unsigned rest, views, m0, m1, m2; // (scalars, not an array: a dynamically indexed array would live in scratch memory)
-    bool in_group, more_in_tile;
+    int n_scales, nl, n_tiles, rt, r_begin, k_begin, r_end, k_end, r_lim;
+    int run, n_groups, next_k, k_hi, layer, q, phase, index;
+    // the groups of the current run (at most 3 scales x 32 views x 4 tiles / 4)
+    int g_scale[96], g_nj[96], g_ci[96];
+    unsigned g_subs[96];
+    bool in_group;
 
-    // (three value selects: `s == 0 ? m0 : ...` becomes a load through a selected ADDRESS and keeps the whole object in memory)
-    VFA_SEQ_HD unsigned mask_of(int s) const { return (s == 0 ? m0 : 0u) | (s == 1 ? m1 : 0u) | (s == 2 ? m2 : 0u); }
-    VFA_SEQ_HD void load_tile()
+    void load_run()
     {
-        const bool on = tile < t_lim;
-        m0 = on ? masks(0, tile) : 0u;
-        m1 = (on && n_scales > 1) ? masks(1, tile) : 0u;
-        m2 = (on && n_scales > 2) ? masks(2, tile) : 0u;
+        n_groups = 0;
+        if (run >= r_lim) return;
+        const int base = run * rt;
+        next_k = run == r_begin ? k_begin : 0;
+        n_groups = walk_groups(n_scales, rt, next_k, [&](int s, int off) { return base + off < n_tiles ? masks(s, base + off) : 0u; },
+                               [&](int k, int s, unsigned subs, int nj, int ci) { g_scale[k] = s; g_subs[k] = subs; g_nj[k] = nj; g_ci[k] = ci; });
+        k_hi = run == r_end ? (k_end < n_groups ? k_end : n_groups) : n_groups;
     }
-    VFA_SEQ_HD void begin(int n_scales_, int nl_, int t_begin, int k_begin, int t_end_, int k_end_)
+    void begin(int n_scales_, int nl_, int n_tiles_, int rt_, int r_begin_, int k_begin_, int r_end_, int k_end_)
     {
-        n_scales = n_scales_; nl = nl_; t_end = t_end_; k_end = k_end_;
-        t_lim = k_end > 0 ? t_end + 1 : t_end;
-        tile = t_begin; scale = 0; rank = 0; layer = q = set = 0; nj = 0; phase = -1; index = -1; cur.tile = -1;
-        views = 0; in_group = false; more_in_tile = false;
-        load_tile();
-        rest = m0;
-        // the first k_begin groups of the tile belong to the workgroup in front
-        for (int skip = k_begin; skip > 0 && tile < t_lim;) {
-            if (rest) {
-                for (int j = 0; j < kGroupViews && rest; ++j) rest &= rest - 1u;
-                --skip; ++rank;
-            } else if (scale + 1 < n_scales) rest = mask_of(++scale);
-            else break;
-        }
+        n_scales = n_scales_; nl = nl_; n_tiles = n_tiles_; rt = rt_; r_begin = r_begin_; k_begin = k_begin_; r_end = r_end_; k_end = k_end_;
+        r_lim = k_end > 0 ? r_end + 1 : r_end;
+        run = r_begin; layer = 0; q = 0; phase = -1; index = -1; in_group = false; cur.run = -1;
+        load_run();
     }
-    // true when a group was formed
-    VFA_SEQ_HD bool next_group()
-    {
-        while (tile < t_lim) {
-            if (rest) {
-                if (tile == t_end && rank >= k_end) return false; // the next workgroup's part of the tile
-                views = 0; nj = 0;
-                for (; nj < kGroupViews && rest; ++nj) {
-                    views |= (unsigned)seq_ctz(rest) << (8 * nj);
-                    rest &= rest - 1u;
-                }
-                bool later = rest != 0u;
-                if (scale < 1 && n_scales > 1) later = later || m1 != 0u;
-                if (scale < 2 && n_scales > 2) later = later || m2 != 0u;
-                more_in_tile = later && !(tile == t_end && rank + 1 >= k_end);
-                return true;
-            }
-            if (scale + 1 < n_scales) rest = mask_of(++scale);
-            else {
-                ++tile; scale = 0; rank = 0;
-                load_tile();
-                rest = m0;
-            }
-        }
-        return false;
-    }
-    VFA_SEQ_HD Phase next_phase()
+    Phase next_phase()
     {
         Phase ph;
-        ph.tile = -1; ph.scale = ph.layer = ph.nj = 0; ph.views = 0; ph.phase = ph.rank = 0; ph.more_in_tile = false;
+        ph.run = -1; ph.scale = ph.layer = ph.nj = 0; ph.subs = 0; ph.phase = ph.rank = ph.ci = 0; ph.more_in_run = false;
         if (in_group) {
             if (layer + 1 < nl) ++layer;
-            else { in_group = false; ++rank; }
+            else { in_group = false; ++next_k; }
         }
         if (!in_group) {
-            if (!next_group()) return ph;
+            while (run < r_lim && next_k >= k_hi) { ++run; load_run(); }
+            if (run >= r_lim) return ph;
             in_group = true;
             layer = 0;
         }
         ++phase;
-        ph.tile = tile; ph.scale = scale; ph.layer = layer; ph.nj = nj; ph.views = views; ph.phase = phase; ph.rank = rank;
-        ph.more_in_tile = more_in_tile;
+        ph.run = run; ph.scale = g_scale[next_k]; ph.layer = layer; ph.nj = g_nj[next_k]; ph.subs = g_subs[next_k]; ph.phase = phase;
+        ph.rank = next_k; ph.ci = g_ci[next_k]; ph.more_in_run = next_k + 1 < k_hi;
         return ph;
     }
-    // the steps one by one (CPU harness; the kernel expands the phases itself)
     Phase cur;
-    VFA_SEQ_HD Step next()
+    Step next()
     {
         if (index < 0 || q == 7) { cur = next_phase(); q = 0; }
         else ++q; // (q doubles as the step counter inside the phase here)
-        if (!cur.valid()) { Step st; st.tile = -1; st.scale = st.layer = st.q = st.set = st.nj = 0; st.views = 0; st.phase = st.rank = st.index = 0;
-                            st.grp_first = st.grp_last = st.tile_last = false; q = 7; index = index < 0 ? 0 : index; return st; }
+        if (!cur.valid()) { Step st; st.run = -1; st.scale = st.layer = st.q = st.set = st.nj = 0; st.subs = 0; st.phase = st.rank = st.ci = st.index = 0;
+                            st.grp_first = st.grp_last = st.run_last = false; q = 7; index = index < 0 ? 0 : index; return st; }
         ++index;
         return step_of(cur, q, nl, index);
     }
 };
 
 // ------------------------------------------------------------------------------------------------
-// work cuts: the groups of the frame in (tile, scale, view) order, cut into `n_chunks` pieces of equal estimated cost.
+// work cuts: the groups of the frame in (run, scale, tile, view) order, cut into `n_chunks` pieces of equal estimated cost.
 // Cost model in units of 64 cycles, fitted to the per-workgroup cycle counts of the diagnostic build of the sixteen-wave kernel on
 // the bench frame and three multi-layer frames (tools/bench_pipe.py --fit): a step with work 69, a step of an empty set 46 (it
 // still waits for the next step's window), a sub-tile pooled from L2 instead of an LDS window + 35 per step, + 14 per group
-// (weight reloads, the running sum), + 36 per tile (its store).
+// (weight reloads, the contributions to the tile sums), + 36 per tile (its store).
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned kStepCost = 69, kEmptyStepCost = 46, kGlobStepCost = 35, kGroupCost = 14, kTileCost = 36, kEmptyCost = 1;
 
@@ -189,26 +229,27 @@ VFA_SEQ_HD unsigned group_cost(int nj, int nl)
     return 4u * (unsigned)nl * (kStepCost * sets + kEmptyStepCost * (2u - sets)) + kGroupCost;
 }
 
-// walks the groups of a tile (masks m[0 .. n_scales)): visit(k, w0, w1) for the k-th group covering [w0, w1) of the tile's cost;
-// `globs` = (view, layer, scale) items of the tile that are pooled from L2 (charged to the first group); returns the tile's cost
+// walks the groups of a run: visit(k, w0, w1) for the k-th group covering [w0, w1) of the run's cost; `counts[s]` = live sub-tiles of
+// (run, scale s); `globs` = (view, layer, scale) items of the run that are pooled from L2 (charged to the first group); `tiles` =
+// tiles of the run.  Returns the run's cost.
 template <class Visit>
-VFA_SEQ_HD unsigned walk_tile(const unsigned *m, int n_scales, int nl, unsigned globs, Visit &&visit)
+VFA_SEQ_HD unsigned walk_run(const int *counts, int n_scales, int nl, unsigned globs, int tiles, Visit &&visit)
 {
     unsigned w = 0;
     int k = 0;
     for (int s = 0; s < n_scales; ++s) {
-        int left = seq_popc(m[s]);
+        int left = counts[s];
         while (left > 0) {
             const int nj = left < kGroupViews ? left : kGroupViews;
             unsigned wi = group_cost(nj, nl);
-            if (k == 0) wi += kTileCost + 4u * kGlobStepCost * globs;
+            if (k == 0) wi += kTileCost * (unsigned)tiles + 4u * kGlobStepCost * globs;
             visit(k, w, w + wi);
             w += wi;
             ++k;
             left -= nj;
         }
     }
-    return k == 0 ? kEmptyCost : w;
+    return k == 0 ? kEmptyCost * (unsigned)tiles : w;
 }
 
 } // namespace vfa_pipe
