@@ -1097,8 +1097,24 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // accumulators with uniform selects (x + 0 = x), stored, forgotten.  A version that summed in place under uniform branches
         // (the head tile's sum carried from the first pair to the second) left the compiler with sixteen-register values merging
         // at every join: it spilled whole accumulators and reloaded all sixteen registers once per element stored.
+        bool tile_open = false; // (four-step phase: the tile's sum so far sits in acc[2])
         auto group_finish = [&](const PhaseRec &ph) __attribute__((always_inline)) {
             const int nj = ph.nj(), sc = ph.scale();
+            if constexpr (SMALL) {
+                // Four-step phase (one or two views, runs of one tile): the products use acc[0], acc[1] only, so the tile's sum stays in
+                // acc[2] across its groups (one per scale) -- no contributions, nothing to read back.  Same values in the same order
+                // as the contributions would be added in: ((s0 + s1) + s2), each the group's relu'd sum times 2^-(ea+ew-shift).
+                relu16(acc[0]);
+                if (nj >= 2) { relu16(acc[1]); add16(acc[0], acc[1]); }
+                const float inv = inv_sub(ph, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float c = F16 ? acc[0][i] * inv : acc[0][i];
+                    acc[2][i] = tile_open ? acc[2][i] + c : c;
+                }
+                tile_open = true;
+                return;
+            }
             const int o0 = sub_tile_off(ph.subs, 0), o1 = sub_tile_off(ph.subs, 1), o2 = sub_tile_off(ph.subs, 2), o3 = sub_tile_off(ph.subs, 3);
             relu16(acc[0]);
             if (nj >= 2) relu16(acc[1]);
@@ -1313,6 +1329,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             if (kAblate & 512) { cmask = 0ull; return; }
             const bool shared = shared_run(run);
             const int which = (run == r_begin && k_begin > 0) ? 0 : 1;
+            tile_open = false;
             auto load16 = [&](f32x16 &v, const float *p) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) v[i] = __hip_atomic_load(p + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1328,7 +1345,12 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
             };
-            if constexpr (!POOL) {
+            if constexpr (!POOL && SMALL) { // (the sum of the run's one tile is in acc[2]: group_finish)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[0][i] = acc[2][i];
+                emit_tile(0);
+            }
+            if constexpr (!POOL && !SMALL) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores of the last group
                 // The contributions of the run as ONE flat sequence (tile, scale, index ascending), three loads in flight all the way
                 // (a batch per (tile, scale) was twelve exposed round trips per run: 85 us per finish on the five-layer MultiviewC frame)
@@ -1620,7 +1642,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                             if (jn < kPS) { w_set(rec.scale(), rec.layer(), quarter_of(jn)); next_chunk = true; }
                             // (not across the end of a GROUP: the code behind it needs the registers of the weight slice -- with the slice
                             // of the next group in them the compiler spilled whole accumulators around the contributions' stores)
-                            else if (nx.valid() && rec.layer() != a.nl - 1) { w_set(nx.scale(), nx.layer(), 0); next_chunk = true; }
+                            // (the four-step phase has registers to spare -- acc[2], acc[3] carry no products -- and a light end of group)
+                            else if (nx.valid() && (SMALL || rec.layer() != a.nl - 1)) { w_set(nx.scale(), nx.layer(), 0); next_chunk = true; }
                         }
                         multiply(std::integral_constant<int, SET>{}, rec, J, PAR, next_chunk);
                     }
@@ -1649,7 +1672,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 rec = nx;
                 ++n;
             }
-            if (group_ended && nx.valid()) { // the first weight slice of the next group: requested here, it lands under the stores below
+            if (!SMALL && group_ended && nx.valid()) { // the first weight slice of the next group: requested here, it lands under the stores below
                 w_set(nx.scale(), nx.layer(), 0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) w_load(ks);
