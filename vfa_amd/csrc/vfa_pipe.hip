@@ -506,6 +506,10 @@ __device__ __forceinline__ void read_frags(unsigned pa, bf16x8 &h0, bf16x8 &l0, 
 template <int KS, int PLANE>
 __device__ __forceinline__ void read_pair(unsigned pa, bf16x8 &f0, bf16x8 &f1)
 {
+    if constexpr ((VFA_PIPE_ABLATE & 2048) != 0) { // (ablation: the products without their fragment reads)
+        asm volatile("" : "+v"(f0), "+v"(f1) : "v"(pa));
+        return;
+    }
     asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
                  : "=&v"(f0), "=&v"(f1)
                  : "v"(pa), "n"(KS * 2 * kChunkStride + PLANE * kPlaneBytes), "n"(KS * 2 * kChunkStride + 512 + PLANE * kPlaneBytes)
@@ -951,7 +955,12 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // reloaded behind the k-steps of set 1 (the next step starts another slice), never behind those of set 0 -- a reload
         // decided at run time inside the k-loop cost register copies at every merge point.
         // one 32 x 32 x 16 product on the matrix pipe: fp16 pieces (default) or bf16 pieces -- the registers hold 8 x 16 bits either way
-        auto mfma16 = [](const bf16x8 &av, const bf16x8 &bv, const f32x16 &cv) {
+        auto mfma16 = [](const bf16x8 &av, const bf16x8 &bv, const f32x16 &cv) -> f32x16 {
+            if constexpr ((kAblate & 1024) != 0) { // (ablation: everything but the matrix instruction itself -- its operands stay alive)
+                f32x16 r = cv;
+                asm volatile("" : "+v"(r) : "v"(av), "v"(bv));
+                return r;
+            }
             if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), cv, 0, 0, 0);
             else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, cv, 0, 0, 0);
         };
@@ -982,7 +991,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             // ONE set of fragment registers: the reads of k-step ks + 1 are issued behind the MFMAs of ks (which latched their A
             // operands when they issued) and land under them and under the partner wave's MFMAs; a second set for reading ahead
             // does not fit beside four accumulators, the tile sums and the weight slice (168 registers at three waves per SIMD)
-            bf16x8 h0, h1, l0, l1; // row blocks 0 / 1 of the hi and of the lo plane: one k-step ahead of the MFMAs
+            bf16x8 h0 = {}, h1 = {}, l0 = {}, l1 = {}; // row blocks 0 / 1 of the hi and of the lo plane: one k-step ahead of the MFMAs
             // A sub-tile without a live box in this layer was ZEROED by its pooling wave and is multiplied like any other; the second
             // row block of a set that has only ONE sub-tile (the last set of a group with an odd number of views: one step in four
             // on a seven-camera rig) is left out -- BOTH = false: half the MFMAs of the step, its accumulator is never read.
@@ -1600,6 +1609,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
             // and the end of the group are facts of the code position; the phase record is read once per phase, the weight-slice
             // address comes from it by scalar arithmetic instead of an LDS read per chunk.
             auto w_set = [&](int scale, int layer, int q) {
+                if (kAblate & 4096) layer = 0; // (ablation: every layer reads the first layer's weights -- a weight set that fits L2)
                 const uint2 wf = *reinterpret_cast<const uint2 *>(&s_sc[scale][4]);
                 const unsigned long long p = ((unsigned long long)wf.y << 32 | wf.x) +
                                              (unsigned long long)(((unsigned)layer * 8u * kSteps + (unsigned)q * 4u) * (unsigned)kWPlanes * 64u) * 16u;
@@ -1625,7 +1635,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                     constexpr int J = decltype(j_tag)::value, SET = SMALL ? 0 : J & 1, PAR = J & 1;
                     dbg_pos = (J + 1) & (kPS - 1);
                     tick(0);
-                    __builtin_amdgcn_s_waitcnt(0x0f70); // the weight slice requested during the last step (see `body`)
+                    // The weight slice requested during the last step (see `body`).  (Round 6: the loads as assembly with a counted vmcnt in
+                    // front of every k-step -- the slice requested last lands under the first products instead of being waited for
+                    // here -- left every workload where it was, within 1 %: the matrix waves wait at the step barrier anyway.)
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
                     tick(1);
                     // (the tables of the next phase are the last pooling wave's job in this layout: `body`)
                     if constexpr (J == kPS - 2) nx = phase_rec(n + 1); // (written a phase ago)
