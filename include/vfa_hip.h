@@ -350,40 +350,53 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
  *
  *   vfa_pipe_boxes_f32     geometry once per frame: every (view, cell, LAYER) cube projected once, a 48-byte box record per scale
  *                          and a 32-byte tap-window header per (tile, layer, view, scale)        replaces vfa_op.py:64-106
- *   vfa_pipe_cuts_f32      cost-balanced work cuts + collapse.weight of every scale as bf16 hi / lo MFMA fragments.
+ *   vfa_pipe_cuts_f32      cost-balanced work cuts + collapse.weight of every scale as 16-bit MFMA fragments (fp16 hi / lo under a
+ *                          power-of-two scale by default, bf16 pieces for terms 3 / 4 / 6).
  *                          weights[k]: (256, 256 * n_layers) fp32 in the REFERENCE layout, column = c * n_layers + layer
  *                          (vfa_op.py:59, :120) -- no host-side permutation
  *   vfa_pipe_records_f32   both of the above
  *   vfa_pipe_collapse_relu_sum_f32
- *                          out (L * W, 256) (+)= sum_scale sum_view relu(vox . W^T + b): one persistent kernel, 12 waves per
- *                          CU -- four pool boxes (the reference's exact fp32 FMA chains) while eight multiply the previous
- *                          64 rows x 64 channels on the matrix cores (bf16 two-piece split, 3 products, fp32 accumulation; the
- *                          accumulators of four views stay in registers across all layers, `relu` follows the whole
- *                          K = n_layers * 256); the voxel features never reach HBM      replaces vfa_op.py:110-125, vfanet.py:79, 82
+ *                          out (L * W, 256) (+)= sum_scale sum_view relu(vox . W^T + b): one persistent kernel, 16 waves per
+ *                          CU -- eight pool boxes (the reference's exact fp32 FMA chains and its correctly rounded quotient)
+ *                          while eight multiply the previous 64 rows x 64 channels on the matrix cores (default: two fp16 pieces
+ *                          per operand under a power-of-two scale, three products, fp32 accumulation: the width of the reference's
+ *                          fp32 nn.Linear; vfa_split.h).  The accumulators of a GROUP of four sub-tiles (a sub-tile = one live
+ *                          view of one (tile, scale)) stay in registers across all layers: `relu` follows the whole
+ *                          K = n_layers * 256.  Round 6: a group takes its sub-tiles from a RUN of 1, 2 or 4 consecutive tiles
+ *                          (vfa_pipe_seq.h: run_tiles_of -- chosen per frame from n_views, the tile count and n_layers), so a frame
+ *                          of one or two views (a rank's share of a camera-sharded rig) fills its groups from four tiles instead of
+ *                          streaming the weight for one view's 32 rows; the voxel features never reach HBM
+ *                                                                                replaces vfa_op.py:110-125, vfanet.py:79, 82
  *
- * workspace: caller-owned, vfa_pipe_workspace_bytes(); the geometry calls fill it, the kernel reads it (and uses its hand-off
- * area: a tile cut between two workgroups is finished by whichever arrives last, nobody waits).  integrals[k]: zero-bordered
- * channels-last (n_views, Hf+2, Wf+2, 256).  n_views <= 32.  flags: VFA_FLAG_TERMS_MASK | VFA_FLAG_RESERVED_CUS(n) |
- * VFA_FLAG_DEBUG(mask).  Terms: 0 / 3 = two bf16 pieces per operand, three products (error ~3e-6 of max|out|, inside the path's
- * 1e-5); 4 adds lo.lo; 6 = THREE pieces per operand (x = p0 + p1 + p2 to 2^-25) and the six products down to 2^-16 of the
- * largest: the arithmetic width of the reference's fp32 sgemm (<= 5e-7 normwise against float64), at twice the matrix work.
- * The geometry calls take the same terms in `flags` (the three-piece variant has smaller LDS tap windows, so the geometry must
- * know which kernel will read its records; pass the value that goes to vfa_pipe_collapse_relu_sum_f32).  On a single-layer
- * grid the three-product result equals vfa_pool_collapse_relu_sum_f32 bit for bit (on tiles no workgroup boundary cuts).
+ * workspace: caller-owned, vfa_pipe_workspace_bytes(); the geometry calls fill it, the kernel reads it and uses three areas of its
+ * own: the CONTRIBUTIONS of a workgroup to the tiles of the run it is in (one 32-row x 256-column buffer per (tile of the run,
+ * scale, group): plain stores at the end of a group, read back and added in (scale, group) order when the workgroup leaves the
+ * run), the PARTS of a run cut between workgroups (every matrix wave stores its 32 columns, draws a ticket of its own, and the wave
+ * that arrives last adds the parts in workgroup order and writes the tiles: nobody waits, no barrier), and the balance state.
+ * integrals[k]: zero-bordered channels-last (n_views, Hf+2, Wf+2, 256).  n_views <= 32.  flags: VFA_FLAG_TERMS_MASK |
+ * VFA_FLAG_RESERVED_CUS(n) | VFA_FLAG_DEBUG(mask) | VFA_FLAG_DUMP_VOX.  Terms: 0 / 2 = two fp16 pieces per operand, three products
+ * (1e-7 ... 3e-7 normwise against float64: an fp32 sgemm's error); 3 = two bf16 pieces, three products (16-bit operands, ~3e-6 of
+ * max|out|, inside the path's 1e-5 but narrower than the reference); 4 adds lo.lo; 6 = THREE bf16 pieces per operand (x = p0 + p1 +
+ * p2 to 2^-25) and the six products down to 2^-16 of the largest, at twice the matrix work.  The geometry calls take the same terms
+ * in `flags` (the weight fragments are split for one arithmetic, and the three-piece variant has smaller LDS tap windows; pass the
+ * value that goes to vfa_pipe_collapse_relu_sum_f32: a launch that asks for the other arithmetic returns a map of NaNs).  Results are
+ * deterministic for a given geometry, launch size and balance state; the association of the view / scale sum differs from
+ * vfa_pool_collapse_relu_sum_f32's (inside the post-GEMM tolerance).
  *
- *   vfa_pipe_balance_f32   (ABI v5) cameras and grid of a frame stream do not move: every launch of the frame kernel leaves the cycles
- *                          each of its workgroups took in the workspace, and mode 1 turns them into new BOUNDS of the workgroups'
- *                          shares of the work cuts (damped, normalised); the frame kernel uses them for every later frame whose cuts
- *                          have the same total cost and whose launch has the same number of workgroups, and falls back to the uniform
- *                          split otherwise.  mode 0 clears the state: call it once on a fresh workspace (the geometry calls never
- *                          touch the state).  Results stay inside the path's tolerance but are NOT bitwise the unbalanced ones: a
- *                          tile cut between two workgroups is summed in another association when the cut moves -- balance for a few
- *                          frames, then stop, and every later frame repeats bit for bit.  offsets[18] of
- *                          vfa_pipe_workspace_layout: the state (8 KiB: int bounds[513], launch size, cost signature; at byte
- *                          4096 a u64 cycle count per workgroup), for callers that keep one state per band of a banded frame.
- *                          offsets must hold 19 entries since ABI v5, 22 since ABI v8: offsets[19 + k] = the sliver shifts of
- *                          scale k, one unsigned per tile (binary places the fp16 operand split of the frame kernel gives up for
- *                          the noisiest visible box of (tile, scale): 0 everywhere but next to boxes of ~1e-5 pixels). */
+ *   vfa_pipe_balance_f32   (ABI v5) mode 1: from the work cuts the geometry call has just left (estimated cost per group), the BOUNDS
+ *                          of the workgroups' shares that minimise the heaviest share, for a launch of the size `reserved_cus`
+ *                          gives; the frame kernel uses them for every later frame whose cuts have the same total cost and whose
+ *                          launch has the same number of workgroups, and falls back to the uniform split otherwise (cameras and grid
+ *                          of a frame stream stand still).  mode 0 clears the state: call it once on a fresh workspace (the geometry
+ *                          calls never touch the state).  Deterministic.  Results stay inside the path's tolerance but are NOT
+ *                          bitwise the unbalanced ones: a run cut between two workgroups is summed in another association when the
+ *                          cut moves.  offsets[18] of vfa_pipe_workspace_layout: the state (8 KiB: int bounds[513], launch size,
+ *                          cost signature; at byte 4096 a u64 cycle count per workgroup of the last launch: diagnostics), for
+ *                          callers that keep one state per band of a banded frame.  offsets must hold 19 entries since ABI v5, 22
+ *                          since ABI v8: offsets[19 + k] = the sliver shifts of scale k, one unsigned per tile (binary places the
+ *                          fp16 operand split of the frame kernel gives up for the noisiest visible box of (tile, scale): 0
+ *                          everywhere but next to boxes of ~1e-5 pixels).  VFA_AMD_PIPE_RT = 1 | 2 | 4 in the environment overrides
+ *                          the run length (geometry call and frame kernel read it alike): measurements only. */
 size_t vfa_pipe_workspace_bytes(int n_views, int L, int W, int n_layers, int n_scales);
 int vfa_pipe_workspace_layout(int n_views, int L, int W, int n_layers, int n_scales, size_t *offsets, int *tiles);
 int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_layers, int n_layers, const float *corner_off, int n_views,

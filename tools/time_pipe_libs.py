@@ -59,7 +59,8 @@ lay = ops.pipe_workspace_layout(n, L, W, nl, 3)
 cyc = ws[lay["balance"] + 4096:lay["balance"] + 4096 + 8 * 512].cpu().numpy().view(np.uint64).astype(np.float64)
 cyc = cyc[cyc > 0]
 print(json.dumps({"us": round(sorted(best)[1], 1), "rows": L, "nl": nl, "n": n, "wgs": int(cyc.size), "wg_cycles_max_over_mean": round(float(cyc.max() / cyc.mean()), 3),
-                  "wg_cycles_min_over_mean": round(float(cyc.min() / cyc.mean()), 3)}))
+                  "wg_cycles_min_over_mean": round(float(cyc.min() / cyc.mean()), 3), "wg_kcycles_mean": round(float(cyc.mean()) / 1e3, 1),
+                  "wg_kcycles_max": round(float(cyc.max()) / 1e3, 1)}))
 """ % REPO
 
 name = next((a for a in sys.argv[1:] if not a.startswith("--")), "multiviewc_156x156x5")

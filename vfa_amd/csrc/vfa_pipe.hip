@@ -542,10 +542,18 @@ __device__ __forceinline__ void read_frags3(unsigned pa, bf16x8 &p0, bf16x8 &p1,
 // -- one per channel quarter, all in the registers of set 0 -- instead of eight of which every other one is empty (a barrier, and the
 // exposed landing of the next step's windows: ~3 100 cycles).  The LDS buffers alternate by quarter, the weight slice is reloaded
 // behind every step.  Same arithmetic in the same order as the eight-step form.
-template <int TERMS, bool DIAG, bool SMALL = false>
+// RT1: runs of ONE tile with three or more views (the order of rounds 3-5).  All sub-tiles of a group belong to one tile and a tile
+// is finished before the next begins, so the tile's sum can do what it did then: wait in the workspace between the groups (one
+// 32-row x 256-column slot per workgroup), come back into the registers of acc[1] in front of the group's LAST step -- set 0 is
+// complete there and r0 + r1 has moved into acc[0] -- and leave behind it; nothing is read back when the tile ends.  A template
+// parameter, not a branch on a.rt: the contribution code of the longer runs in the same loop body cost the step loop 3-5 %.
+// RTC: the run length as a compile-time fact (2 or 4; 0 = read from the arguments): the generator's loops over the tiles of a run
+// unroll and its state stays out of the pooling loops' registers (the tile-by-tile templates gained 2 % from the same).
+template <int TERMS, bool DIAG, bool SMALL = false, bool RT1 = false, int RTC = 0>
 __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
 {
     static_assert(!SMALL || TERMS != 6, "the four-step phase exists in the sixteen-wave layout only");
+    static_assert(!RT1 || (TERMS != 6 && !SMALL), "RT1: the sixteen-wave layout's eight-step phase");
     constexpr int kPS = SMALL ? 4 : 8, kPSh = SMALL ? 2 : 3; // steps of a phase; step i: phase i >> kPSh, position i & (kPS - 1)
     auto quarter_of = [](int k) { return SMALL ? k : k >> 1; }; // position k of a phase -> channel quarter (the LDS parity is k & 1 either way)
     // separate objects: one per role of the data (hipcc orders LDS-DMA against every LDS access it cannot prove disjoint)
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         tb = uniform_i(a.chunk_start[c0]); kb = uniform_i(a.chunk_rank[c0]);
         te = uniform_i(a.chunk_start[c1]); ke = uniform_i(a.chunk_rank[c1]);
     };
-    const int rt = a.rt;                // tiles of a run: 1, 2 or 4
+    const int rt = (RT1 || SMALL) ? 1 : (RTC ? RTC : a.rt); // tiles of a run: 1, 2 or 4 (a compile-time 1 in the tile-by-tile templates: their generator folds to one tile)
     int r_begin, k_begin, r_end, k_end; // runs of rt tiles, groups of a run (vfa_pipe_seq.h)
     range_of(lb, r_begin, k_begin, r_end, k_end);
     unsigned long long *wg_cycles = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(a.balance) + kBalCyclesAt) + lb;
@@ -1106,9 +1114,42 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
         // accumulators with uniform selects (x + 0 = x), stored, forgotten.  A version that summed in place under uniform branches
         // (the head tile's sum carried from the first pair to the second) left the compiler with sixteen-register values merging
         // at every join: it spilled whole accumulators and reloaded all sixteen registers once per element stored.
-        bool tile_open = false; // (four-step phase: the tile's sum so far sits in acc[2])
+        bool tile_open = false; // (four-step phase: the tile's sum so far sits in acc[2]; RT1: in the workspace slot)
+        auto rt1_begin = [&](const PhaseRec &ph) __attribute__((always_inline)) { // in front of the group's last step
+            const bool two = ph.nj() > 1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float r0 = relu_t(acc[0][i]), r1 = relu_t(acc[1][i]);
+                acc[0][i] = two ? r0 + r1 : r0;
+            }
+            const float *slot = a.slots + (size_t)lb * (8 * 16 * 64) + lane_off();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[1][i] = slot[i * 64]; // (always: what an unopened tile's slot holds is never used)
+        };
         auto group_finish = [&](const PhaseRec &ph) __attribute__((always_inline)) {
             const int nj = ph.nj(), sc = ph.scale();
+            if constexpr (RT1) {
+                // (sub-tiles 0, 1 summed into acc[0] and the tile's sum so far requested into acc[1] in front of the last step: rt1_begin)
+                const float inv = inv_sub(ph, 0);
+                const bool three = nj >= 3, four = nj >= 4, open = tile_open;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float g = acc[0][i];
+                    const float r2 = relu_t(acc[2][i]), r3 = relu_t(acc[3][i]);
+                    g = three ? g + r2 : g;
+                    g = four ? g + r3 : g;
+                    const float s0 = open ? acc[1][i] : 0.0f;
+                    if constexpr (F16) acc[0][i] = fmaf(g, inv, s0); // (g 2^-(ea+ew-shift) is exact: the same bits as multiply, then add)
+                    else acc[0][i] = s0 + g;
+                }
+                if (ph.more()) {
+                    float *slot = a.slots + (size_t)lb * (8 * 16 * 64) + lane_off();
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) slot[i * 64] = acc[0][i];
+                }
+                tile_open = ph.more();
+                return;
+            }
             if constexpr (SMALL) {
                 // Four-step phase (one or two views, runs of one tile): the products use acc[0], acc[1] only, so the tile's sum stays in
                 // acc[2] across its groups (one per scale) -- no contributions, nothing to read back.  Same values in the same order
@@ -1359,7 +1400,8 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 for (int i = 0; i < 16; ++i) acc[0][i] = acc[2][i];
                 emit_tile(0);
             }
-            if constexpr (!POOL && !SMALL) {
+            if constexpr (!POOL && RT1) emit_tile(0); // (the tile's sum is in acc[0]: group_finish)
+            if constexpr (!POOL && !SMALL && !RT1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores of the last group
                 // The contributions of the run as ONE flat sequence (tile, scale, index ascending), three loads in flight all the way
                 // (a batch per (tile, scale) was twelve exposed round trips per run: 85 us per finish on the five-layer MultiviewC frame)
@@ -1656,7 +1698,10 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                             // (not across the end of a GROUP: the code behind it needs the registers of the weight slice -- with the slice
                             // of the next group in them the compiler spilled whole accumulators around the contributions' stores)
                             // (the four-step phase has registers to spare -- acc[2], acc[3] carry no products -- and a light end of group)
-                            else if (nx.valid() && (SMALL || rec.layer() != a.nl - 1)) { w_set(nx.scale(), nx.layer(), 0); next_chunk = true; }
+                            else if (nx.valid() && (SMALL || RT1 || rec.layer() != a.nl - 1)) { w_set(nx.scale(), nx.layer(), 0); next_chunk = true; }
+                        }
+                        if constexpr (RT1 && J == kPS - 1) {
+                            if (rec.layer() == a.nl - 1) rt1_begin(rec);
                         }
                         multiply(std::integral_constant<int, SET>{}, rec, J, PAR, next_chunk);
                     }
@@ -1685,7 +1730,7 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
                 rec = nx;
                 ++n;
             }
-            if (!SMALL && group_ended && nx.valid()) { // the first weight slice of the next group: requested here, it lands under the stores below
+            if (!SMALL && !RT1 && group_ended && nx.valid()) { // the first weight slice of the next group: requested here, it lands under the stores below
                 w_set(nx.scale(), nx.layer(), 0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) w_load(ks);
@@ -2086,8 +2131,11 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
     }
     // (the tickets are clear: zeroed with the masks by the geometry call, and put back by the last arriver of every earlier launch)
     const bool small = n_views <= 2 && a.rt == 1; // (groups of at most two sub-tiles: the four-step phase)
+    const bool rt1 = n_views > 2 && a.rt == 1;    // (tile by tile: the tile's sum waits in a slot of the workspace between its groups)
     if (debug && small && !(debug & kDbgDumpVox)) // (diagnostic build of the default arithmetic)
         hipLaunchKernelGGL((pipe_kernel<2, true, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
+    else if (debug && rt1 && !(debug & kDbgDumpVox))
+        hipLaunchKernelGGL((pipe_kernel<2, true, false, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     else if (debug)
         hipLaunchKernelGGL((pipe_kernel<2, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     else if (terms == 4)
@@ -2100,6 +2148,12 @@ int vfa_pipe_collapse_relu_sum_f32(const float *const *integrals, const unsigned
         hipLaunchKernelGGL((pipe_kernel<3, false>), dim3(nblk), dim3(threads_of(3)), 0, s, a);
     else if (small)
         hipLaunchKernelGGL((pipe_kernel<2, false, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
+    else if (rt1)
+        hipLaunchKernelGGL((pipe_kernel<2, false, false, true>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
+    else if (a.rt == 2)
+        hipLaunchKernelGGL((pipe_kernel<2, false, false, false, 2>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
+    else if (a.rt == 4)
+        hipLaunchKernelGGL((pipe_kernel<2, false, false, false, 4>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     else
         hipLaunchKernelGGL((pipe_kernel<2, false>), dim3(nblk), dim3(threads_of(2)), 0, s, a);
     return (int)hipGetLastError();
