@@ -31,8 +31,22 @@ SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_IN
 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM
 GRBM_GUI_ACTIVE
 SETS
+# the same four passes on the shipped five-layer MultiviewC frame: the pipelined kernel where it ships (round-5 verdict: SQ_WAIT_ANY there)
+mkdir -p "$OUT/mc5"
+i=0
+while read -r SET; do
+  i=$((i+1))
+  timeout -s KILL 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/mc5/sq$i" -- python3 "$R/bench.py" --workload multiviewc_156x156x5 $SHORT > "$OUT/mc5/sq$i.log" 2>&1
+done <<'SETS'
+SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES
+SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM
+GRBM_GUI_ACTIVE
+SETS
 cd "$R"
 python3 tools/pmc_sq_summary.py "$OUT" "$OUT/fused_sq.json"
+python3 tools/pmc_sq_summary.py "$OUT/mc5" "$OUT/fused_sq_mc5.json"
+rm -rf "$OUT/mc5"/sq[0-9] "$OUT/mc5"/*.log; rmdir "$OUT/mc5" 2>/dev/null
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 find "$OUT/trace5" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_mc5.csv" \;
 rm -rf "$OUT/trace" "$OUT/trace5" "$OUT"/fetch* "$OUT"/write* "$OUT"/sq[0-9] "$OUT"/*.log

@@ -90,6 +90,13 @@ constexpr int kDbgDumpVox = 0x1000; // (set by VFA_FLAG_DUMP_VOX; bits 0-11 are 
 #ifndef VFA_PIPE_ABLATE
 #define VFA_PIPE_ABLATE 0
 #endif
+// wave priorities of the two roles (s_setprio): the pooling waves go first (measured: tools/ablate_pipe.sh EXTRA=-DVFA_PIPE_PRIO_...)
+#ifndef VFA_PIPE_PRIO_POOL
+#define VFA_PIPE_PRIO_POOL 1
+#endif
+#ifndef VFA_PIPE_PRIO_MAT
+#define VFA_PIPE_PRIO_MAT 0
+#endif
 constexpr int kAblate = VFA_PIPE_ABLATE;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1756,13 +1763,14 @@ __global__ __launch_bounds__(threads_of(TERMS)) void pipe_kernel(PipeArgs a)
     if (wave >= kMatWaves) {
         // the pooling wave is the busiest third of its SIMD and its step the longest: it goes first (its step head 150 against 500
         // cycles, pooling 3 800 against 4 000 without the priority)
-        if (!(DIAG && (a.debug & 8))) __builtin_amdgcn_s_setprio(1);
+        if (!(DIAG && (a.debug & 8))) __builtin_amdgcn_s_setprio(VFA_PIPE_PRIO_POOL);
         if constexpr (F16) fp16_saturate_mode(true); // (the pooling waves convert and never multiply; the matrix waves keep the default mode: vfa_split.h)
 #ifndef VFA_PIPE_NO_POOL
         run(std::true_type{});
 #endif
     } else {
         if (DIAG && (a.debug & 16)) __builtin_amdgcn_s_setprio(2);
+        else if (VFA_PIPE_PRIO_MAT) __builtin_amdgcn_s_setprio(VFA_PIPE_PRIO_MAT);
 #ifndef VFA_PIPE_NO_MAT
         run(std::false_type{});
 #endif

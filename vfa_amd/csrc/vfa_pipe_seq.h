@@ -49,17 +49,18 @@ VFA_SEQ_HD int seq_ctz(unsigned v) { return __builtin_ctz(v); }
 VFA_SEQ_HD int groups_of_count(int n_sub) { return (n_sub + kGroupViews - 1) / kGroupViews; }
 VFA_SEQ_HD int runs_of(int n_tiles, int rt) { return (n_tiles + rt - 1) / rt; }
 
-// Run length of a frame (measured, round 6, one MI355X; launch time of the frame kernel in us, rt = 1 / 2 / 4):
-//   seven cameras, MultiviewC 156 x 156 x 5     1 545 / 1 585 / 1 650     (tile by tile until round 5: 1 455)
-//   six cameras,   MultiviewX 160 x 250 x 8     3 475 / 3 255 / 3 315     (3 430)
-//   seven cameras, Wildtrack 120 x 360 x 8      3 840 / 3 810 / 3 785     (3 765)
-//   eight cameras, 512 x 512 x 32, one band     27 100 / 25 250 / 24 850   (27 000)
-//   one camera,    512 x 512 x 32               28 500 / 19 000 / 14 050   (four-step phase of rounds 4-5: 20 900)
-//   one camera,    MultiviewC 156 x 156 x 5     555 / 450 / 480            (four-step phase: 305)
+// Run length of a frame (measured, round 6, launch time of the frame kernel in us on one MI355X, rt = 1 / 2 / 4; round 5 = tile by tile):
+//   seven cameras, MultiviewC 156 x 156 x 5     1 470-1 590 / 1 585 / 1 650     (round 5: 1 445-1 575)
+//   six cameras,   MultiviewX 160 x 250 x 8     3 465 / 3 140-3 165 / 3 315    (3 400-3 420)
+//   seven cameras, Wildtrack 120 x 360 x 8      3 700 / 3 680-3 720 / 3 785    (3 695-3 700)
+//   eight cameras, 512 x 512 x 32, one band     27 100 / 25 250 / 23 300-23 350 (26 600-26 750)
+//   one camera,    512 x 512 x 32               28 500 / 19 000 / 13 400        (four-step phase of rounds 4-5: 20 700-20 850)
+//   one camera,    MultiviewC 156 x 156 x 5     341-353 (four-step) / 450 / 480 (four-step phase: 305-310)
 // Longer runs fill the groups (fewer steps: -12 % for seven cameras, -25 % for six, -75 % for one) and keep a workgroup on one
-// image for longer (the eight-camera frame has nothing to fill and still gains 8 %); they cost at the end of a run -- every
+// image for longer (the eight-camera frame has nothing to fill and still gains 12 %); they cost at the end of a run -- every
 // workgroup that holds groups of a run reads its contributions to ALL tiles of the run back, and a group, the unit of the work cuts,
-// gets no smaller --: what a frame can afford grows with the steps a workgroup has between two ends of runs.  Frames of one or two
+// gets no smaller --: what a frame can afford grows with the steps a workgroup has between two ends of runs.  Rigs of three and more
+// cameras on small frames keep the tile-by-tile order and its register-carried sums (pipe_kernel<.., RT1>); frames of one or two
 // views are a rank's share of a camera-sharded rig: big ones fill their groups from four tiles, small ones keep the four-step phase
 // (rt = 1, two sub-tiles per group at most: pipe_kernel<.., SMALL>).
 VFA_SEQ_HD int run_tiles_of(int n_views, int n_tiles, int n_scales, int nl, int n_blocks)
