@@ -393,14 +393,25 @@ def roofline_fused(g, workload, entry, live=None, terms=2):
     issued = products * per_launch * live_frac
     achieved = issued / avg_s / 1e12
     waves = "8 matrix waves + 4 pooling waves" if terms == 6 else "8 matrix waves + 8 pooling waves"
-    def _small(tag):  # (SMALL one- and two-view frames keep the four-step phase: vfa_pipe_seq.h run_tiles_of, restated)
+    def _variant(tag):
+        """Template arguments of the pipelined kernel this frame runs (vfa_pipe_seq.h: run_tiles_of and the launch in vfa_pipe.hip,
+        restated): the four-step phase (SMALL) for small one- and two-view frames, tile by tile (RT1) for small frames of three and
+        more views, else runs of 2 or 4 tiles as a template argument."""
         nv, L, W, nl, hws = tag
         tiles = ((L + 3) // 4) * ((W + 7) // 8)
         nblk = (min(256, tiles) + 7) // 8 * 8
-        return nv <= 2 and 2 * nl * nv * len(hws) * tiles // nblk < 1000
-    small = pipe and all(_small(tag) for tag in g["by_tag"])
-    kernel_id = (f"pipe_kernel<{terms}, false, {'true' if small else 'false'}>" if pipe else f"pool_collapse_kernel<{terms}, false, false>")
-    kname = (f"{kernel_id} (persistent; {waves} per CU: box pooling from LDS tap windows beside the {label}-split MFMA "
+        steps = 2 * nl * nv * len(hws) * tiles // nblk
+        rt = (4 if steps >= 1000 else 1) if nv <= 2 else (4 if steps >= 4000 else (2 if steps >= 1200 else 1))
+        forced = os.environ.get("VFA_AMD_PIPE_RT")
+        rt = int(forced) if forced in ("1", "2", "4") else rt
+        if terms == 6 or terms == 4:
+            return "false, false, 0", rt
+        if rt == 1:
+            return ("true, false, 0" if nv <= 2 else "false, true, 0"), rt
+        return ("false, false, 0", rt) if terms == 3 else (f"false, false, {rt}", rt)
+    variants = sorted({_variant(tag) for tag in g["by_tag"]}) if pipe else []
+    kernel_id = (f"pipe_kernel<{terms}, false, {variants[0][0]}>" if pipe else f"pool_collapse_kernel<{terms}, false, false>")
+    kname = (f"{kernel_id} (runs of {variants[0][1]} tile(s); persistent; {waves} per CU: box pooling from LDS tap windows beside the {label}-split MFMA "
              "collapse of the previous 64 rows x 64 channels; accumulators of four (tile, view) sub-tiles in registers across all z-layers; "
              "bias + ReLU + view / scale sum)") if pipe else \
             (f"pool_collapse_kernel<{terms}, false, false> (persistent, one launch per frame: box pooling of all views x scales from LDS "
