@@ -1507,9 +1507,13 @@ inline WorkspaceLayout layout_of(int n_views, int L, int W, int n_scales)
     off = align_up(off + 512 * 8 * sizeof(unsigned long long), 256); // diagnostic build: 8 counters per workgroup
     // pooled rows of the direct items: room for a quarter of all (view, tile, scale) items, at most 256 MiB; the rest (none on the
     // BASELINE frames: 3 % of the items of the bench frame are direct) goes through the second launch
+    // Round 6: where a row slot for EVERY item costs at most 1 GiB (the bench frame: 26 250 items, 860 MB of address space of which
+    // the 3-4 % direct items are ever touched) the workspace has them all: no item can be left without one, and the frame call
+    // drops the second launch (4 us of an empty kernel + a dependent-launch gap per frame).
     const size_t items = (size_t)n_views * w.n_tiles * n_scales;
     size_t cap = items / 4 + 64;
     if (cap > 8192) cap = 8192;
+    if (items * (size_t)(kTileBoxes * kC * sizeof(float)) <= ((size_t)1 << 30)) cap = items;
     if (cap > items) cap = items;
     w.rows_cap = (int)cap;
     w.row_list = off;
@@ -1808,6 +1812,7 @@ int vfa_pool_collapse_relu_sum_f32(const float *const *integrals, const unsigned
         hipLaunchKernelGGL((pool_collapse_kernel<2, false, false>), dim3(nblk), dim3(kThreads), 0, s, a);
     int st = (int)hipGetLastError();
     if (st || debug) return st;
+    if ((size_t)rows_cap >= (size_t)n_views * lay.n_tiles * n_scales) return st; // (every item has a row slot: nothing can be left over)
     // the few items whose tap window does not fit LDS: same kernel, taps straight from the image, ADDED to the map (the
     // launch leaves at once where there are none)
     if (terms == 4)
