@@ -29,7 +29,12 @@
 #include "vfa_split.h"
 
 #ifndef VFA_TICKET_ORDER
-#define VFA_TICKET_ORDER __ATOMIC_ACQ_REL // (the hand-off ticket of a tile cut between workgroups: see finish_tile / flush)
+// The hand-off ticket of a tile cut between workgroups (flush): a RELAXED agent-scope add by one lane behind a workgroup barrier.
+// Every handed-off byte is stored `sc1` behind the storing wave's vmcnt(0) and read `sc1` behind the return of the add: the guide's
+// measured-valid form (MI355X_MICROARCH.md, inter-workgroup visibility, first row).  Until round 6 the add was acquire-release: a
+// `buffer_wbl2 sc1` (the XCD's L2 written back) + `buffer_inv sc1` per hand-off that the sc1 discipline makes redundant
+// (vfa_pipe.hip has the measurement).  -DVFA_TICKET_ORDER=__ATOMIC_ACQ_REL restores it.
+#define VFA_TICKET_ORDER __ATOMIC_RELAXED
 #endif
 
 namespace {
@@ -980,8 +985,8 @@ __global__ __launch_bounds__(kThreads) void pool_collapse_kernel(FusedArgs a)
             if (!(at_begin || at_end)) {
                 write_tile(pend_tile, sum, true);
             } else {
-                // every part goes to the workspace (sc1 stores, every storing wave drained, then one acquire-release ticket per
-                // workgroup at agent scope: vfa_pipe.hip, finish_tile); the last arriver adds the parts in workgroup order -- one
+                // every part goes to the workspace (sc1 stores, every storing wave drained, then one ticket per workgroup at agent
+                // scope -- VFA_TICKET_ORDER at the head of this file --: vfa_pipe.hip, finish_run); the last arriver adds the parts in workgroup order -- one
                 // fixed association -- and stores the tile
                 const int which = at_begin ? 0 : 1;
                 float *pp = a.partial + (((size_t)lb * 2 + which) * 8 + wave) * 16 * 64 + lane;

@@ -35,7 +35,14 @@
 #include "vfa_split.h"
 
 #ifndef VFA_TICKET_ORDER
-#define VFA_TICKET_ORDER __ATOMIC_ACQ_REL // (the hand-off ticket of a tile cut between workgroups: see finish_tile / flush)
+// The hand-off ticket of a run cut between workgroups (finish_run): a RELAXED agent-scope add.  Every byte handed off is stored `sc1`
+// by the wave that signals for it, behind that wave's own vmcnt(0), and read `sc1` by the wave whose add came last, behind the
+// return of that add: the guide's measured-valid form (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the table) with
+// "workgroup" read as "wave" -- each matrix wave hands off its own 32 columns.  Rounds 3-5 drew ONE acquire-release ticket per
+// workgroup; with a ticket per wave that order cost a `buffer_wbl2 sc1` + `buffer_inv sc1` (the XCD's L2 written back, the CU's L1
+// invalidated) in each of the eight matrix waves of every workgroup at both ends of its range: 100 K cycles per workgroup on the
+// one-camera five-layer frame (613 K -> 5xx K), the whole cost of "finish" there.  -DVFA_TICKET_ORDER=__ATOMIC_ACQ_REL restores it.
+#define VFA_TICKET_ORDER __ATOMIC_RELAXED
 #endif
 
 namespace {
