@@ -401,7 +401,7 @@ def roofline_fused(g, workload, entry, live=None, terms=2):
         tiles = ((L + 3) // 4) * ((W + 7) // 8)
         nblk = (min(256, tiles) + 7) // 8 * 8
         steps = 2 * nl * nv * len(hws) * tiles // nblk
-        rt = (4 if steps >= 1000 else 1) if nv <= 2 else (4 if steps >= 4000 else (2 if steps >= 1200 else 1))
+        rt = (4 if steps >= 250 else 1) if nv <= 2 else (4 if steps >= 1600 else (2 if steps >= 1200 else 1))
         forced = os.environ.get("VFA_AMD_PIPE_RT")
         rt = int(forced) if forced in ("1", "2", "4") else rt
         if terms == 6 or terms == 4:

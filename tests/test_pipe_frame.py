@@ -481,7 +481,7 @@ def test_pipe_work_cuts_match_the_serial_restatement():
     nblk = min(256, tiles)
     nblk = (nblk + 7) // 8 * 8
     steps = 2 * nl * n * ns * tiles // nblk
-    RUN = (4 if steps >= 1000 else 1) if n <= 2 else (4 if steps >= 4000 else (2 if steps >= 1200 else 1))
+    RUN = (4 if steps >= 250 else 1) if n <= 2 else (4 if steps >= 1600 else (2 if steps >= 1200 else 1))
     forced = os.environ.get("VFA_AMD_PIPE_RT")
     RUN = int(forced) if forced in ("1", "2", "4") else RUN
     runs = (tiles + RUN - 1) // RUN

@@ -50,12 +50,14 @@ VFA_SEQ_HD int groups_of_count(int n_sub) { return (n_sub + kGroupViews - 1) / k
 VFA_SEQ_HD int runs_of(int n_tiles, int rt) { return (n_tiles + rt - 1) / rt; }
 
 // Run length of a frame (measured, round 6, launch time of the frame kernel in us on one MI355X, rt = 1 / 2 / 4; round 5 = tile by tile):
-//   seven cameras, MultiviewC 156 x 156 x 5     1 470-1 590 / 1 585 / 1 650     (round 5: 1 445-1 575)
-//   six cameras,   MultiviewX 160 x 250 x 8     3 465 / 3 140-3 165 / 3 315    (3 400-3 420)
-//   seven cameras, Wildtrack 120 x 360 x 8      3 700 / 3 680-3 720 / 3 785    (3 695-3 700)
-//   eight cameras, 512 x 512 x 32, one band     27 100 / 25 250 / 23 300-23 350 (26 600-26 750)
-//   one camera,    512 x 512 x 32               28 500 / 19 000 / 13 400        (four-step phase of rounds 4-5: 20 700-20 850)
-//   one camera,    MultiviewC 156 x 156 x 5     341-353 (four-step) / 450 / 480 (four-step phase: 305-310)
+//   seven cameras, MultiviewC 156 x 156 x 5     1 456-1 488 / 1 470-1 490 / 1 468-1 475   (round 5: 1 445-1 575)
+//   six cameras,   MultiviewX 160 x 250 x 8     3 376-3 381 / 3 125-3 136 / 3 135-3 149    (3 400-3 420)
+//   seven cameras, Wildtrack 120 x 360 x 8      3 746-3 864 / 3 666-3 719 / 3 570-3 595    (3 695-3 790)
+//   eight cameras, 512 x 512 x 32, one band     27 100 / 25 250 / 23 300-23 350            (26 600-26 750)
+//   one camera,    512 x 512 x 32               28 500 / 19 000 / 13 400                   (four-step phase of rounds 4-5: 20 700-20 850)
+//   one camera,    Wildtrack 120 x 360 x 8      606 (four-step) / 646 / 596                (625)
+//   one camera,    MultiviewC 156 x 156 x 5     285 (four-step) / 314 / 317                (305)
+//   two cameras,   MultiviewC 156 x 156 x 5     488 (four-step) / 474 / 494                (485)
 // Longer runs fill the groups (fewer steps: -12 % for seven cameras, -25 % for six, -75 % for one) and keep a workgroup on one
 // image for longer (the eight-camera frame has nothing to fill and still gains 12 %); they cost at the end of a run -- every
 // workgroup that holds groups of a run reads its contributions to ALL tiles of the run back, and a group, the unit of the work cuts,
@@ -66,8 +68,8 @@ VFA_SEQ_HD int runs_of(int n_tiles, int rt) { return (n_tiles + rt - 1) / rt; }
 VFA_SEQ_HD int run_tiles_of(int n_views, int n_tiles, int n_scales, int nl, int n_blocks)
 {
     const long long steps = 2ll * nl * n_views * n_scales * n_tiles / (n_blocks > 0 ? n_blocks : 1); // per workgroup, full groups
-    if (n_views <= 2) return steps >= 1000 ? kRunTiles : 1;
-    return steps >= 4000 ? kRunTiles : (steps >= 1200 ? 2 : 1);
+    if (n_views <= 2) return steps >= 250 ? kRunTiles : 1;
+    return steps >= 1600 ? kRunTiles : (steps >= 1200 ? 2 : 1);
 }
 
 // sub-tile j of a group in byte j of `subs`: view in bits 0-4, tile offset inside the run in bits 5-6
