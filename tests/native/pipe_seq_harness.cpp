@@ -21,41 +21,26 @@ struct HostMasks {
 
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s (seed %u)\n", __FILE__, __LINE__, #c, seed); return 1; } } while (0)
 
-static void counts_of(const std::vector<unsigned> &live, int n_tiles, int n_scales, int rt, int run, int *counts, int &tiles)
-{
-    tiles = 0;
-    for (int s = 0; s < 3; ++s) counts[s] = 0;
-    for (int off = 0; off < rt; ++off) {
-        const int t = run * rt + off;
-        if (t >= n_tiles) break;
-        ++tiles;
-        for (int s = 0; s < n_scales; ++s) counts[s] += __builtin_popcount(live[(size_t)s * n_tiles + t]);
-    }
-}
-
-// serial restatement of pipe_cuts_kernel: chunk c starts at the group (start[c], rank[c]) -- start in RUNS
-static void serial_cuts(const std::vector<unsigned> &live, int n_tiles, int n_scales, int nl, int rt, int n_chunks, std::vector<int> &start,
-                        std::vector<int> &rank)
+// serial restatement of pipe_cuts_kernel: chunk c starts at the group (start[c], rank[c]) -- start in RUNS; `subcost[s][tile * n_views + view]`
+// = the sub-tile's cost over its layers (what pipe_records_kernel adds up)
+static void serial_cuts(const std::vector<unsigned> &live, const std::vector<unsigned> &subcost, int n_tiles, int n_views, int n_scales, int nl, int rt,
+                        int n_chunks, std::vector<int> &start, std::vector<int> &rank)
 {
     const int n_runs = runs_of(n_tiles, rt);
+    auto mask_of = [&](int r) { return [&, r](int s, int off) { return r * rt + off < n_tiles ? live[(size_t)s * n_tiles + r * rt + off] : 0u; }; };
+    auto cost_of = [&](int r) { return [&, r](int s, int off, int v) { return subcost[((size_t)s * n_tiles + r * rt + off) * n_views + v]; }; };
+    auto tiles_of = [&](int r) { return n_tiles - r * rt < rt ? n_tiles - r * rt : rt; };
     std::vector<unsigned long long> before(n_runs + 1, 0);
-    for (int r = 0; r < n_runs; ++r) {
-        int counts[3], tiles;
-        counts_of(live, n_tiles, n_scales, rt, r, counts, tiles);
-        before[r + 1] = before[r] + walk_run(counts, n_scales, nl, 0u, tiles, [](int, unsigned, unsigned) {});
-    }
+    for (int r = 0; r < n_runs; ++r) before[r + 1] = before[r] + walk_run(n_scales, rt, nl, tiles_of(r), mask_of(r), cost_of(r), [](int, unsigned, unsigned) {});
     const unsigned long long total = before[n_runs];
     start.assign(n_chunks + 1, n_runs);
     rank.assign(n_chunks + 1, 0);
     auto pos_of = [&](long long c) { return (total * (unsigned long long)c + n_chunks - 1) / n_chunks; };
     long long c = 0;
     for (int r = 0; r < n_runs; ++r) {
-        int counts[3], tiles;
-        counts_of(live, n_tiles, n_scales, rt, r, counts, tiles);
         const unsigned long long tb = before[r];
-        int n_groups = 0;
-        walk_run(counts, n_scales, nl, 0u, tiles, [&](int k, unsigned, unsigned) { n_groups = k + 1; });
-        const unsigned w = walk_run(counts, n_scales, nl, 0u, tiles, [&](int kk, unsigned w0, unsigned w1) {
+        const int n_groups = groups_of_run(n_scales, rt, mask_of(r));
+        const unsigned w = walk_run(n_scales, rt, nl, tiles_of(r), mask_of(r), cost_of(r), [&](int kk, unsigned w0, unsigned w1) {
             while (c < n_chunks) {
                 const unsigned long long pc = pos_of(c);
                 if (pc >= tb + w1) break;
@@ -91,19 +76,23 @@ int main(int argc, char **argv)
             if (density == 1 && rng() % 3 == 0) x = 0;
             if (density == 2) x = vm;
         }
-        // the cost walk and the generator agree on the number of groups of every run, and a run's groups are full except the last
-        // one of a scale
+        // a sub-tile's cost over its layers, as the geometry pass would add it up (any value: the cuts only weigh with it)
+        std::vector<unsigned> subcost((size_t)n_scales * n_tiles * n_views);
+        for (auto &x : subcost) x = (unsigned)nl * (188u + rng() % 1200u);
+        // the cost walk, the mask-only count and the generator agree on the number of groups of every run, and a run's groups are
+        // full except the last one of a scale
         for (int r = 0; r < n_runs; ++r) {
-            int counts[3], tiles, n_cost = 0;
-            counts_of(live, n_tiles, n_scales, rt, r, counts, tiles);
-            walk_run(counts, n_scales, nl, 0u, tiles, [&](int k, unsigned, unsigned) { n_cost = k + 1; });
+            auto mask = [&](int s, int off) { return r * rt + off < n_tiles ? live[(size_t)s * n_tiles + r * rt + off] : 0u; };
+            int n_cost = 0;
+            walk_run(n_scales, rt, nl, 1, mask, [&](int s, int off, int v) { return subcost[((size_t)s * n_tiles + r * rt + off) * n_views + v]; },
+                     [&](int k, unsigned, unsigned) { n_cost = k + 1; });
             int last_scale = -1, last_nj = 4;
-            const int n_gen = walk_groups(n_scales, rt, 0, [&](int s, int off) { return r * rt + off < n_tiles ? live[(size_t)s * n_tiles + r * rt + off] : 0u; },
+            const int n_gen = walk_groups(n_scales, rt, 0, mask,
                                           [&](int, int s, unsigned, int nj, int) { if (s == last_scale && last_nj != 4) std::abort(); last_scale = s; last_nj = nj; });
-            CHECK(n_cost == n_gen);
+            CHECK(n_cost == n_gen && groups_of_run(n_scales, rt, mask) == n_gen);
         }
         std::vector<int> start, rank;
-        serial_cuts(live, n_tiles, n_scales, nl, rt, n_chunks, start, rank);
+        serial_cuts(live, subcost, n_tiles, n_views, n_scales, nl, rt, n_chunks, start, rank);
         CHECK(start[0] == 0 && rank[0] == 0);
         CHECK(start[n_chunks] == n_runs && rank[n_chunks] == 0);
         // (tile, scale, view) -> count of (layer, q) visits

@@ -486,20 +486,27 @@ def test_pipe_work_cuts_match_the_serial_restatement():
     RUN = int(forced) if forced in ("1", "2", "4") else RUN
     runs = (tiles + RUN - 1) // RUN
 
-    def groups_of(r):  # costs of the groups of run r in (scale, tile, view) order (vfa_pipe_seq.h: group_cost, walk_run)
+    # cost of a sub-tile over its layers, as pipe_records_kernel adds it up from the headers it writes (vfa_pipe_seq.h: sub_layer_cost):
+    # live 366 + 2 per window slot (or + 500 when pooled from L2), without a live box 188; units of 16 cycles
+    hdrs = [host[lay["hdrs"][s]:lay["hdrs"][s] + tiles * nl * n * 32].view(np.uint32).reshape(tiles, nl, n, 8) for s in range(ns)]
+
+    def subcost(s, t, v):
+        h = hdrs[s][t, :, v]
+        lv, direct = (h[:, 0] & 1) == 1, (h[:, 0] & 2) == 2
+        return int(np.where(lv, 366 + np.where(direct, 500, 2 * h[:, 1].astype(np.int64)), 188).sum())
+
+    def groups_of(r):  # costs of the groups of run r in (scale, tile, view) order (vfa_pipe_seq.h: walk_run)
         out = []
         ts = range(r * RUN, min(tiles, (r + 1) * RUN))
         for s in range(ns):
-            left = sum(bin(int(live[s][t])).count("1") for t in ts)
-            while left > 0:
-                nj = min(left, 4)
-                sets = (nj + 1) // 2
-                out.append(4 * nl * (69 * sets + 46 * (2 - sets)) + 14 + ((36 * len(ts) + 4 * 35 * sum(int(globs[t]) for t in ts)) if not out else 0))
-                left -= nj
+            subs = [(t, v) for t in ts for v in range(n) if (int(live[s][t]) >> v) & 1]
+            for g0 in range(0, len(subs), 4):
+                grp = subs[g0:g0 + 4]
+                out.append(nl * (625 + (100 if len(grp) <= 2 else 0)) + 9 + sum(subcost(s, t, v) for t, v in grp) + (144 * len(ts) if not out else 0))
         return out
 
     costs = [groups_of(r) for r in range(runs)]
-    weight = [sum(c) if c else min(RUN, tiles - r * RUN) for r, c in enumerate(costs)]
+    weight = [sum(c) if c else 16 * min(RUN, tiles - r * RUN) for r, c in enumerate(costs)]
     before = np.concatenate([[0], np.cumsum(weight)])
     total = int(before[-1])
     exp_start, exp_rank = np.full(K + 1, runs, np.int32), np.zeros(K + 1, np.int32)

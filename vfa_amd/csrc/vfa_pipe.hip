@@ -123,6 +123,7 @@ struct RecordArgs {
     ScaleDims dims[kMaxScales];
     unsigned *live[kMaxScales];      // (n_tiles) bit v = view v has a live box in the tile, in any layer
     unsigned *globs;                 // (n_tiles) live (view, layer, scale) items whose tap window does not fit LDS
+    unsigned *subcost[kMaxScales];   // (n_tiles, n_views) estimated cost of the sub-tile over its layers (vfa_pipe_seq.h: sub_layer_cost)
     unsigned *shift[kMaxScales];     // (n_tiles) sliver shift of (tile, scale): the largest over its views, layers and visible boxes (vfa_geom.h)
     unsigned char *hdrs[kMaxScales];
     unsigned char *recs[kMaxScales];
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(kWave) void pipe_records_kernel(RecordArgs a)
             }
             live_any[s] = live_any[s] || any_live;
             if (any_live && direct) ++n_glob;
+            if (pair_ok && b == 0) atomicAdd(a.subcost[s] + (size_t)tile * a.n_views + view, sub_layer_cost(any_live, direct, n_slots)); // (the work cuts' weight)
             __syncthreads(); // the stage is reused
         }
     }
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(256) void pipe_split_weight_kernel(SplitArgs sa)
 struct CutArgs {
     const unsigned *live[kMaxScales];
     const unsigned *globs;
+    const unsigned *subcost[kMaxScales]; // (n_tiles, n_views): pipe_records_kernel
     int n_scales, n_tiles, n_views, nl, rt; // rt: tiles of a run (vfa_pipe_seq.h: run_tiles_of)
     int *chunk_start, *chunk_rank;
     unsigned long long *chunk_cost; // (kChunks + 1): estimated cost of everything in front of the group boundary a piece starts at
@@ -340,27 +343,22 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
     const int tid = threadIdx.x, n_tiles = a.n_tiles, rt = a.rt, n_runs = runs_of(n_tiles, rt);
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
     const int per = (n_runs + 1023) / 1024, r0 = min(n_runs, tid * per), r1 = min(n_runs, r0 + per);
-    // live sub-tiles of (run, scale), the run's tiles and its items pooled from L2
-    auto counts_of = [&](int r, int *cnt, int &tiles, unsigned &globs) {
-        tiles = min(rt, n_tiles - r * rt);
-        globs = 0u;
-#pragma unroll
-        for (int s = 0; s < kMaxScales; ++s) cnt[s] = 0;
-        for (int off = 0; off < tiles; ++off) {
+    // the masks and the sub-tile costs of a run (vector loads: L2 hits, the geometry pass has just written them)
+    auto mask_of = [&](int r) {
+        return [&, r](int s2, int off) -> unsigned {
             const int t = r * rt + off;
-            globs += a.globs[t];
-#pragma unroll
-            for (int s = 0; s < kMaxScales; ++s)
-                if (s < a.n_scales) cnt[s] += __popc(a.live[s][t] & view_mask);
-        }
+            const unsigned *lv = s2 == 0 ? a.live[0] : (s2 == 1 ? a.live[1] : a.live[2]);
+            return t < n_tiles ? (lv[t] & view_mask) : 0u;
+        };
+    };
+    auto cost_of = [&](int r) {
+        return [&, r](int s2, int off, int v) -> unsigned {
+            const unsigned *sc = s2 == 0 ? a.subcost[0] : (s2 == 1 ? a.subcost[1] : a.subcost[2]);
+            return sc[(size_t)(r * rt + off) * a.n_views + v];
+        };
     };
     unsigned long long local = 0;
-    for (int r = r0; r < r1; ++r) {
-        int cnt[kMaxScales], tiles;
-        unsigned globs;
-        counts_of(r, cnt, tiles, globs);
-        local += walk_run(cnt, a.n_scales, a.nl, globs, tiles, [](int, unsigned, unsigned) {});
-    }
+    for (int r = r0; r < r1; ++r) local += walk_run(a.n_scales, rt, a.nl, min(rt, n_tiles - r * rt), mask_of(r), cost_of(r), [](int, unsigned, unsigned) {});
     part[tid] = local;
     for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_runs; a.chunk_rank[c] = 0; a.chunk_cost[c] = ~0ull; }
     __syncthreads();
@@ -379,12 +377,8 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
         const unsigned long long tb = before;
         long long c = tb > 0 ? (long long)((tb - 1) * kChunks / total) : 0;
         while (c < kChunks && pos_of(c) < tb) ++c;
-        int cnt[kMaxScales], tiles;
-        unsigned globs;
-        counts_of(r, cnt, tiles, globs);
-        int n_groups = 0;
-        walk_run(cnt, a.n_scales, a.nl, globs, tiles, [&](int kk, unsigned, unsigned) { n_groups = kk + 1; });
-        const unsigned w = walk_run(cnt, a.n_scales, a.nl, globs, tiles, [&](int kk, unsigned w0, unsigned w1) {
+        const int n_groups = groups_of_run(a.n_scales, rt, mask_of(r));
+        const unsigned w = walk_run(a.n_scales, rt, a.nl, min(rt, n_tiles - r * rt), mask_of(r), cost_of(r), [&](int kk, unsigned w0, unsigned w1) {
             while (c < kChunks) {
                 const unsigned long long pc = pos_of(c);
                 if (pc >= tb + w1) break;
@@ -1871,7 +1865,7 @@ inline int pipe_blocks(int n_tiles, int reserved_cus)
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct PipeLayout {
-    size_t live[kMaxScales], shifts[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, costs, partial, slots, diag, balance, wmax, wexp, amax, total;
+    size_t live[kMaxScales], shifts[kMaxScales], subcost[kMaxScales], tickets, globs, masks_bytes, hdrs[kMaxScales], recs[kMaxScales], wfrag[kMaxScales], chunks, ranks, costs, partial, slots, diag, balance, wmax, wexp, amax, total;
     int tiles_l, tiles_w, n_tiles;
 };
 inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
@@ -1893,6 +1887,10 @@ inline PipeLayout layout_of(int n_views, int L, int W, int nl, int n_scales)
     off = align_up(off + (size_t)w.n_tiles * 8 * 4, 256);
     w.globs = off;
     off = align_up(off + (size_t)w.n_tiles * 4, 256);
+    for (int s = 0; s < kMaxScales; ++s) { // (zeroed with the masks: the geometry pass adds the sub-tiles' costs up)
+        w.subcost[s] = off;
+        off = align_up(off + (s < n_scales ? (size_t)w.n_tiles * n_views * 4 : 0), 256);
+    }
     w.masks_bytes = off;
     const size_t items = (size_t)w.n_tiles * nl * n_views;
     for (int s = 0; s < kMaxScales; ++s) {
@@ -1992,6 +1990,7 @@ int vfa_pipe_boxes_f32(const float *calibs, const float *grid, const float *z_la
         if ((unsigned long long)(a.dims[k].Hf + 2) * (a.dims[k].Wf + 2) * kSlotBytes >= (1ull << 32)) return VFA_ERR_UNSUPPORTED;
         a.live[k] = reinterpret_cast<unsigned *>(ws + lay.live[k]);
         a.shift[k] = reinterpret_cast<unsigned *>(ws + lay.shifts[k]);
+        a.subcost[k] = reinterpret_cast<unsigned *>(ws + lay.subcost[k]);
         a.hdrs[k] = ws + lay.hdrs[k];
         a.recs[k] = ws + lay.recs[k];
     }
@@ -2019,6 +2018,7 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
     CutArgs ca;
     for (int k = 0; k < kMaxScales; ++k) ca.live[k] = reinterpret_cast<const unsigned *>(ws + lay.live[k < n_scales ? k : 0]);
     ca.globs = reinterpret_cast<const unsigned *>(ws + lay.globs);
+    for (int k = 0; k < kMaxScales; ++k) ca.subcost[k] = reinterpret_cast<const unsigned *>(ws + lay.subcost[k < n_scales ? k : 0]);
     ca.n_scales = n_scales; ca.n_tiles = lay.n_tiles; ca.n_views = n_views; ca.nl = n_layers;
     ca.rt = frame_run_tiles(n_views, lay.n_tiles, n_scales, n_layers);
     ca.chunk_start = reinterpret_cast<int *>(ws + lay.chunks);

@@ -219,40 +219,52 @@ struct Sequencer {
 
 // ------------------------------------------------------------------------------------------------
 // work cuts: the groups of the frame in (run, scale, tile, view) order, cut into `n_chunks` pieces of equal estimated cost.
-// Cost model in units of 64 cycles, fitted to the per-workgroup cycle counts of the diagnostic build of the sixteen-wave kernel on
-// the bench frame and three multi-layer frames (tools/bench_pipe.py --fit): a step with work 69, a step of an empty set 46 (it
-// still waits for the next step's window), a sub-tile pooled from L2 instead of an LDS window + 35 per step, + 14 per group
-// (weight reloads, the contributions to the tile sums), + 36 per tile (its store).
+// Cost model, round 6 (tools/fit_pipe_cost.py: least squares of the cycles every workgroup of the production kernel took against what
+// it had to do, on the three shipped configs; the same terms within 1 % on all of them), in units of 16 cycles:
+//   per (group, layer), its eight steps whatever is in them (barriers, tables, weight slices)   625  (+ 100 when set 1 is empty)
+//   per sub-tile and layer with a live box (four quarter-steps of pooling + products)           366  + 2 per slot of its tap window
+//                                                                                                 or + 500 when it is pooled from L2
+//   per sub-tile and layer without one (the planes are zeroed, the products run)                188
+//   per group 9, per tile of the run (its store) 144 on the run's first group
+// The geometry pass (pipe_records_kernel) adds the per-layer terms of a sub-tile up: `subcost[scale][tile * n_views + view]`.
+// Rounds 3-5 priced a group by its view count alone (+ the tile's L2 items on its first group): heaviest workgroup 1.05-1.08 x the
+// mean on the shipped configs; this model leaves 1.01-1.02 in the fit.
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned kStepCost = 69, kEmptyStepCost = 46, kGlobStepCost = 35, kGroupCost = 14, kTileCost = 36, kEmptyCost = 1;
+constexpr unsigned kPhaseCost = 625, kPhaseSmallExtra = 100, kSubLiveCost = 366, kSubSlotCost = 2, kSubDirectCost = 500, kSubDeadCost = 188;
+constexpr unsigned kGroupCost = 9, kTileCost = 144, kEmptyCost = 16;
 
-VFA_SEQ_HD unsigned group_cost(int nj, int nl)
+VFA_SEQ_HD unsigned sub_layer_cost(bool live, bool direct, int n_slots)
 {
-    const unsigned sets = (unsigned)((nj + 1) >> 1);
-    return 4u * (unsigned)nl * (kStepCost * sets + kEmptyStepCost * (2u - sets)) + kGroupCost;
+    return live ? kSubLiveCost + (direct ? kSubDirectCost : kSubSlotCost * (unsigned)n_slots) : kSubDeadCost;
 }
 
-// walks the groups of a run: visit(k, w0, w1) for the k-th group covering [w0, w1) of the run's cost; `counts[s]` = live sub-tiles of
-// (run, scale s); `globs` = (view, layer, scale) items of the run that are pooled from L2 (charged to the first group); `tiles` =
-// tiles of the run.  Returns the run's cost.
-template <class Visit>
-VFA_SEQ_HD unsigned walk_run(const int *counts, int n_scales, int nl, unsigned globs, int tiles, Visit &&visit)
+// walks the groups of a run: visit(k, w0, w1) for the k-th group covering [w0, w1) of the run's cost; `mask(s, off)` as in
+// walk_groups, `subcost(s, off, view)` = the sub-tile's cost over all layers; `tiles` = tiles of the run.  Returns the run's cost.
+template <class Mask, class SubCost, class Visit>
+VFA_SEQ_HD unsigned walk_run(int n_scales, int rt, int nl, int tiles, Mask &&mask, SubCost &&subcost, Visit &&visit)
 {
     unsigned w = 0;
+    const int k = walk_groups(n_scales, rt, 0, mask, [&](int kk, int s, unsigned subs, int nj, int) {
+        unsigned wi = (unsigned)nl * (kPhaseCost + (nj <= 2 ? kPhaseSmallExtra : 0u)) + kGroupCost;
+        for (int j = 0; j < nj; ++j) wi += subcost(s, sub_tile_off(subs, j), sub_view(subs, j));
+        if (kk == 0) wi += kTileCost * (unsigned)tiles;
+        visit(kk, w, w + wi);
+        w += wi;
+    });
+    return k == 0 ? kEmptyCost * (unsigned)tiles : w;
+}
+
+// groups of a run from its masks alone
+template <class Mask>
+VFA_SEQ_HD int groups_of_run(int n_scales, int rt, Mask &&mask)
+{
     int k = 0;
     for (int s = 0; s < n_scales; ++s) {
-        int left = counts[s];
-        while (left > 0) {
-            const int nj = left < kGroupViews ? left : kGroupViews;
-            unsigned wi = group_cost(nj, nl);
-            if (k == 0) wi += kTileCost * (unsigned)tiles + 4u * kGlobStepCost * globs;
-            visit(k, w, w + wi);
-            w += wi;
-            ++k;
-            left -= nj;
-        }
+        int cnt = 0;
+        for (int off = 0; off < rt; ++off) cnt += seq_popc(mask(s, off));
+        k += groups_of_count(cnt);
     }
-    return k == 0 ? kEmptyCost * (unsigned)tiles : w;
+    return k;
 }
 
 } // namespace vfa_pipe
