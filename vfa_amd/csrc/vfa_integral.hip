@@ -300,11 +300,12 @@ __global__ __launch_bounds__(kOpThreads, 4) void integral_onepass_kernel(OnePass
         {
             // eight lanes = the 128 bytes of one (row, channel) of the strip, eight such lines per wave instruction: with a whole
             // line per LANE (64 lines per instruction, each touched by eight instructions) the address path of the CU, not its
-            // arithmetic, set the pace of the kernel
+            // arithmetic, set the pace of the kernel.  The 64 lines of a wave's eight loads are the lines of the WAVE ITSELF (line =
+            // thread of phase R): see the transpose below
             const int x4 = tid & 7;
 #pragma unroll
             for (int j = 0; j < kOpCols / 4; ++j) {
-                const int line = (tid >> 3) + 64 * j, row = line >> 4, ch = line & 15;
+                const int line = (tid & ~63) + 8 * j + ((tid & 63) >> 3), row = line >> 4, ch = line & 15;
                 buf[j] = *reinterpret_cast<const float4 *>(m.feat + ((size_t)v * C + c0 + ch) * plane + (size_t)min(y0 + row, H - 1) * W +
                                                            min(x0 + 4 * x4, W - 4)); // (W is a multiple of 4 on this path)
             }
@@ -332,18 +333,19 @@ __global__ __launch_bounds__(kOpThreads, 4) void integral_onepass_kernel(OnePass
             float *trow = tile + r * kOpRowPitch + c;
             {
                 // row-contiguous map: the strip as it was loaded -- thread (line, x quad) -- goes through LDS (512 lines of 33 floats:
-                // conflict-free both ways, the size of the tile) and comes back as this thread's own line (r, c) = line tid
+                // conflict-free both ways, the size of the tile) and comes back as this thread's own line (r, c) = line tid.  A wave
+                // loads ITS OWN 64 lines and their 64 x 33 floats are the four tile rows it writes in phase R: the transpose is private
+                // to the wave -- no barrier in it (two barriers per strip fewer: 90.6 -> 87.3 us per bench frame in one process, round
+                // 6); the barrier at the end of a strip keeps the other waves' phase S of the last tile in front of it.
                 float *raw = tile;
 #pragma unroll
                 for (int j = 0; j < kOpCols / 4; ++j) {
-                    float *p = raw + ((tid >> 3) + 64 * j) * 33 + 4 * (tid & 7);
+                    float *p = raw + ((tid & ~63) + 8 * j + ((tid & 63) >> 3)) * 33 + 4 * (tid & 7);
                     p[0] = cur[j].x; p[1] = cur[j].y; p[2] = cur[j].z; p[3] = cur[j].w;
                 }
-                lds_barrier();
 #pragma unroll
                 for (int j = 0; j < kOpCols / 4; ++j)
                     cur[j] = make_float4(raw[tid * 33 + 4 * j], raw[tid * 33 + 4 * j + 1], raw[tid * 33 + 4 * j + 2], raw[tid * 33 + 4 * j + 3]);
-                lds_barrier();
             }
             auto raw_of = [&](int k) {
                 const float4 q = cur[k / 4];
