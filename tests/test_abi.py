@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = ctypes.CDLL(built_lib)
     for name in _declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/vfa_hip.h but not exported"
-    assert lib.vfa_abi_version() == 8
+    assert lib.vfa_abi_version() == 9
     assert not hasattr(lib, "vfa_set_option")  # since ABI v2: tuning choices are per-call flags, the library keeps no state
 
 

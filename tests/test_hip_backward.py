@@ -134,16 +134,18 @@ def test_lds_scatter_matches_atomic_scatter_and_is_the_adjoint(workload, n_cam, 
     assert live.any()
     gvox = torch.where(live, gvox, torch.full_like(gvox, 1e30))  # masked voxels pass no gradient, whatever arrives
     grads = {}
-    for name, kern in (("lds", None), ("atomics", "direct")):  # a per-call flag of the entry point, no library state
+    gw = wl["grid"].shape[-2]  # cells per row of the ground grid: the scatter on 4 x 8 patches ("patches") instead of cells in a line
+    for name, kern, w_ in (("lds", None, 0), ("patches", None, gw), ("atomics", "direct", 0)):  # per-call arguments, no library state
         grads[name] = ops.project_gather_backward(gvox, tuple(integral.shape), calibs, grid, zl, co, kind, size,
-                                                  cell_begin=begin, cell_count=count, kernel=kern)
+                                                  cell_begin=begin, cell_count=count, kernel=kern, grid_w=w_)
         twice = ops.project_gather_backward(gvox, tuple(integral.shape), calibs, grid, zl, co, kind, size,
                                             cell_begin=begin, cell_count=count, out=grads[name].clone(),
-                                            accumulate=True, kernel=kern)
+                                            accumulate=True, kernel=kern, grid_w=w_)
         torch.testing.assert_close(twice, 2 * grads[name], rtol=1e-4, atol=1e-5 * grads[name].abs().max().item())
     scale = grads["atomics"].abs().max().item()
-    assert scale > 0 and torch.isfinite(grads["lds"]).all()
+    assert scale > 0 and torch.isfinite(grads["lds"]).all() and torch.isfinite(grads["patches"]).all()
     torch.testing.assert_close(grads["lds"], grads["atomics"], rtol=1e-4, atol=2e-5 * scale)
+    torch.testing.assert_close(grads["patches"], grads["atomics"], rtol=1e-4, atol=2e-5 * scale)
     lhs = (vox.double() * torch.where(live, gvox, torch.zeros_like(gvox)).double()).sum().item()
     rhs = (integral.double() * grads["lds"].double()).sum().item()
     norm = (vox.double().abs() * torch.where(live, gvox, torch.zeros_like(gvox)).double().abs()).sum().item()

@@ -19,7 +19,8 @@ calibs = wl["calibs"].reshape(n, 12).to(dev)
 grid = wl["grid"].reshape(-1, 3).to(dev)
 kind = _lib.CONV_KIND[wl["args"].data]
 size = wl["args"].image_size[::-1]
-modes = [("atomics", 0, 0), ("lds", 1, 0)]
+modes = [("atomics", 0, 0), ("lds, 32 in a line", 1, 0), ("lds, 4 x 8 patches", 1, 1)]
+gw = wl["grid"].shape[-2]
 for s in range(3):
     feat = torch.cat([wl["features"][c][s] for c in range(n)]).to(dev)
     Hf, Wf = feat.shape[-2:]
@@ -27,12 +28,12 @@ for s in range(3):
     line = [f"stride {8 << s} ({Hf}x{Wf})"]
     for name, cache, dbg in modes:
         for _ in range(2):
-            ops.project_gather_backward(gvox, (n, Hf + 2, Wf + 2, 256), calibs, grid, zl, co, kind, size, kernel=None if cache else 'direct')
+            ops.project_gather_backward(gvox, (n, Hf + 2, Wf + 2, 256), calibs, grid, zl, co, kind, size, kernel=None if cache else 'direct', grid_w=gw if dbg else 0)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            ops.project_gather_backward(gvox, (n, Hf + 2, Wf + 2, 256), calibs, grid, zl, co, kind, size, kernel=None if cache else 'direct')
+            ops.project_gather_backward(gvox, (n, Hf + 2, Wf + 2, 256), calibs, grid, zl, co, kind, size, kernel=None if cache else 'direct', grid_w=gw if dbg else 0)
         e1.record()
         torch.cuda.synchronize()
         line.append(f"{name} {e0.elapsed_time(e1) / 5 * 1e3:.0f} us")

@@ -5,10 +5,11 @@ import csv, glob, sys
 path = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-def last_of_frame(r):
+def frame_kernel(r):
     k = r["Kernel_Name"].replace(" ", "")
-    return ("pool_collapse_kernel" in k and "true>" in k) or "pipe_kernel" in k
-ends = [i for i, r in enumerate(rows) if last_of_frame(r)]
+    return "pool_collapse_kernel" in k or "pipe_kernel<" in k
+# (the serial kernel may be followed by its second launch -- the direct items without a row slot --: the frame ends with the last of them)
+ends = [i for i, r in enumerate(rows) if frame_kernel(r) and not (i + 1 < len(rows) and frame_kernel(rows[i + 1]))]
 last, prev = ends[-2], ends[-3]
 frame = rows[prev + 1:last + 1]
 t0 = min(int(r["Start_Timestamp"]) for r in frame)

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VFA_AMD_LIB") or os.path.join(_HERE, "csrc", "libvfa_hip.so")  # (override: A/B runs of two builds)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 CONV_KIND = {"MultiviewC": 0, "MultiviewX": 1, "Wildtrack": 2}
 VOX_REFERENCE, VOX_LAYER_MAJOR = 0, 1
@@ -46,6 +46,8 @@ SIGNATURES = {
                                   _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],
     "vfa_project_gather_backward_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],
+    "vfa_project_gather_backward_grid_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                             _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_float, _c_int, _vp],
     "vfa_integral_image_backward_f32": [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp],
     "vfa_relu_mask_backward_f32": [_vp, _vp, _vp, _vp, _vp, _c_int, _c_size_t, _c_int, _vp],
     "vfa_bias_relu_accumulate_f32": [_vp, _vp, _vp, _c_int, _c_size_t, _c_int, _c_int, _vp],

@@ -274,6 +274,9 @@ struct GatherDims {
     // tap-cache kernels: tile = (view, cell block, layer), layer fastest
     unsigned n_tiles;     // n_views * tiles_per_view
     FastDiv tiles_per_view, layers;
+    // backward tap cache: patches of 4 x 8 cells (grid_w > 0: cells per row of the ground grid; tile_row0 = first patch row the
+    // processed range touches, tiles_x = patches per grid row) or 32 cells in a line (grid_w == 0)
+    int grid_w, tile_row0, tiles_x;
 };
 
 // Per-box record staged in LDS by phase 1 of the gather kernel (32 words = 8 x ds_read_b128, broadcast to the wave).
@@ -770,26 +773,183 @@ __global__ __launch_bounds__(kWave) void gather_cached_kernel(const float *__res
     }
 }
 
-// Backward twin of gather_cached_kernel: the same tiles, records and hash set.  d integral[tap] of a tile is
+// Backward twin of gather_cached_kernel: the same records and hash set.  d integral[tap] of a tile of boxes is
 //   sum_box coef[tap][box] * grad_vox[box],   coef = the signed bilinear weights / area of the box's taps that hit `tap`,
-// an (n_taps x 8) matrix built once per tile in LDS.  A lane owns channels lane + 64 q: it keeps the 8 x 4 gradients of
-// the tile in registers, forms each distinct tap's row with 8 fmas per channel and issues ONE 256-byte atomic row per
-// distinct tap and 64-channel slice -- 3-8x fewer global atomics than the per-box scatter (which runs at the chip's
-// ~1.3 TB/s atomic rate), no LDS traffic in the channel loop beyond two broadcast reads per tap.
+// an (n_taps x boxes) matrix built once per tile in LDS.  A lane owns channels lane + 64 q: per 64-channel slice it keeps the
+// gradients of the tile's boxes in registers, forms each distinct tap's row with one fma per box and channel and issues ONE 256-byte
+// atomic row per distinct tap and slice -- no LDS traffic in the channel loop beyond the broadcast reads of a tap's coefficients.
+// The kernel runs at the chip's rate of float atomic rows (~1.3 TB/s), so what counts is how many distinct taps a tile has per box.
+// Round 6: a tile is a PATCH of 4 x 8 cells of the ground grid (vfa_project_gather_backward_grid_f32 tells the grid's width) instead
+// of 8 consecutive cells: neighbours share taps in both directions.  Bench frame, counted with the oracle's boxes: 1.74 / 0.89 / 0.49
+// distinct taps per box on strides 8 / 16 / 32 against 4.48 / 2.70 / 1.65 for 1 x 8 (32 cells in a line: 3.48 / 1.80 / 0.91).  The
+// hash set has 128 entries; a patch with more distinct taps (7 % on stride 8: boxes right in front of a camera) falls back to its
+// four rows of 8 (64 entries), those to the per-box scatter.  Without a grid width: 32 cells in a line.
+constexpr int kBwdBoxes = 32, kBwdHash = 128;
 struct BackwardLds {
-    BoxRec recs[kCacheBoxes];                 // only read by the fallback
-    unsigned tab[kCacheHash];
-    unsigned slot_key[kCacheHash];            // every hash entry can be a tap: the fallback is for > 64 distinct taps
-    unsigned char ids[kCacheHash];
-    float coef[kCacheHash][kCacheBoxes];
+    BoxRec recs[kBwdBoxes];
+    unsigned tab[kBwdHash];
+    unsigned slot_key[kBwdHash];
+    unsigned char ids[kBwdHash];
+    float coef[kBwdHash][kBwdBoxes];
 };
+// where the boxes of a tile sit: box b = (row b >> tw_shift, column b & (2^tw_shift - 1)) of the tile; its cell, local to the
+// processed range, is base_local + row * row_stride + column -- valid inside [0, cell_count) and left of the grid's right edge
+struct BwdTile {
+    long long base_local;
+    int row_stride, tw_shift, col0, col_lim;
+    __device__ __forceinline__ long long local_of(int b, int cell_count) const
+    {
+        const int ry = b >> tw_shift, cx = b & ((1 << tw_shift) - 1);
+        const long long lc = base_local + (long long)ry * row_stride + cx;
+        return (col0 + cx < col_lim && lc >= 0 && lc < cell_count) ? lc : -1;
+    }
+};
+
+// the boxes of one tile of (view, layer); false: more distinct taps than hash entries, nothing was added
+template <int NB, int HASH>
+__device__ __forceinline__ bool gather_backward_tile(BackwardLds &L, const BoxGeom &g, const GatherDims &d, int view, int layer, const BwdTile &tl,
+                                                     char *gimg, const char *gv_view, size_t box_pitch)
+{
+    constexpr int kPasses = NB / 8; // (box, corner) passes of the wave over the tile
+    static_assert(HASH == 64 || HASH == 128, "one or two hash entries per lane");
+    const int lane = threadIdx.x, b8 = lane >> 3, corner = lane & 7;
+    __syncthreads(); // (the LDS of a tile before this one is done with)
+    // ---- 1. box parameters: lane = (box, corner), eight boxes per pass; the records go to LDS
+    unsigned vis_bits = 0u; // bit b: box b is visible (wave-uniform)
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+        const int b = 8 * p + b8;
+        const long long lc = tl.local_of(b, d.cell_count);
+        const bool valid = lc >= 0;
+        float l, t, r, bt, area = 0.0f;
+        bool vis = false;
+        {
+            const int cell = d.cell_begin + (int)(valid ? lc : 0);
+            const float *P = g.calibs + (size_t)view * 12;
+            const float gx = g.grid[cell * 3 + 0] + 0.0f; // + the int64 zeros of z_corners (vfa_op.py:52, :64)
+            const float gy = g.grid[cell * 3 + 1] + 0.0f;
+            const float gz = g.grid[cell * 3 + 2] + g.z_layers[layer];
+            float nu, nv;
+            project_corner(g, P, gx, gy, gz, corner, nu, nv);
+            l = r = nu; t = bt = nv;
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) { // exact, order-insensitive (NaN propagates either way)
+                l = min_t(l, __shfl_xor(l, m));
+                r = max_t(r, __shfl_xor(r, m));
+                t = min_t(t, __shfl_xor(t, m));
+                bt = max_t(bt, __shfl_xor(bt, m));
+            }
+            area = box_area(l, t, r, bt, d.Hf, d.Wf);
+            vis = valid && box_visible(area, d.Hf, d.Wf);
+        }
+        unsigned key_x, key_y;
+        BoxRec rec;
+        fill_record(rec, view, l, t, r, bt, area, vis, d, key_x, key_y);
+        if (!valid) { rec.h.flags = 0; rec.h.masked = 0.0f; }
+        if (corner == 0) L.recs[b] = rec;
+        const unsigned long long bal = __ballot(vis); // lanes 8 k .. 8 k + 7 = box 8 p + k
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vis_bits |= (unsigned)((bal >> (8 * k)) & 1ull) << (8 * p + k);
+    }
+    if (vis_bits == 0u) return true; // masked voxels pass no gradient
+#pragma unroll
+    for (int e = 0; e < HASH / kWave; ++e) L.tab[lane + kWave * e] = kEmptyKey;
+    __syncthreads();
+
+    // ---- 2. distinct taps of the tile: lane (box, corner) owns taps 2*corner and 2*corner + 1 of its box
+    unsigned myh = 0u, myh2 = 0u; // hash entry of tap i of pass p: byte 2 p + i of myh (p < 2) / byte 2 (p - 2) + i of myh2
+    bool overflow = false;
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+        const int b = 8 * p + b8;
+        if ((vis_bits >> b) & 1u) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // tap = 2 * corner + i: row index corner >> 1, column index 2 * (corner & 1) + i
+                const int ri = corner >> 1, ci = 2 * (corner & 1) + i;
+                const unsigned key = L.recs[b].h.row[ri] + L.recs[b].h.col[ci];
+                unsigned h = ((key >> 10) * 2654435761u) >> (HASH == 64 ? 26 : 25);
+                int probes = 0;
+#pragma unroll 1
+                for (; probes < HASH; ++probes) { // bounded: a full table means "too many distinct taps"
+                    const unsigned old = atomicCAS(&L.tab[h], kEmptyKey, key);
+                    if (old == kEmptyKey || old == key) break;
+                    h = (h + 1) & (HASH - 1);
+                }
+                if (probes == HASH) overflow = true;
+                if (p < 2) myh |= h << (8 * (2 * p + i));
+                else myh2 |= h << (8 * (2 * (p - 2) + i));
+            }
+        }
+    }
+    __syncthreads();
+    if (__ballot(overflow) != 0ull) return false;
+    int n_slots = 0;
+#pragma unroll
+    for (int e = 0; e < HASH / kWave; ++e) { // dense slot ids in entry order
+        const unsigned mine = L.tab[lane + kWave * e];
+        const bool occ = mine != kEmptyKey;
+        const unsigned long long occ_mask = __ballot(occ);
+        const int my_id = n_slots + __popcll(occ_mask & ((1ull << lane) - 1ull));
+        if (occ) {
+            L.ids[lane + kWave * e] = (unsigned char)my_id;
+            L.slot_key[my_id] = mine;
+        }
+        n_slots += __popcll(occ_mask);
+    }
+    // ---- 3. coefficient matrix: lane (box, corner) adds its two taps (ds_add_f32)
+#pragma unroll
+    for (int e = 0; e < HASH / kWave; ++e)
+#pragma unroll
+        for (int k = 0; k < NB; ++k) L.coef[lane + kWave * e][k] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+        const int b = 8 * p + b8;
+        if ((vis_bits >> b) & 1u) {
+            const BoxWeights &w = L.recs[b].w;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ri = corner >> 1, ci = 2 * (corner & 1) + i, k = (ri & 1) * 2 + (ci & 1);
+                const bool top = ri < 2, left = ci < 2;
+                const float *arr = top ? (left ? w.lt : w.rt) : (left ? w.lb : w.rb);
+                const float wt = arr[k];
+                const unsigned h = ((p < 2 ? myh >> (8 * (2 * p + i)) : myh2 >> (8 * (2 * (p - 2) + i))) & 0xffu);
+                atomicAdd(&L.coef[L.ids[h]][b], (top == left ? wt : -wt) / w.area);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. lane = channel (+ 64 q): the gradients of a 64-channel slice in registers, one atomic row per distinct tap
+    const char *gv_layer = gv_view + (size_t)layer * 1024;
+    for (int q = 0; q < kCachePasses; ++q) {
+        float gv[NB];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) { // masked voxels pass no gradient (and may hold anything)
+            gv[bb] = 0.0f;
+            if ((vis_bits >> bb) & 1u)
+                gv[bb] = *reinterpret_cast<const float *>(gv_layer + (size_t)tl.local_of(bb, d.cell_count) * box_pitch + q * 256 + lane * 4);
+        }
+        for (int i = 0; i < n_slots; ++i) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k4 = 0; k4 < NB / 4; ++k4) {
+                const float4 cc = *reinterpret_cast<const float4 *>(&L.coef[i][4 * k4]);
+                a = fmaf(cc.x, gv[4 * k4 + 0], a); a = fmaf(cc.y, gv[4 * k4 + 1], a);
+                a = fmaf(cc.z, gv[4 * k4 + 2], a); a = fmaf(cc.w, gv[4 * k4 + 3], a);
+            }
+            unsafeAtomicAdd(reinterpret_cast<float *>(gimg + L.slot_key[i]) + lane + q * kWave, a);
+        }
+    }
+    return true;
+}
 
 __global__ __launch_bounds__(kWave) void gather_backward_cached_kernel(const float *__restrict__ grad_vox, BoxGeom g,
                                                                       GatherDims d, float *__restrict__ grad_integral)
 {
     __shared__ BackwardLds L;
     const int lane = threadIdx.x;
-    // A tile is 8 consecutive CELLS of one (view, layer): neighbouring cells of a layer are the boxes that share taps.
     // Tiles are numbered (view, cell block, layer) so that tiles running side by side touch the same image columns.
     const unsigned tile = (blockIdx.x & 7u) * (unsigned)d.per_xcd + (blockIdx.x >> 3); // xcd_contiguous, 32-bit
     if (tile >= d.n_tiles) return;
@@ -797,140 +957,42 @@ __global__ __launch_bounds__(kWave) void gather_backward_cached_kernel(const flo
     const unsigned tv = tile - (unsigned)view * d.tiles_per_view.d;
     const unsigned cb = fast_div(tv, d.layers);
     const int layer = (int)(tv - cb * d.layers.d);
-    const int cell0 = (int)cb * kCacheBoxes; // first cell (local to the processed range) of the tile
-    const int nb = min(kCacheBoxes, d.cell_count - cell0);
+    BwdTile tl;
+    if (d.grid_w > 0) { // a patch of 4 x 8 cells of the ground grid; cell block = (tile row of the range, tile column)
+        const unsigned tr = cb / (unsigned)d.tiles_x, tc = cb - tr * (unsigned)d.tiles_x;
+        tl.base_local = ((long long)d.tile_row0 + tr) * 4 * d.grid_w + 8ll * tc - d.cell_begin;
+        tl.row_stride = d.grid_w; tl.tw_shift = 3; tl.col0 = 8 * (int)tc; tl.col_lim = d.grid_w;
+    } else {            // 32 consecutive cells
+        tl.base_local = (long long)cb * kBwdBoxes;
+        tl.row_stride = 0; tl.tw_shift = 5; tl.col0 = 0; tl.col_lim = 0x7fffffff;
+    }
     const size_t img_stride = (size_t)(d.Hf + 2) * (d.Wf + 2) * d.C * sizeof(float);
     char *gimg = reinterpret_cast<char *>(grad_integral) + (size_t)view * img_stride;
-    // layer-major output: box (cell, layer) owns 1 KiB at ((view * cells + cell) * nl + layer) * 1024
+    // layer-major input: box (cell, layer) owns 1 KiB at ((view * cells + cell) * nl + layer) * 1024
     const size_t box_pitch = (size_t)d.nl * 1024;
-    const char *gv_tile = reinterpret_cast<const char *>(grad_vox) + (((size_t)view * d.cell_count + cell0) * d.nl + layer) * 1024;
-
-    // ---- 1. box parameters: lane = (box, corner)
-    const int b = lane >> 3, corner = lane & 7;
-    const bool valid = b < nb;
-    float l, t, r, bt, area = 0.0f;
-    bool vis = false;
-    {
-        const int cell = d.cell_begin + cell0 + (valid ? b : 0);
-        const float *P = g.calibs + (size_t)view * 12;
-        const float gx = g.grid[cell * 3 + 0] + 0.0f; // + the int64 zeros of z_corners (vfa_op.py:52, :64)
-        const float gy = g.grid[cell * 3 + 1] + 0.0f;
-        const float gz = g.grid[cell * 3 + 2] + g.z_layers[layer];
-        float nu, nv;
-        project_corner(g, P, gx, gy, gz, corner, nu, nv);
-        l = r = nu; t = bt = nv;
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) { // exact, order-insensitive (NaN propagates either way)
-            l = min_t(l, __shfl_xor(l, m));
-            r = max_t(r, __shfl_xor(r, m));
-            t = min_t(t, __shfl_xor(t, m));
-            bt = max_t(bt, __shfl_xor(bt, m));
-        }
-        area = box_area(l, t, r, bt, d.Hf, d.Wf);
-        vis = valid && box_visible(area, d.Hf, d.Wf);
-    }
-    unsigned key_x, key_y;
-    BoxRec rec;
-    fill_record(rec, view, l, t, r, bt, area, vis, d, key_x, key_y);
-    if (!valid) { rec.h.flags = 0; rec.h.masked = 0.0f; }
-    if (__ballot(vis) == 0ull) return; // masked voxels pass no gradient
-    if (corner == 0) L.recs[b] = rec;
-    L.tab[lane] = kEmptyKey;
-    __syncthreads();
-
-    // ---- 2. distinct taps of the tile: lane (box, corner) owns taps 2*corner and 2*corner + 1 of its box
-    int myh[2] = {0, 0};
-    bool overflow = false;
-    if (vis) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            // tap = 2 * corner + i: row index corner >> 1, column index 2 * (corner & 1) + i (selects, not indexing:
-            // a runtime index into the record would put it in scratch)
-            const int ri = corner >> 1, ci = 2 * (corner & 1) + i;
-            const unsigned rsel = ri == 0 ? rec.h.row[0] : (ri == 1 ? rec.h.row[1] : (ri == 2 ? rec.h.row[2] : rec.h.row[3]));
-            const unsigned csel = ci == 0 ? rec.h.col[0] : (ci == 1 ? rec.h.col[1] : (ci == 2 ? rec.h.col[2] : rec.h.col[3]));
-            const unsigned key = rsel + csel;
-            unsigned h = ((key >> 10) * 2654435761u) >> 26;
-            int probes = 0;
-#pragma unroll 1
-            for (; probes < kCacheHash; ++probes) { // bounded: a full table means "too many distinct taps"
-                const unsigned old = atomicCAS(&L.tab[h], kEmptyKey, key);
-                if (old == kEmptyKey || old == key) break;
-                h = (h + 1) & (kCacheHash - 1);
+    const char *gv_view = reinterpret_cast<const char *>(grad_vox) + (size_t)view * d.cell_count * box_pitch;
+    if (gather_backward_tile<kBwdBoxes, kBwdHash>(L, g, d, view, layer, tl, gimg, gv_view, box_pitch)) return;
+    for (int sub = 0; sub < kBwdBoxes / kCacheBoxes; ++sub) { // too many distinct taps: eight boxes at a time (a row of the patch)
+        BwdTile ts = tl;
+        ts.base_local = d.grid_w > 0 ? tl.base_local + (long long)sub * d.grid_w : tl.base_local + sub * kCacheBoxes;
+        ts.row_stride = 0; ts.tw_shift = 3;
+        if (gather_backward_tile<kCacheBoxes, kCacheHash>(L, g, d, view, layer, ts, gimg, gv_view, box_pitch)) continue;
+        // ---- still too many: per-box global atomics, lanes = 64 channels x 4 sweeps (the records of the eight are in LDS)
+        for (int j = 0; j < kCacheBoxes; ++j) {
+            const BoxRec &rc = L.recs[j];
+            if (!(uniform_i(rc.h.flags) & 1)) continue;
+            const BoxWeights w = rc.w;
+            const float *gvox = reinterpret_cast<const float *>(gv_view + (size_t)ts.local_of(j, d.cell_count) * box_pitch + (size_t)layer * 1024);
+            for (int c = lane; c < d.C; c += kWave) {
+                const float gv = gvox[c] / w.area;
+                auto add = [&](int ry, int cx, float wt) {
+                    unsafeAtomicAdd(reinterpret_cast<float *>(gimg + (rc.h.row[ry] + rc.h.col[cx])) + c, gv * wt);
+                };
+                add(0, 0, w.lt[0]); add(0, 1, w.lt[1]); add(1, 0, w.lt[2]); add(1, 1, w.lt[3]);
+                add(2, 2, w.rb[0]); add(2, 3, w.rb[1]); add(3, 2, w.rb[2]); add(3, 3, w.rb[3]);
+                add(0, 2, -w.rt[0]); add(0, 3, -w.rt[1]); add(1, 2, -w.rt[2]); add(1, 3, -w.rt[3]);
+                add(2, 0, -w.lb[0]); add(2, 1, -w.lb[1]); add(3, 0, -w.lb[2]); add(3, 1, -w.lb[3]);
             }
-            if (probes == kCacheHash) overflow = true;
-            myh[i] = (int)h;
-        }
-    }
-    __syncthreads();
-    const unsigned mine = L.tab[lane];
-    const bool occ = mine != kEmptyKey;
-    const unsigned long long occ_mask = __ballot(occ);
-    const int n_slots = __popcll(occ_mask);
-    const int my_id = __popcll(occ_mask & ((1ull << lane) - 1ull));
-    const bool cached = __ballot(overflow) == 0ull;
-    if (occ && cached) {
-        L.ids[lane] = (unsigned char)my_id;
-        L.slot_key[my_id] = mine;
-    }
-    __syncthreads();
-    // ---- 3. coefficient matrix: lane (box, corner) adds its two taps (ds_add_f32, twice per tile)
-#pragma unroll
-    for (int k = 0; k < kCacheBoxes; ++k) L.coef[lane][k] = 0.0f;
-    __syncthreads();
-    if (vis && cached) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ri = corner >> 1, ci = 2 * (corner & 1) + i, k = (ri & 1) * 2 + (ci & 1);
-            const bool top = ri < 2, left = ci < 2;
-            auto pick = [&](const float(&a)[4]) { return k == 0 ? a[0] : (k == 1 ? a[1] : (k == 2 ? a[2] : a[3])); };
-            const float wt = top ? (left ? pick(rec.w.lt) : pick(rec.w.rt)) : (left ? pick(rec.w.lb) : pick(rec.w.rb));
-            atomicAdd(&L.coef[L.ids[myh[i]]][b], (top == left ? wt : -wt) / rec.w.area);
-        }
-    }
-    __syncthreads();
-
-    if (cached) {
-        // ---- 4. lane = channel (+ 64 q): gradients of the tile in registers, one atomic row per distinct tap and slice
-        const unsigned long long vis_mask = __ballot(vis); // lane 8 b .. 8 b + 7 = box b
-        float gv[kCacheBoxes][kCachePasses];
-#pragma unroll
-        for (int bb = 0; bb < kCacheBoxes; ++bb) {
-            const bool on = (vis_mask >> (8 * bb)) & 1ull; // masked voxels pass no gradient (and may hold anything)
-#pragma unroll
-            for (int q = 0; q < kCachePasses; ++q)
-                gv[bb][q] = on ? *reinterpret_cast<const float *>(gv_tile + (size_t)bb * box_pitch + q * 256 + lane * 4) : 0.0f;
-        }
-        for (int i = 0; i < n_slots; ++i) {
-            const float4 c0 = *reinterpret_cast<const float4 *>(&L.coef[i][0]);
-            const float4 c1 = *reinterpret_cast<const float4 *>(&L.coef[i][4]);
-            float *dst = reinterpret_cast<float *>(gimg + L.slot_key[i]) + lane;
-#pragma unroll
-            for (int q = 0; q < kCachePasses; ++q) {
-                float a = c0.x * gv[0][q];
-                a = fmaf(c0.y, gv[1][q], a); a = fmaf(c0.z, gv[2][q], a); a = fmaf(c0.w, gv[3][q], a);
-                a = fmaf(c1.x, gv[4][q], a); a = fmaf(c1.y, gv[5][q], a); a = fmaf(c1.z, gv[6][q], a);
-                a = fmaf(c1.w, gv[7][q], a);
-                unsafeAtomicAdd(dst + q * kWave, a);
-            }
-        }
-        return;
-    }
-    // ---- fallback (more distinct taps than slots): per-box global atomics, lanes = 64 channels x 4 sweeps
-    for (int j = 0; j < nb; ++j) {
-        const BoxRec &rc = L.recs[j];
-        if (!(uniform_i(rc.h.flags) & 1)) continue;
-        const BoxWeights w = rc.w;
-        const float *gvox = reinterpret_cast<const float *>(gv_tile + (size_t)j * box_pitch);
-        for (int c = lane; c < d.C; c += kWave) {
-            const float gv = gvox[c] / w.area;
-            auto add = [&](int ry, int cx, float wt) {
-                unsafeAtomicAdd(reinterpret_cast<float *>(gimg + (rc.h.row[ry] + rc.h.col[cx])) + c, gv * wt);
-            };
-            add(0, 0, w.lt[0]); add(0, 1, w.lt[1]); add(1, 0, w.lt[2]); add(1, 1, w.lt[3]);
-            add(2, 2, w.rb[0]); add(2, 3, w.rb[1]); add(3, 2, w.rb[2]); add(3, 3, w.rb[3]);
-            add(0, 2, -w.rt[0]); add(0, 3, -w.rt[1]); add(1, 2, -w.rt[2]); add(1, 3, -w.rt[3]);
-            add(2, 0, -w.lb[0]); add(2, 1, -w.lb[1]); add(3, 0, -w.lb[2]); add(3, 1, -w.lb[3]);
         }
     }
 }
@@ -1825,7 +1887,17 @@ int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, 
                                     int nl, int n_cells, int cell_begin, int cell_count, int conv_kind, float img_w,
                                     float img_h, float cmin, float cmax, int flags, void *stream)
 {
+    return vfa_project_gather_backward_grid_f32(grad_vox, calibs, grid, z_layers, corner_off, grad_integral, n_views, C, Hf, Wf, nl, n_cells,
+                                                cell_begin, cell_count, 0, conv_kind, img_w, img_h, cmin, cmax, flags, stream);
+}
+
+int vfa_project_gather_backward_grid_f32(const float *grad_vox, const float *calibs, const float *grid, const float *z_layers,
+                                         const float *corner_off, float *grad_integral, int n_views, int C, int Hf, int Wf,
+                                         int nl, int n_cells, int cell_begin, int cell_count, int grid_w, int conv_kind, float img_w,
+                                         float img_h, float cmin, float cmax, int flags, void *stream)
+{
     const int accumulate = flags & VFA_BWD_ACCUMULATE;
+    if (grid_w < 0 || (grid_w > 0 && n_cells % grid_w != 0)) return VFA_ERR_BAD_ARGUMENT;
     if (flags & ~(VFA_BWD_ACCUMULATE | VFA_VOX_KERNEL_DIRECT | VFA_VOX_KERNEL_TAP_CACHE)) return VFA_ERR_BAD_ARGUMENT;
     if (n_views < 0 || C <= 0 || Hf <= 0 || Wf <= 0 || nl <= 0 || n_cells < 0 || cell_begin < 0 || cell_count < 0 ||
         cell_begin + cell_count > n_cells || conv_kind < 0 || conv_kind > 2)
@@ -1845,11 +1917,19 @@ int vfa_project_gather_backward_f32(const float *grad_vox, const float *calibs, 
     d.n_boxes = (long long)n_views * cell_count * nl;
     if (d.n_boxes == 0) return 0;
     if (C == 256 && !(flags & VFA_VOX_KERNEL_DIRECT)) {
-        const long long tiles = (long long)n_views * nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes);
-        if (tiles >= (1ll << 31) - 8) return VFA_ERR_BAD_ARGUMENT;
+        long long blocks_per_layer = (cell_count + kBwdBoxes - 1) / kBwdBoxes; // cell blocks of a (view, layer)
+        d.grid_w = grid_w; d.tile_row0 = 0; d.tiles_x = 0;
+        if (grid_w > 0 && cell_count > 0) { // patches of 4 x 8 cells: every patch the range [cell_begin, cell_begin + cell_count) touches
+            const int row_a = cell_begin / grid_w, row_b = (cell_begin + cell_count - 1) / grid_w;
+            d.tile_row0 = row_a / 4;
+            d.tiles_x = (grid_w + 7) / 8;
+            blocks_per_layer = (long long)(row_b / 4 - d.tile_row0 + 1) * d.tiles_x;
+        }
+        const long long tiles = (long long)n_views * nl * blocks_per_layer;
+        if (tiles >= (1ll << 31) - 8 || blocks_per_layer * nl >= (1ll << 31)) return VFA_ERR_BAD_ARGUMENT;
         d.per_xcd = (tiles + 7) / 8;
         d.n_tiles = (unsigned)tiles;
-        d.tiles_per_view = make_fastdiv((unsigned)(nl * ((cell_count + kCacheBoxes - 1) / kCacheBoxes)));
+        d.tiles_per_view = make_fastdiv((unsigned)(nl * blocks_per_layer));
         d.layers = make_fastdiv((unsigned)nl);
         hipLaunchKernelGGL(gather_backward_cached_kernel, dim3((unsigned)(d.per_xcd * 8)), dim3(kWave), 0, s, grad_vox, g, d,
                            grad_integral);

@@ -349,9 +349,11 @@ def project_gather_ws(integral, calibs, grid_flat, z_layers, corner_off, conv_ki
 
 
 def project_gather_backward(grad_vox, integral_shape, calibs, grid_flat, z_layers, corner_off, conv_kind, image_wh,
-                            crange=(-1, 0.95), cell_begin=0, cell_count=None, out=None, accumulate=False, kernel=None):
+                            crange=(-1, 0.95), cell_begin=0, cell_count=None, out=None, accumulate=False, kernel=None, grid_w=0):
     """d vox (n, cell_count, nl*C) layer-major -> d integral (n, Hf+2, Wf+2, C) by scatter-add (float atomics).
-    ``kernel="direct"`` selects the per-box atomic kernel instead of the LDS-privatised one (C = 256)."""
+    ``kernel="direct"`` selects the per-box atomic kernel instead of the LDS-privatised one (C = 256).  ``grid_w``: cells per row of
+    the ground grid the cells come from (row-major; 0 = unknown) -- the LDS-privatised scatter then works on patches of 4 x 8 cells
+    (``vfa_project_gather_backward_grid_f32``) instead of 32 cells in a line."""
     _lib.require_device(grad_vox, calibs, grid_flat, z_layers, corner_off, out)
     n, Hp, Wp, C = integral_shape
     n_cells, nl = grid_flat.shape[0], z_layers.numel()
@@ -360,9 +362,10 @@ def project_gather_backward(grad_vox, integral_shape, calibs, grid_flat, z_layer
     if out is None:
         out = torch.empty(tuple(integral_shape), dtype=torch.float32, device=grad_vox.device)
         accumulate = False
-    _launch("vfa_project_gather_backward_f32", _lib.ptr(grad_vox), _lib.ptr(calibs), _lib.ptr(grid_flat),
+    grid_w = int(grid_w) if grid_w and n_cells % int(grid_w) == 0 else 0
+    _launch("vfa_project_gather_backward_grid_f32", _lib.ptr(grad_vox), _lib.ptr(calibs), _lib.ptr(grid_flat),
             _lib.ptr(z_layers), _lib.ptr(corner_off), _lib.ptr(out), n, C, Hp - 2, Wp - 2, nl, n_cells, cell_begin,
-            cell_count, int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]),
+            cell_count, grid_w, int(conv_kind), float(image_wh[0]), float(image_wh[1]), float(crange[0]), float(crange[1]),
             (_lib.BWD_ACCUMULATE if accumulate else 0) | (_lib.VOX_KERNEL_DIRECT if kernel == "direct" else 0),
             _lib.current_stream_handle())
     return out

@@ -85,7 +85,7 @@ class _BoxPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, integral, calibs, grid_flat, z_layers, corner_off, geom, cell_begin, cell_count):
-        conv_kind, img_w, img_h, cmin, cmax = geom
+        conv_kind, img_w, img_h, cmin, cmax = geom[:5]
         vox = ops.project_gather(integral, calibs, grid_flat, z_layers, corner_off, conv_kind, (img_w, img_h),
                                  (cmin, cmax), cell_begin, cell_count, _lib.VOX_LAYER_MAJOR)
         ctx.save_for_backward(calibs, grid_flat, z_layers, corner_off)
@@ -95,9 +95,11 @@ class _BoxPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_vox):
         calibs, grid_flat, z_layers, corner_off = ctx.saved_tensors
-        (conv_kind, img_w, img_h, cmin, cmax), shape, cell_begin, cell_count = ctx.meta
+        geom, shape, cell_begin, cell_count = ctx.meta
+        conv_kind, img_w, img_h, cmin, cmax = geom[:5]
         grad_integral = ops.project_gather_backward(grad_vox, shape, calibs, grid_flat, z_layers, corner_off, conv_kind,
-                                                    (img_w, img_h), (cmin, cmax), cell_begin, cell_count)
+                                                    (img_w, img_h), (cmin, cmax), cell_begin, cell_count,
+                                                    grid_w=geom[5] if len(geom) > 5 else 0)
         return grad_integral, None, None, None, None, None, None, None
 
 
@@ -505,7 +507,7 @@ class _FusedFrameTrain(torch.autograd.Function):
                         g_vox = ops.grad_input(g2, w_lm).view(n, count, nl * C)
                         ops.project_gather_backward(g_vox, tuple(integral.shape), cal, grid_flat, z_layers, corner_off, conv_kind,
                                                     (img_w, img_h), crange, cell_begin=begin, cell_count=count, out=g_int,
-                                                    accumulate=True)
+                                                    accumulate=True, grid_w=grid.shape[-2] if grid.dim() >= 3 else 0)
                         del g_vox
                     del vox, g_lin
                 g_lats.append(ops.integral_image_backward(g_int) if need_lat else None)
@@ -638,7 +640,8 @@ class VFA(nn.Module):
         grid_flat = grid.reshape(-1, 3).to(dtype=torch.float32).contiguous()
         calibs = calibs.reshape(n, 12).to(dtype=torch.float32).contiguous()
         z_layers, corner_off = self._kernel_geometry(dev)
-        geom = (conv_kind, img_w, img_h, float(crange[0]), float(crange[1]))
+        # (+ the width of the ground grid: the backward scatter works on patches of 4 x 8 cells)
+        geom = (conv_kind, img_w, img_h, float(crange[0]), float(crange[1]), int(grid.shape[-2]) if grid.dim() >= 3 else 0)
         n_cells, nl = grid_flat.shape[0], self.num_grid_layer
 
         if n_cells == 0 or n == 0:
