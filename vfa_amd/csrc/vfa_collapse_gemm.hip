@@ -314,18 +314,42 @@ __global__ __launch_bounds__(kThreads) void collapse_gemm_kernel(const float *__
             // more than the product at K = 256
             long long cell0 = 0;
             if constexpr (MASK) cell0 = (long long)__builtin_amdgcn_readfirstlane((int)(row0 % ma.cells));
+            if constexpr (MASK) {
+                // The sixteen gradients of the lane FIRST, all in flight together, then the sixteen stores.  Written element by
+                // element -- load, compare, store under the `row < M` branch -- every load waited with vmcnt(0) for itself AND for
+                // the store in front of it: 64 dependent round trips per tile, ~95 000 cycles, 2.4 x the whole product (round 6:
+                // 436 -> see DESIGN.md section 4.5 us per bench scale).  The loads need no branch (a cell index is always in range).
+                // Offsets are 32-bit from uniform bases (the host checks the sizes): one register per address, none spilled.
+                float gq[16];
+                const unsigned lane_byte = (unsigned)(wave * 32 + r) * 4u;
+                const int cell0_i = (int)cell0, cells_i = (int)ma.cells; // (cells < 2^22: the host checks)
+                const char *gbase = reinterpret_cast<const char *>(ma.grad);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    int cell = cell0_i + row;
+                    cell = cell >= cells_i ? cell - cells_i : cell;
+                    gq[i] = *reinterpret_cast<const float *>(gbase + ((unsigned)cell * (unsigned)(kN * 4) + lane_byte));
+                }
+                char *otile = reinterpret_cast<char *>(lin + (size_t)row0 * kN); // (uniform)
+                const int rows_left = (int)(M - row0 < 32 ? M - row0 : 32);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const float pre_act = F16 ? acc[rb][i] : acc[rb][i] + bias_c; // (fp16 form: the bias is in the accumulator)
+                    const float o = (pre_act > 0.0f) ? gq[i] : 0.0f;
+                    if (row < rows_left) {
+                        *reinterpret_cast<float *>(otile + ((unsigned)row * (unsigned)(kN * 4) + lane_byte)) = o;
+                        gb += o;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (row0 + row < M) {
                     if constexpr (MASK) {
-                        long long cell = cell0 + row;
-                        cell = cell >= ma.cells ? cell - ma.cells : cell;
-                        const float g = ma.grad[(size_t)cell * kN + wave * 32 + r];
-                        const float pre_act = F16 ? acc[rb][i] : acc[rb][i] + bias_c; // (fp16 form: the bias is in the accumulator)
-                        const float o = (pre_act > 0.0f) ? g : 0.0f;
-                        orow[(size_t)row * kN] = o;
-                        gb += o;
                     } else {
                         // (fp16 form: back from the row's units 2^(ea + ew - shift): exact)
                         orow[(size_t)row * kN] = F16 ? acc[rb][i] * pow2f((shifted_tile ? (int)fa.shift[row0 + row] : 0) - (ea + ew)) : acc[rb][i];
@@ -437,7 +461,7 @@ extern "C" int vfa_collapse_gemm_relu_backward_f32(const float *vox, const float
 {
     if (n_views < 0 || !grad_out || !grad_lin) return VFA_ERR_BAD_ARGUMENT;
     if (n_views == 0 || cells == 0) return 0;
-    if (cells < 32 || cells >= (1ull << 31)) return VFA_ERR_UNSUPPORTED; // (a 32-row block wraps over the cells at most once)
+    if (cells < 32 || cells >= (1ull << 22)) return VFA_ERR_UNSUPPORTED; // (a 32-row block wraps over the cells at most once; 32-bit byte offsets into d out)
     const MaskArgs ma = {bias, grad_out, grad_bias, (long long)cells};
     return collapse_gemm_launch(vox, weight, grad_lin, workspace, workspace_bytes, (size_t)n_views * cells, K, N, flags, &ma, stream);
 }
@@ -457,7 +481,7 @@ extern "C" int vfa_collapse_gemm_relu_backward_f16_f32(const float *vox, const f
     if (n_views < 0 || !grad_out || !grad_lin || !feat_absmax || absmax_count <= 0 || (tile_any && !row_shift)) return VFA_ERR_BAD_ARGUMENT;
     if (flags & VFA_FLAG_TERMS_MASK & ~2) return VFA_ERR_BAD_ARGUMENT; // (terms 0 / 2: this entry point IS the fp16 form)
     if (n_views == 0 || cells == 0) return 0;
-    if (cells < 32 || cells >= (1ull << 31)) return VFA_ERR_UNSUPPORTED;
+    if (cells < 32 || cells >= (1ull << 22)) return VFA_ERR_UNSUPPORTED;
     const MaskArgs ma = {bias, grad_out, grad_bias, (long long)cells};
     const F16Args fa = {feat_absmax, absmax_count, nullptr, row_shift, tile_any};
     return collapse_gemm_launch(vox, weight, grad_lin, workspace, workspace_bytes, (size_t)n_views * cells, K, N, flags & ~VFA_FLAG_TERMS_MASK, &ma, stream, &fa);
