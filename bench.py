@@ -66,6 +66,7 @@ def parse():
     p.add_argument("--shipped-steps", type=int, default=3,
                    help="timed blocks' steps of the `shipped_configs` leg: the reference's three shipped configs (vfa/config.py:5-85), "
                         "all through pipe_kernel (0 disables)")
+    p.add_argument("--train-steps", type=int, default=5, help="timed steps of the training_step leg: forward + backward of the bench frame (0 disables)")
     p.add_argument("--rotate", type=int, default=4, help="input sets of the rotating-input leg (0 disables)")
     p.add_argument("--fp32-steps", type=int, default=20, help="timed steps of the fp32-arithmetic collapse leg (0 disables)")
     p.add_argument("--proxy-steps", type=int, default=20, help="timed steps of the per-rank proxy legs (0 disables)")
@@ -861,6 +862,49 @@ def main():
         extra["shipped_configs"] = dict(shipped, note="the reference's shipped configs (vfa/config.py:5-85), one GPU, whole frame per step (integral images + "
                                         "geometry + pipe_kernel), steps bracketed like `value`; roofline = the pipelined kernel, HIP events around every launch; "
                                         "frac_of_survey_hbm_roofline = value / (units per frame / (SURVEY Appendix C algorithmic bytes / 8 TB/s))")
+    # ---- the training step of the reference's trainer (trainer.py:41: loss.backward() through the aggregate): forward + backward of the
+    # bench frame through the fused autograd node, a handful of steps, with the time of every entry point
+    if a.train_steps > 0 and world == 1 and a.workload == PRIMARY and a.channels == 256:
+        import vfa_amd
+        from vfa_amd.synthetic import make_workload
+        twl = make_workload(PRIMARY, channels=256, seed=0)
+        tn = twl["n_cam"]
+        torch.manual_seed(0)
+        tmods = [vfa_amd.VFA(256, grid_height=twl["grid_height"], cube_size=twl["cube_size"], args=twl["args"]).to(dev) for _ in range(3)]
+        tlats = [torch.cat([twl["features"][c][s] for c in range(tn)]).to(dev).requires_grad_(True) for s in range(3)]
+        tcal, tgrid = twl["calibs"].to(dev), twl["grid"].to(dev)
+
+        def train_step():
+            out = vfa_amd.aggregate_views(*tmods, *tlats, tcal, tgrid)
+            out.square().mean().backward()
+            for t in tlats:
+                t.grad = None
+            for m in tmods:
+                m.zero_grad(set_to_none=True)
+
+        for _ in range(2):
+            train_step()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.train_steps):
+            train_step()
+        e1.record()
+        torch.cuda.synchronize()
+        ktt = ops.KernelTimer(every=1)  # (a second pass for the entry points: events around every call, not part of ms_per_step)
+        with ktt:
+            for _ in range(a.train_steps):
+                train_step()
+            torch.cuda.synchronize()
+        extra["training_step"] = {"workload": PRIMARY, "steps": a.train_steps, "ms_per_step": e0.elapsed_time(e1) / a.train_steps,
+                                  "peak_memory_gb": torch.cuda.max_memory_allocated() / 1e9,
+                                  "entry_points_ms_per_step": {k: v["ms"] / a.train_steps for k, v in ktt.summary().items()},
+                                  "note": "forward (the fused frame kernel) + backward (pooling again in cell chunks, the forward's own product "
+                                          "recomputed with the ReLU mask as its epilogue, the two gradient products, the scatter on 4 x 8 patches, "
+                                          "the integral images' adjoint) of loss = mean(out^2) w.r.t. features, collapse weights and biases; "
+                                          "HIP events around the steps; not `value`"}
+        del tmods, tlats, twl
     # ---- BASELINE.json configs[4]: synthetic 8 x 4K -> 512 x 512 x 32, cameras sharded over the ranks
     if a.c5_steps > 0 and a.workload == PRIMARY and a.channels == 256:
         c5 = Leg(C5, a, rank, world, dev, "strong")

@@ -86,3 +86,6 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert pr["8"]["cameras_of_rank0"] == 1 and pr["2"]["cameras_of_rank0"] == 4 and pr["1"]["ms_per_frame"] > pr["8"]["ms_per_frame"] > 0
     pf = line["producer_f3"]  # the producer in front of the path (f3): hand-written lateral branch against the library's operations
     assert 0 < pf["hand_written_ms_per_frame"] < pf["library_ms_per_frame"] and pf["cameras"] == 7
+    ts = line["training_step"]  # forward + backward of the bench frame through the fused autograd node (f2)
+    assert ts["ms_per_step"] > 0 and ts["steps"] == 5 and "vfa_project_gather_backward_grid_f32" in ts["entry_points_ms_per_step"]
+    assert "vfa_collapse_gemm_relu_backward_f16_f32" in ts["entry_points_ms_per_step"]
