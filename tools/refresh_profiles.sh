@@ -12,7 +12,7 @@ python3 -c "import torch" >/dev/null 2>&1
 timeout -s KILL 700 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 timeout -s KILL 300 python3 bench.py --workload multiviewc_156x156x5 --cpu-seconds 0 > "$OUT/bench_mc5.json" 2>> "$OUT/bench.err"
 cd /tmp
-SHORT="--cpu-seconds 0 --steps 5 --warmup 2 --fp32-steps 0 --c5-steps 0 --rotate 0 --proxy-steps 0 --loop-steps 0"
+SHORT="--cpu-seconds 0 --steps 5 --warmup 2 --fp32-steps 0 --c5-steps 0 --rotate 0 --proxy-steps 0 --loop-steps 0 --train-steps 0"
 timeout -s KILL 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --cpu-seconds 0 --proxy-steps 0 --loop-steps 0 > "$OUT/trace.log" 2>&1
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace5" -- python3 "$R/bench.py" --workload multiviewc_156x156x5 --cpu-seconds 0 --fp32-steps 0 --rotate 0 --proxy-steps 0 --loop-steps 0 > "$OUT/trace5.log" 2>&1
 for W in multiviewc_200x200x1 multiviewc_156x156x5; do
@@ -24,7 +24,7 @@ done
 i=0
 while read -r SET; do
   i=$((i+1))
-  timeout -s KILL 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/sq$i" -- python3 "$R/bench.py" --fp32-steps 3 --cpu-seconds 0 --steps 5 --warmup 2 --c5-steps 0 --rotate 0 --proxy-steps 0 --loop-steps 0 > "$OUT/sq$i.log" 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc $SET --output-format csv -d "$OUT/sq$i" -- python3 "$R/bench.py" --fp32-steps 3 --train-steps 0 --cpu-seconds 0 --steps 5 --warmup 2 --c5-steps 0 --rotate 0 --proxy-steps 0 --loop-steps 0 > "$OUT/sq$i.log" 2>&1
 done <<'SETS'
 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES

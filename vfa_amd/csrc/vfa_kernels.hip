@@ -791,7 +791,15 @@ struct BackwardLds {
     unsigned slot_key[kBwdHash];
     unsigned char ids[kBwdHash];
     float coef[kBwdHash][kBwdBoxes];
+    unsigned vis_bits;  // what wave 0 found for the other wave of the tile: visible boxes,
+    int n_slots;        // distinct taps,
+    int status;         // 0 = go, 1 = nothing visible, 2 = more distinct taps than hash entries
 };
+// waves per tile: wave 0 builds the tile's tables, all run the channel loop, a 64-channel slice each (the tile's 21 KB of LDS leave seven
+// tiles per CU: with one wave each the scatter ran at half the rate -- bench frame 600 / 335 / 224 us per scale, now 550 / 215 / 160)
+constexpr int kBwdWaves = 4;
+// (wave 0's steps follow each other through LDS: instructions of one wave reach the LDS in order; the compiler must keep them so)
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // where the boxes of a tile sit: box b = (row b >> tw_shift, column b & (2^tw_shift - 1)) of the tile; its cell, local to the
 // processed range, is base_local + row * row_stride + column -- valid inside [0, cell_count) and left of the grid's right edge
 struct BwdTile {
@@ -812,8 +820,9 @@ __device__ __forceinline__ bool gather_backward_tile(BackwardLds &L, const BoxGe
 {
     constexpr int kPasses = NB / 8; // (box, corner) passes of the wave over the tile
     static_assert(HASH == 64 || HASH == 128, "one or two hash entries per lane");
-    const int lane = threadIdx.x, b8 = lane >> 3, corner = lane & 7;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b8 = lane >> 3, corner = lane & 7;
     __syncthreads(); // (the LDS of a tile before this one is done with)
+    if (wave == 0) {
     // ---- 1. box parameters: lane = (box, corner), eight boxes per pass; the records go to LDS
     unsigned vis_bits = 0u; // bit b: box b is visible (wave-uniform)
 #pragma unroll
@@ -851,14 +860,16 @@ __device__ __forceinline__ bool gather_backward_tile(BackwardLds &L, const BoxGe
 #pragma unroll
         for (int k = 0; k < 8; ++k) vis_bits |= (unsigned)((bal >> (8 * k)) & 1ull) << (8 * p + k);
     }
-    if (vis_bits == 0u) return true; // masked voxels pass no gradient
-#pragma unroll
-    for (int e = 0; e < HASH / kWave; ++e) L.tab[lane + kWave * e] = kEmptyKey;
-    __syncthreads();
-
-    // ---- 2. distinct taps of the tile: lane (box, corner) owns taps 2*corner and 2*corner + 1 of its box
+    int status = vis_bits == 0u ? 1 : 0; // (masked voxels pass no gradient)
+    int n_slots = 0;
     unsigned myh = 0u, myh2 = 0u; // hash entry of tap i of pass p: byte 2 p + i of myh (p < 2) / byte 2 (p - 2) + i of myh2
     bool overflow = false;
+    if (status == 0) {
+#pragma unroll
+    for (int e = 0; e < HASH / kWave; ++e) L.tab[lane + kWave * e] = kEmptyKey;
+    wave_lds_fence();
+
+    // ---- 2. distinct taps of the tile: lane (box, corner) owns taps 2*corner and 2*corner + 1 of its box
 #pragma unroll
     for (int p = 0; p < kPasses; ++p) {
         const int b = 8 * p + b8;
@@ -882,9 +893,10 @@ __device__ __forceinline__ bool gather_backward_tile(BackwardLds &L, const BoxGe
             }
         }
     }
-    __syncthreads();
-    if (__ballot(overflow) != 0ull) return false;
-    int n_slots = 0;
+    wave_lds_fence();
+    if (__ballot(overflow) != 0ull) status = 2;
+    }
+    if (status == 0) {
 #pragma unroll
     for (int e = 0; e < HASH / kWave; ++e) { // dense slot ids in entry order
         const unsigned mine = L.tab[lane + kWave * e];
@@ -902,7 +914,7 @@ __device__ __forceinline__ bool gather_backward_tile(BackwardLds &L, const BoxGe
     for (int e = 0; e < HASH / kWave; ++e)
 #pragma unroll
         for (int k = 0; k < NB; ++k) L.coef[lane + kWave * e][k] = 0.0f;
-    __syncthreads();
+    wave_lds_fence();
 #pragma unroll
     for (int p = 0; p < kPasses; ++p) {
         const int b = 8 * p + b8;
@@ -919,11 +931,17 @@ __device__ __forceinline__ bool gather_backward_tile(BackwardLds &L, const BoxGe
             }
         }
     }
+    }
+    if (lane == 0) { L.vis_bits = vis_bits; L.n_slots = n_slots; L.status = status; }
+    } // (wave 0)
     __syncthreads();
+    const int status = uniform_i(L.status), n_slots = uniform_i(L.n_slots);
+    const unsigned vis_bits = (unsigned)uniform_i((int)L.vis_bits);
+    if (status) return status == 1;
 
     // ---- 4. lane = channel (+ 64 q): the gradients of a 64-channel slice in registers, one atomic row per distinct tap
     const char *gv_layer = gv_view + (size_t)layer * 1024;
-    for (int q = 0; q < kCachePasses; ++q) {
+    for (int q = wave; q < kCachePasses; q += kBwdWaves) {
         float gv[NB];
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) { // masked voxels pass no gradient (and may hold anything)
@@ -945,11 +963,10 @@ __device__ __forceinline__ bool gather_backward_tile(BackwardLds &L, const BoxGe
     return true;
 }
 
-__global__ __launch_bounds__(kWave) void gather_backward_cached_kernel(const float *__restrict__ grad_vox, BoxGeom g,
-                                                                      GatherDims d, float *__restrict__ grad_integral)
+__global__ __launch_bounds__(kWave * kBwdWaves) void gather_backward_cached_kernel(const float *__restrict__ grad_vox, BoxGeom g,
+                                                                                  GatherDims d, float *__restrict__ grad_integral)
 {
     __shared__ BackwardLds L;
-    const int lane = threadIdx.x;
     // Tiles are numbered (view, cell block, layer) so that tiles running side by side touch the same image columns.
     const unsigned tile = (blockIdx.x & 7u) * (unsigned)d.per_xcd + (blockIdx.x >> 3); // xcd_contiguous, 32-bit
     if (tile >= d.n_tiles) return;
@@ -983,7 +1000,7 @@ __global__ __launch_bounds__(kWave) void gather_backward_cached_kernel(const flo
             if (!(uniform_i(rc.h.flags) & 1)) continue;
             const BoxWeights w = rc.w;
             const float *gvox = reinterpret_cast<const float *>(gv_view + (size_t)ts.local_of(j, d.cell_count) * box_pitch + (size_t)layer * 1024);
-            for (int c = lane; c < d.C; c += kWave) {
+            for (int c = threadIdx.x; c < d.C; c += kWave * kBwdWaves) {
                 const float gv = gvox[c] / w.area;
                 auto add = [&](int ry, int cx, float wt) {
                     unsafeAtomicAdd(reinterpret_cast<float *>(gimg + (rc.h.row[ry] + rc.h.col[cx])) + c, gv * wt);
@@ -1931,7 +1948,7 @@ int vfa_project_gather_backward_grid_f32(const float *grad_vox, const float *cal
         d.n_tiles = (unsigned)tiles;
         d.tiles_per_view = make_fastdiv((unsigned)(nl * blocks_per_layer));
         d.layers = make_fastdiv((unsigned)nl);
-        hipLaunchKernelGGL(gather_backward_cached_kernel, dim3((unsigned)(d.per_xcd * 8)), dim3(kWave), 0, s, grad_vox, g, d,
+        hipLaunchKernelGGL(gather_backward_cached_kernel, dim3((unsigned)(d.per_xcd * 8)), dim3(kWave * kBwdWaves), 0, s, grad_vox, g, d,
                            grad_integral);
         return launch_status();
     }
