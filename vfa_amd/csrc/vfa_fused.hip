@@ -374,22 +374,38 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(ChunkArgs a)
     // This kernel runs beside the bandwidth-bound integral-image kernels, where every dependent memory round trip costs
     // microseconds: everything a tile needs is requested at once and -- for the first two tiles of a thread, i.e. all of
     // them up to 2048 tiles -- kept in registers for the second walk.
-    auto load_tile = [&](int t) {
+    // (Every load UNCONDITIONAL, from a clamped scale / view group / tile, and masked afterwards: written under `s < n_scales` and
+    // `t0 < t1` the loads of a thread came out as a chain -- masks of scale 0, wait, costs of scale 0, masks of scale 1, ... for the
+    // first tile, then the same for the second: twelve dependent round trips beside a bandwidth-bound kernel, most of this kernel's
+    // 33 us -- round 6)
+    struct RawTile { unsigned lv[kMaxScales], ov[kMaxScales]; uint4 q[kMaxScales][G]; };
+    auto load_raw = [&](int t) {
+        RawTile rt;
+#pragma unroll
+        for (int s = 0; s < kMaxScales; ++s) {
+            const bool on = s < a.n_scales;
+            const unsigned *lp = on ? a.live[s] : a.live[0], *op = on ? a.overflow[s] : a.overflow[0];
+            rt.lv[s] = lp[t]; rt.ov[s] = op[t];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int gg = g * 8 < a.n_views ? g : 0;
+                rt.q[s][g] = *reinterpret_cast<const uint4 *>(a.item_w + ((size_t)t * kMaxScales + (on ? s : 0)) * a.views_pad + 8 * gg);
+            }
+        }
+        return rt;
+    };
+    auto finish_tile = [&](const RawTile &rt) {
         TileItems ti;
 #pragma unroll
         for (int s = 0; s < kMaxScales; ++s) {
-            unsigned lv = 0, ov = 0;
-            if (s < a.n_scales) { lv = a.live[s][t]; ov = a.overflow[s][t]; }
+            const bool on = s < a.n_scales;
+            ti.m[s] = on ? rt.lv[s] & ~rt.ov[s] & view_mask : 0u; // (the items of the main launch: live, minus the direct ones without a row slot)
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                ti.q[s][g] = make_uint4(0u, 0u, 0u, 0u);
-                if (s < a.n_scales && g * 8 < a.n_views)
-                    ti.q[s][g] = *reinterpret_cast<const uint4 *>(a.item_w + ((size_t)t * kMaxScales + s) * a.views_pad + 8 * g);
-            }
-            ti.m[s] = lv & ~ov & view_mask; // (the items of the main launch: live, minus the direct ones without a row slot)
+            for (int g = 0; g < G; ++g) ti.q[s][g] = (!on || g * 8 >= a.n_views) ? make_uint4(0u, 0u, 0u, 0u) : rt.q[s][g];
         }
         return ti;
     };
+    auto load_tile = [&](int t) { return finish_tile(load_raw(t)); };
     // walks the items of a tile in kernel order; `visit(k, w0, w1)`: item k covers the positions [w0, w1) of the tile's weight
     auto walk = [&](const TileItems &ti, auto &&visit) -> unsigned {
         unsigned w = 0;
@@ -418,8 +434,12 @@ __global__ __launch_bounds__(1024) void tile_chunks_kernel(ChunkArgs a)
         return k == 0 ? kEmpty : w;
     };
     TileItems c0 = {}, c1 = {};
-    if (kCache && t0 < t1) c0 = load_tile(t0);
-    if (kCache && t0 + 1 < t1) c1 = load_tile(t0 + 1);
+    if (kCache && n_tiles > 0) { // (clamped: a thread without tiles reads the last one and never looks at it; both tiles' loads first)
+        const RawTile r0 = load_raw(min(t0, n_tiles - 1)), r1 = load_raw(min(t0 + 1, n_tiles - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        c0 = finish_tile(r0);
+        c1 = finish_tile(r1);
+    }
     auto tile_of = [&](int t) { return (kCache && t == t0) ? c0 : (kCache && t == t0 + 1) ? c1 : load_tile(t); };
     unsigned long long local = 0;
     for (int t = t0; t < t1; ++t) local += walk(tile_of(t), [](int, unsigned, unsigned) {});
@@ -1395,6 +1415,9 @@ __global__ __launch_bounds__(512) void pool_direct_kernel(PoolArgs a)
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[i][j] = *reinterpret_cast<const float4 *>(img + (size_t)(rws[i] * Wp + cls[j]) * kSlotBytes);
+        // (the sixteen loads stay in front of the arithmetic: left to itself the compiler kept 62 registers and two or three loads in
+        // flight, eight round trips per unit instead of one -- round 6)
+        __builtin_amdgcn_sched_barrier(0);
         const float4 lt = sample4(t[0][0], t[0][1], t[1][0], t[1][1], wt[0], wt[1], wt[2], wt[3]);
         const float4 rb = sample4(t[2][2], t[2][3], t[3][2], t[3][3], wt[4], wt[5], wt[6], wt[7]);
         const float4 rt = sample4(t[0][2], t[0][3], t[1][2], t[1][3], wt[8], wt[9], wt[10], wt[11]);
@@ -1458,6 +1481,9 @@ __global__ __launch_bounds__(512) void pool_rows_kernel(RowsArgs a)
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[i][j] = *reinterpret_cast<const float4 *>(img + (size_t)(rws[i] * Wp + cls[j]) * kSlotBytes);
+        // (the sixteen loads stay in front of the arithmetic: left to itself the compiler kept 62 registers and two or three loads in
+        // flight, eight round trips per unit instead of one -- round 6)
+        __builtin_amdgcn_sched_barrier(0);
         const float4 lt = sample4(t[0][0], t[0][1], t[1][0], t[1][1], wt[0], wt[1], wt[2], wt[3]);
         const float4 rb = sample4(t[2][2], t[2][3], t[3][2], t[3][3], wt[4], wt[5], wt[6], wt[7]);
         const float4 rt = sample4(t[0][2], t[0][3], t[1][2], t[1][3], wt[8], wt[9], wt[10], wt[11]);
