@@ -4,6 +4,7 @@
 // cost walk (walk_run) equals the generator's (walk_groups).  Built and run by tests/test_pipe_seq.py.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <map>
 #include <random>
 #include <tuple>
@@ -90,6 +91,21 @@ int main(int argc, char **argv)
             const int n_gen = walk_groups(n_scales, rt, 0, mask,
                                           [&](int, int s, unsigned, int nj, int) { if (s == last_scale && last_nj != 4) std::abort(); last_scale = s; last_nj = nj; });
             CHECK(n_cost == n_gen && groups_of_run(n_scales, rt, mask) == n_gen);
+            // the walk by scale (what the cuts kernel runs: a thread per (run, scale)) lists the same groups with the same cost intervals
+            auto cost = [&](int s, int off, int v) { return subcost[((size_t)s * n_tiles + r * rt + off) * n_views + v]; };
+            std::vector<std::pair<unsigned, unsigned>> by_run, by_scale;
+            const int tiles = std::min(rt, n_tiles - r * rt);
+            const unsigned w_run = walk_run(n_scales, rt, nl, tiles, mask, cost, [&](int, unsigned w0, unsigned w1) { by_run.push_back({w0, w1}); });
+            unsigned w_scales = 0;
+            bool first = true;
+            for (int s = 0; s < n_scales; ++s) {
+                const unsigned base = w_scales;
+                const unsigned ws = walk_scale(rt, nl, tiles, s, first, mask, cost, [&](int, unsigned w0, unsigned w1) { by_scale.push_back({base + w0, base + w1}); });
+                if (ws) first = false;
+                w_scales += ws;
+            }
+            CHECK(by_run == by_scale);
+            CHECK(n_gen == 0 ? w_run == kEmptyCost * (unsigned)tiles : w_run == w_scales);
         }
         std::vector<int> start, rank;
         serial_cuts(live, subcost, n_tiles, n_views, n_scales, nl, rt, n_chunks, start, rank);

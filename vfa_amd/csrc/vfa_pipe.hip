@@ -319,10 +319,18 @@ struct CutArgs {
     unsigned long long *chunk_cost; // (kChunks + 1): estimated cost of everything in front of the group boundary a piece starts at
     SplitArgs split;                // wmax_count > 0: the blocks behind block 0 leave the partial maxima of |W| (they need nothing of the frame)
     long long wmax_count;           // weights per scale
+    int staged;                     // 1: the launch has LDS for the masks and sub-tile costs of the whole frame (n_scales * n_tiles * (1 + n_views) words)
 };
+#ifdef VFA_CUTS_STAMPS
+__device__ unsigned long long g_cut_stamps[16];
+#define CUT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_cut_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CUT_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
 {
     __shared__ unsigned long long part[1024];
+    CUT_STAMP(0);
     if (blockIdx.x > 0) {
         // the partial maxima of max|W| (block 1 + scale * kWmaxParts + part), riding in this launch: as a launch of its own behind the
         // cuts (rounds 3-4) it was 13 us of the geometry stream's tail
@@ -342,26 +350,75 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
     }
     const int tid = threadIdx.x, n_tiles = a.n_tiles, rt = a.rt, n_runs = runs_of(n_tiles, rt);
     const unsigned view_mask = a.n_views >= 32 ? 0xffffffffu : ((1u << a.n_views) - 1u);
-    const int per = (n_runs + 1023) / 1024, r0 = min(n_runs, tid * per), r1 = min(n_runs, r0 + per);
-    // the masks and the sub-tile costs of a run (vector loads: L2 hits, the geometry pass has just written them)
+    // The masks and the sub-tile costs of the frame come into LDS first, all threads together, coalesced.  A thread walks its runs
+    // three times and asks for a mask or a cost where the walk needs it: out of global memory that is a chain of ~100 dependent
+    // round trips per run of four tiles -- 105 us for the Wildtrack frame, 54 for MultiviewX, 29 for 156 x 156 x 5 (round 6, when the
+    // sub-tile costs arrived; the masks alone: 18).  Frames whose tables do not fit (512 x 512 x 32: 221 KB per band) walk global memory.
+    extern __shared__ unsigned cut_stage[]; // [scale][tile] masks, then [scale][tile][view] costs
+    const size_t cost_base = (size_t)a.n_scales * n_tiles;
+    if (a.staged) {
+        for (int s2 = 0; s2 < a.n_scales; ++s2) { // (a loop per table: one flat loop with the table picked per word measured slower)
+            const unsigned *lv = s2 == 0 ? a.live[0] : (s2 == 1 ? a.live[1] : a.live[2]);
+            const unsigned *sc = s2 == 0 ? a.subcost[0] : (s2 == 1 ? a.subcost[1] : a.subcost[2]);
+            for (int t = tid; t < n_tiles; t += 1024) cut_stage[(size_t)s2 * n_tiles + t] = lv[t] & view_mask;
+            const int n_cost = n_tiles * a.n_views;
+            for (int i = tid; i < n_cost; i += 1024) cut_stage[cost_base + (size_t)s2 * n_cost + i] = sc[i];
+        }
+        __syncthreads();
+    }
+    CUT_STAMP(1);
     auto mask_of = [&](int r) {
         return [&, r](int s2, int off) -> unsigned {
             const int t = r * rt + off;
+            if (t >= n_tiles) return 0u;
+            if (a.staged) return cut_stage[(size_t)s2 * n_tiles + t];
             const unsigned *lv = s2 == 0 ? a.live[0] : (s2 == 1 ? a.live[1] : a.live[2]);
-            return t < n_tiles ? (lv[t] & view_mask) : 0u;
+            return lv[t] & view_mask;
         };
     };
     auto cost_of = [&](int r) {
         return [&, r](int s2, int off, int v) -> unsigned {
+            if (a.staged) return cut_stage[cost_base + ((size_t)s2 * n_tiles + (r * rt + off)) * a.n_views + v];
             const unsigned *sc = s2 == 0 ? a.subcost[0] : (s2 == 1 ? a.subcost[1] : a.subcost[2]);
             return sc[(size_t)(r * rt + off) * a.n_views + v];
         };
     };
+    // entries = (run, scale) in the kernel's order; a thread takes a contiguous range of them
+    const int n_entries = n_runs * a.n_scales, per_e = (n_entries + 1023) / 1024, e0 = min(n_entries, tid * per_e), e1 = min(n_entries, e0 + per_e);
+    struct RunInfo { int groups_before, n_groups; bool first_of_run; };
+    int info_run = -1, info_groups[kMaxScales] = {0, 0, 0}; // (the entries of a thread follow each other: mostly the same run)
+    auto run_info = [&](int r, int s2) { // what entry (r, s2) needs to know of the other scales of its run: their group counts
+        if (r != info_run) {
+            info_run = r;
+#pragma unroll
+            for (int s3 = 0; s3 < kMaxScales; ++s3) {
+                int cnt = 0;
+                if (s3 < a.n_scales)
+                    for (int off = 0; off < rt; ++off) cnt += seq_popc(mask_of(r)(s3, off));
+                info_groups[s3] = groups_of_count(cnt);
+            }
+        }
+        RunInfo ri = {0, 0, true};
+#pragma unroll
+        for (int s3 = 0; s3 < kMaxScales; ++s3) {
+            const int g = info_groups[s3];
+            if (s3 < s2) { ri.groups_before += g; if (g) ri.first_of_run = false; }
+            ri.n_groups += g;
+        }
+        return ri;
+    };
     unsigned long long local = 0;
-    for (int r = r0; r < r1; ++r) local += walk_run(a.n_scales, rt, a.nl, min(rt, n_tiles - r * rt), mask_of(r), cost_of(r), [](int, unsigned, unsigned) {});
+    for (int e = e0; e < e1; ++e) {
+        const int r = e / a.n_scales, s2 = e - r * a.n_scales, tiles = min(rt, n_tiles - r * rt);
+        const RunInfo ri = run_info(r, s2);
+        if (ri.n_groups == 0) local += s2 == 0 ? kEmptyCost * (unsigned)tiles : 0u; // (a run without items: its cost sits in its first entry)
+        else local += walk_scale(rt, a.nl, tiles, s2, ri.first_of_run, mask_of(r), cost_of(r), [](int, unsigned, unsigned) {});
+    }
     part[tid] = local;
+    CUT_STAMP(2);
     for (int c = tid; c <= kChunks; c += 1024) { a.chunk_start[c] = n_runs; a.chunk_rank[c] = 0; a.chunk_cost[c] = ~0ull; }
     __syncthreads();
+    CUT_STAMP(3);
     for (int d = 1; d < 1024; d <<= 1) {
         const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
         __syncthreads();
@@ -369,30 +426,40 @@ __global__ __launch_bounds__(1024) void pipe_cuts_kernel(CutArgs a)
         __syncthreads();
     }
     const unsigned long long total = part[1023];
+    CUT_STAMP(4);
     if (tid == 0) { a.chunk_start[kSigAt] = (int)(unsigned)total; a.chunk_start[kSigAt + 1] = (int)(unsigned)(total >> 32); }
     // (pieces behind the last group keep chunk_cost = ~0: the balance kernel reads them as `total`)
     unsigned long long before = part[tid] - local;
     auto pos_of = [&](long long cc) { return (total * (unsigned long long)cc + kChunks - 1) / kChunks; };
-    for (int r = r0; r < r1; ++r) {
-        const unsigned long long tb = before;
+    for (int e = e0; e < e1; ++e) {
+        const int r = e / a.n_scales, s2 = e - r * a.n_scales, tiles = min(rt, n_tiles - r * rt);
+        const RunInfo ri = run_info(r, s2);
+        const unsigned long long tb = before; // cost of everything in front of this entry
         long long c = tb > 0 ? (long long)((tb - 1) * kChunks / total) : 0;
         while (c < kChunks && pos_of(c) < tb) ++c;
-        const int n_groups = groups_of_run(a.n_scales, rt, mask_of(r));
-        const unsigned w = walk_run(a.n_scales, rt, a.nl, min(rt, n_tiles - r * rt), mask_of(r), cost_of(r), [&](int kk, unsigned w0, unsigned w1) {
-            while (c < kChunks) {
-                const unsigned long long pc = pos_of(c);
-                if (pc >= tb + w1) break;
-                const int k = ((unsigned)(pc - tb) - w0) * 2 < (w1 - w0) ? kk : kk + 1;
-                if (k >= n_groups) { a.chunk_start[c] = r + 1 < n_runs ? r + 1 : n_runs; a.chunk_rank[c] = 0; }
-                else { a.chunk_start[c] = r; a.chunk_rank[c] = k; }
-                a.chunk_cost[c] = tb + (k == kk ? w0 : w1);
-                ++c;
-            }
-        });
-        if (n_groups == 0)
+        unsigned w = 0;
+        if (ri.n_groups == 0) {
+            w = s2 == 0 ? kEmptyCost * (unsigned)tiles : 0u;
             for (; c < kChunks && pos_of(c) < tb + w; ++c) { a.chunk_start[c] = r; a.chunk_rank[c] = 0; a.chunk_cost[c] = tb; }
+        } else {
+            w = walk_scale(rt, a.nl, tiles, s2, ri.first_of_run, mask_of(r), cost_of(r), [&](int j, unsigned w0, unsigned w1) {
+                const int kk = ri.groups_before + j; // rank of the group in its run
+                while (c < kChunks) {
+                    const unsigned long long pc = pos_of(c);
+                    if (pc >= tb + w1) break;
+                    const int k = ((unsigned)(pc - tb) - w0) * 2 < (w1 - w0) ? kk : kk + 1;
+                    if (k >= ri.n_groups) { a.chunk_start[c] = r + 1 < n_runs ? r + 1 : n_runs; a.chunk_rank[c] = 0; }
+                    else { a.chunk_start[c] = r; a.chunk_rank[c] = k; }
+                    a.chunk_cost[c] = tb + (k == kk ? w0 : w1);
+                    ++c;
+                }
+            });
+        }
         before += w;
     }
+    CUT_STAMP(5);
+    __syncthreads();
+    CUT_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1931,6 +1998,9 @@ inline bool dims_ok(int n_views, int L, int W, int nl, int n_scales)
 } // namespace
 
 extern "C" {
+#ifdef VFA_CUTS_STAMPS
+int vfa_debug_cut_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cut_stamps), sizeof(unsigned long long) * 16); }
+#endif
 
 size_t vfa_pipe_workspace_bytes(int n_views, int L, int W, int n_layers, int n_scales)
 {
@@ -2039,7 +2109,14 @@ int vfa_pipe_cuts_f32(int n_views, int L, int W, int n_layers, int n_scales, con
         if (sa.f16) ca.wmax_count = (long long)kC * kC * n_layers; // the partial maxima: spare blocks of the cuts launch
     }
     ca.split = sa;
-    hipLaunchKernelGGL(pipe_cuts_kernel, dim3(1 + (ca.wmax_count ? kWmaxParts * n_scales : 0)), dim3(1024), 0, s, ca);
+    // the frame's masks and sub-tile costs in LDS where they fit beside the scan's 8 KB (static)
+    const size_t stage_bytes = (size_t)n_scales * lay.n_tiles * (1 + (size_t)n_views) * 4;
+    ca.staged = stage_bytes <= 144 * 1024 ? 1 : 0;
+    if (ca.staged) {
+        const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(pipe_cuts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        if (e0 != hipSuccess) return (int)e0;
+    }
+    hipLaunchKernelGGL(pipe_cuts_kernel, dim3(1 + (ca.wmax_count ? kWmaxParts * n_scales : 0)), dim3(1024), ca.staged ? stage_bytes : 0, s, ca);
     int st = (int)hipGetLastError();
     if (st) return st;
     if (weights) {

@@ -254,6 +254,40 @@ VFA_SEQ_HD unsigned walk_run(int n_scales, int rt, int nl, int tiles, Mask &&mas
     return k == 0 ? kEmptyCost * (unsigned)tiles : w;
 }
 
+// The same by SCALE (the cuts kernel works on (run, scale) entries: a thread per entry instead of per run -- a run of four tiles and
+// seven views is ~85 sub-tiles of strictly serial code).  emit(j, subs, nj) for the j-th group of scale s; returns their number.
+template <class Mask, class Emit>
+VFA_SEQ_HD int walk_scale_groups(int rt, int s, Mask &&mask, Emit &&emit)
+{
+    int k = 0, nj = 0;
+    unsigned subs = 0;
+    for (int off = 0; off < rt; ++off) {
+        unsigned rest = mask(s, off);
+        while (rest) {
+            subs |= sub_byte(seq_ctz(rest), off) << (8 * nj);
+            rest &= rest - 1u;
+            if (++nj == kGroupViews) { emit(k, subs, nj); ++k; subs = 0; nj = 0; }
+        }
+    }
+    if (nj) { emit(k, subs, nj); ++k; }
+    return k;
+}
+// cost of the groups of scale s of a run, as walk_run counts them: `first_of_run` = no scale in front of s has a group (the run's
+// first group carries the tiles' cost); visit(j, w0, w1) = the j-th group of the scale covers [w0, w1) of the scale's cost
+template <class Mask, class SubCost, class Visit>
+VFA_SEQ_HD unsigned walk_scale(int rt, int nl, int tiles, int s, bool first_of_run, Mask &&mask, SubCost &&subcost, Visit &&visit)
+{
+    unsigned w = 0;
+    walk_scale_groups(rt, s, mask, [&](int j, unsigned subs, int nj) {
+        unsigned wi = (unsigned)nl * (kPhaseCost + (nj <= 2 ? kPhaseSmallExtra : 0u)) + kGroupCost;
+        for (int i = 0; i < nj; ++i) wi += subcost(s, sub_tile_off(subs, i), sub_view(subs, i));
+        if (j == 0 && first_of_run) wi += kTileCost * (unsigned)tiles;
+        visit(j, w, w + wi);
+        w += wi;
+    });
+    return w;
+}
+
 // groups of a run from its masks alone
 template <class Mask>
 VFA_SEQ_HD int groups_of_run(int n_scales, int rt, Mask &&mask)
