@@ -18,7 +18,9 @@ N >= 7; a rank without a camera contributes zeros), the partial maps are fused b
 are streamed and the all-reduce of frame i overlaps the projection of frame i+1.  The same line also carries
 `scaling_curve_c5`: BASELINE.json configs[4] (`synthetic4k_512x512x32`, 8 cameras x 4K, one camera per GPU at N = 8),
 measured the same way with fewer steps -- the configuration on which >= 6x at 8 GPUs is attainable.
-`--scaling weak` (every rank a full rig, grids summed) is kept as an option.
+`--scaling weak` (every rank a full rig, grids summed) is kept as an option.  Side legs at N = 1 (none of them `value`):
+`shipped_configs` (the reference's three shipped configs through the pipelined kernel), `training_step` (forward + backward of the
+bench frame through the fused autograd node), `per_rank_proxy`, `reference_loop`, `producer_f3`, the other arithmetic forms.
 
 Prints ONE JSON line on rank 0.
 """
