@@ -101,11 +101,15 @@ def test_aggregate_gradients_match_per_camera_loop():
         torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4 * b.abs().max().item())
 
 
-@pytest.mark.parametrize("workload,n_cam,cells", [("multiviewc_156x156x5", 2, (0, None)),
-                                                   ("multiviewc_200x200x1", 3, (0, None)),
-                                                   ("wildtrack_120x360x8", 2, (1003, 20011)),
-                                                   ("multiviewx_160x250x8", 2, (77, 13))])
-def test_lds_scatter_matches_atomic_scatter_and_is_the_adjoint(workload, n_cam, cells):
+@pytest.mark.parametrize("workload,n_cam,cells,crop", [("multiviewc_156x156x5", 2, (0, None), None),
+                                                        ("multiviewc_200x200x1", 3, (0, None), None),
+                                                        ("wildtrack_120x360x8", 2, (1003, 20011), None),
+                                                        ("multiviewx_160x250x8", 2, (77, 13), None),
+                                                        # a grid of 7 x 13 cells out of the middle of the field: patches cut by the grid's
+                                                        # right edge and its last rows, and a range that starts inside a patch
+                                                        ("multiviewc_200x200x1", 2, (5, 80), (7, 13)),
+                                                        ("multiviewc_156x156x5", 3, (0, None), (9, 5))])
+def test_lds_scatter_matches_atomic_scatter_and_is_the_adjoint(workload, n_cam, cells, crop):
     """C = 256 takes the LDS-privatised backward (`gather_backward_cached_kernel`).  Box pooling is linear in the
     integral image, so <pool(I), G> == <I, pool^T(G)> (a size-independent property), and the kernel agrees with the
     run-combined atomic scatter."""
@@ -119,7 +123,8 @@ def test_lds_scatter_matches_atomic_scatter_and_is_the_adjoint(workload, n_cam, 
     mod = vfa_amd.VFA(256, grid_height=wl["grid_height"], cube_size=wl["cube_size"], args=wl["args"]).to(dev)
     zl, co = mod._kernel_geometry(dev)
     calibs = wl["calibs"].reshape(n_cam, 12).to(dev)
-    grid = wl["grid"].reshape(-1, 3).to(dev)
+    grid4 = wl["grid"] if crop is None else wl["grid"][:, 60:60 + crop[0], 70:70 + crop[1]].contiguous()
+    grid = grid4.reshape(-1, 3).to(dev)
     kind, size = _lib.CONV_KIND[wl["args"].data], wl["args"].image_size[::-1]
     begin, count = cells
     count = grid.shape[0] - begin if count is None else count
@@ -134,7 +139,7 @@ def test_lds_scatter_matches_atomic_scatter_and_is_the_adjoint(workload, n_cam, 
     assert live.any()
     gvox = torch.where(live, gvox, torch.full_like(gvox, 1e30))  # masked voxels pass no gradient, whatever arrives
     grads = {}
-    gw = wl["grid"].shape[-2]  # cells per row of the ground grid: the scatter on 4 x 8 patches ("patches") instead of cells in a line
+    gw = grid4.shape[-2]  # cells per row of the ground grid: the scatter on 4 x 8 patches ("patches") instead of cells in a line
     for name, kern, w_ in (("lds", None, 0), ("patches", None, gw), ("atomics", "direct", 0)):  # per-call arguments, no library state
         grads[name] = ops.project_gather_backward(gvox, tuple(integral.shape), calibs, grid, zl, co, kind, size,
                                                   cell_begin=begin, cell_count=count, kernel=kern, grid_w=w_)
