@@ -380,6 +380,35 @@ def test_batched_integral_images_are_bitwise_the_per_map_ones(shapes, n, C):
         assert torch.equal(g.view(torch.int32), want.view(torch.int32)), tuple(f.shape)
 
 
+@pytest.mark.parametrize("shapes,n,C", [(((90, 160), (45, 80), (23, 40)), 7, 256),   # the bench frame: two column parts on the wide map
+                                        (((40, 300), (9, 36)), 4, 256),               # ten strips with a 12-column tail, a two-strip map
+                                        (((33, 64), (8, 4)), 8, 128)])                # one row past a batch; a map of one narrow strip
+def test_one_pass_integral_images_are_bitwise_the_per_map_ones(shapes, n, C):
+    """`integral_onepass_kernel` (frames of >= 64 (view, 16-channel block) units: the case above stays on the two-pass kernels) against
+    the per-map kernels the oracle pins -- BITWISE, borders included, and the SAME feature statistic; heavy-tailed inputs (double
+    sums that round would expose any re-association); plain and with the fused affine + ReLU; twice (nothing carried over)."""
+    from vfa_amd import ops
+    dev = _dev()
+    assert n * (C // 16) >= 64
+    gen = torch.Generator().manual_seed(len(shapes) * 1000 + C + n)
+    feats = []
+    for H, W in shapes:
+        f = torch.randn(n, C, H, W, generator=gen)
+        f = f * torch.exp(6 * torch.randn(n, C, H, W, generator=gen))
+        feats.append(f.to(dev))
+    scales = [(torch.rand(n, C, generator=gen) * 2 + 0.1).to(dev) for _ in shapes]
+    shifts = [(torch.randn(n, C, generator=gen) * 0.5).to(dev) for _ in shapes]
+    for affine in (False, True):
+        sc, sh = (scales, shifts) if affine else (None, None)
+        want = [ops.affine_relu_integral_image(f, a, b) if affine else ops.integral_image(f) for f, a, b in zip(feats, scales, shifts)]
+        for _ in range(2):
+            got = ops.integral_images(feats, sc, sh)
+            for f, g, w_, st, a, b in zip(feats, got, want, got.absmax, scales, shifts):
+                assert g.shape == w_.shape and torch.equal(g.view(torch.int32), w_.view(torch.int32)), (tuple(f.shape), affine)
+                x = torch.relu(f * a[:, :, None, None] + b[:, :, None, None]) if affine else f
+                assert int(st.max()) == int(x.abs().max().view(torch.int32)), (tuple(f.shape), affine)
+
+
 @pytest.mark.parametrize("row_slots", [0, 5])
 def test_direct_items_without_a_row_slot_take_the_second_launch(row_slots):
     """The workspace may be smaller than recommended: direct items (tap window larger than LDS) that find no pooled-row slot are
